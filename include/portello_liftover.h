@@ -1,0 +1,216 @@
+/*
+ * portello_liftover.h -- C ABI of the MI355X-native liftover engine.
+ *
+ * This is the drop-in boundary for portello's per-read CIGAR-composition hot path.  The reference has no FFI:
+ * the path is three `pub fn`s called synchronously, one (read segment x contig segment) pair at a time, from
+ *   get_liftover_alignment_for_read_and_contig_segment        src/read_alignment_scanner.rs:136-288
+ * inside scan_chromosome_segment (src/read_alignment_scanner.rs:369-492).  A Rust caller binds the functions
+ * below with `extern "C"`, keeps one `plo_ctx` per BamReaderWorkerThreadData
+ * (src/worker_thread_data.rs:8-18) and turns the per-record loop into: collect window -> one batch call ->
+ * finish records.
+ *
+ * Conventions
+ *   - every function returns a plo_status (0 = ok) and never unwinds; plo_last_error() gives a message;
+ *   - a plo_index is immutable after creation and may be shared by any number of contexts/threads;
+ *   - a plo_ctx is single-threaded (one per worker thread), owns one HIP stream, its workspaces and its
+ *     output buffers; output pointers stay valid until the next call on the same context;
+ *   - one *item* = one call of get_liftover_alignment_for_read_and_contig_segment, i.e. one
+ *     (read split segment x contig split segment) pair;
+ *   - CIGAR ops use the BAM encoding `len << 4 | op`, op in M0 I1 D2 N3 S4 H5 P6 =7 X8 (rust-htslib `Cigar`);
+ *   - all positions are 0-based; coordinates must fit the BAM 31-bit range (else PLO_ERR_RANGE);
+ *   - there is NO CPU fallback: without a usable HIP device every entry point fails with PLO_ERR_NO_DEVICE.
+ */
+#ifndef PORTELLO_LIFTOVER_H
+#define PORTELLO_LIFTOVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLO_API_VERSION 1
+
+typedef enum plo_status {
+    PLO_OK = 0,
+    PLO_ERR_INVALID_ARG = 1,
+    PLO_ERR_NO_DEVICE = 2,
+    PLO_ERR_HIP = 3,
+    PLO_ERR_OUT_OF_MEMORY = 4,
+    PLO_ERR_RANGE = 5,    /* coordinate outside the 31-bit BAM range or invalid CIGAR op code            */
+    PLO_ERR_INTERNAL = 6  /* device-side capacity exceeded even in the large-item path                  */
+} plo_status;
+
+/* Per-item result status.  The reference expresses these as Option::None / panic!:
+ *   LIFTED        Some(record)                                   src/read_alignment_scanner.rs:185,284
+ *   NO_LIFTOVER   liftover_read_alignment returned None           src/liftover_read_alignment.rs:218
+ *   LEN_MISMATCH  read length of lifted CIGAR != seq_len; the reference aborts   src/read_alignment_scanner.rs:204-229
+ *   PANIC         a sequence index would be out of bounds (Rust slice-index panic in
+ *                 simplify_alignment_indels.rs:58-60,74-77 / indel_breakend_homology.rs:38-39)          */
+enum {
+    PLO_ITEM_LIFTED = 0,
+    PLO_ITEM_NO_LIFTOVER = 1,
+    PLO_ITEM_LEN_MISMATCH = 2,
+    PLO_ITEM_PANIC = 3
+};
+
+/* Read-sequence encodings accepted at the boundary */
+enum {
+    PLO_SEQ_BAM4 = 0, /* BAM 4-bit packing, 2 bases per byte, high nibble first, code table "=ACMGRSVTWYHKDBN"
+                         (what bam::Record::seq() holds; decoded by as_bytes() at read_alignment_scanner.rs:170,238) */
+    PLO_SEQ_ASCII = 1 /* one byte per base */
+};
+
+/* Where the sequence / batch buffers of a descriptor live */
+enum {
+    PLO_MEM_HOST = 0,  /* host memory: the library copies to the device */
+    PLO_MEM_DEVICE = 1 /* device memory on the index's device: borrowed, caller keeps it alive */
+};
+
+/* Pipeline stages (bit mask).  PLO_STAGES_ALL reproduces get_liftover_alignment_for_read_and_contig_segment;
+ * subsets expose the individual reference functions so that they can be pinned against the reference's own
+ * known-answer tests. */
+enum {
+    PLO_STAGE_STRAND = 1u << 0,   /* caller glue src/read_alignment_scanner.rs:149-176: need_flipped, and for
+                                     reverse-mapped contig segments rev_pos + reversed CIGAR                     */
+    PLO_STAGE_LSHIFT = 1u << 1,   /* left_shift_indels (lib/rust-vc-utils/.../shift_indels/left_shift_indels.rs:17-39);
+                                     with STRAND: only items on reverse-mapped contig segments (as the reference),
+                                     without STRAND: every item, CIGAR/pos used as given, ref_seq = the contig's
+                                     rev_contig_seq                                                              */
+    PLO_STAGE_LIFTOVER = 1u << 2, /* liftover_read_alignment  src/liftover_read_alignment.rs:137-223            */
+    PLO_STAGE_LENCHECK = 1u << 3, /* seq_len == get_cigar_read_offset(cigar,false)  read_alignment_scanner.rs:204-229 */
+    PLO_STAGE_SIMPLIFY = 1u << 4, /* simplify_alignment_indels src/simplify_alignment_indels.rs:119-156,
+                                     ref_seq = reference[chrom_index of the contig segment]                      */
+    PLO_STAGES_ALL = 0x1f
+};
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Index: the contig->reference mapping consumed by phase 2, i.e. AllContigMappingInfo
+ * (src/contig_alignment_scanner/mod.rs:25-47,76) + the reference sequences (src/main.rs:24-62) + contig lengths
+ * (ChromList of the read->contig BAM, src/read_alignment_scanner.rs:163-164).
+ * plo_index_create builds, per contig segment, the block map of get_read_segment_to_ref_pos_tree_map
+ * (lib/rust-vc-utils/src/bam_utils/read_to_ref_map.rs:101-137, ignore_hard_clip = false as at
+ * contig_alignment_scanner/mod.rs:98-102) on the device and packs everything into HBM once.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct plo_index_desc {
+    /* contigs (index = tid in the read->contig BAM) */
+    uint32_t n_contigs;
+    const int64_t *contig_len;      /* [n_contigs] */
+    const uint32_t *contig_seg_off; /* [n_contigs+1] CSR into the segment arrays = ordered_contig_segment_info */
+
+    /* contig split segments, sequencing order within each contig (SeqOrderSplitReadSegment,
+       lib/rust-vc-utils/src/bam_utils/split_read.rs:15-32) */
+    uint32_t n_segments;
+    const uint32_t *seg_chrom_index;      /* reference chromosome the segment maps to            */
+    const int64_t *seg_pos;               /* 0-based reference start of the segment alignment    */
+    const uint8_t *seg_is_fwd_strand;     /* 1 = contig segment maps to the forward strand       */
+    const uint8_t *seg_mapq;
+    const int64_t *seg_seq_order_start;   /* seq_order_read_start (contig coordinates)           */
+    const int64_t *seg_seq_order_end;     /* seq_order_read_end                                  */
+    const uint32_t *seg_cigar_off;        /* [n_segments+1] CSR into seg_cigar                   */
+    const uint32_t *seg_cigar;            /* contig->reference CIGARs, BAM-encoded ops           */
+
+    /* reference chromosomes: `reference: &[Vec<u8>]` (upper-cased ASCII, src/main.rs:24-62) */
+    uint32_t n_chroms;
+    const int64_t *chrom_len;             /* [n_chroms] */
+    const uint8_t *const *chrom_seq;      /* [n_chroms] pointers (see seq_mem) */
+
+    /* ContigMappingInfo::rev_contig_seq (contig_alignment_scanner/mod.rs:113-125): ASCII, length contig_len,
+       NULL where the contig has no reverse-mapped segment */
+    const uint8_t *const *rev_contig_seq; /* [n_contigs] pointers or NULL array */
+
+    int32_t seq_mem;                      /* PLO_MEM_HOST or PLO_MEM_DEVICE for chrom_seq / rev_contig_seq */
+} plo_index_desc;
+
+typedef struct plo_index plo_index;
+typedef struct plo_ctx plo_ctx;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Batch input: a window of primary read records with their sequencing-order split segments
+ * (get_seq_order_read_split_segments output, read_alignment_scanner.rs:421).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct plo_batch_in {
+    /* reads = primary bam::Record's */
+    uint32_t n_reads;
+    const uint8_t *read_is_reverse;  /* [n_reads] record.is_reverse()                          */
+    const uint32_t *read_seq_len;    /* [n_reads] record.seq_len()                             */
+    const uint64_t *read_seq_off;    /* [n_reads] byte offset of the read's bases inside `seq` */
+    const uint8_t *seq;              /* all read bases, encoding `seq_fmt`                      */
+    uint64_t seq_bytes;              /* size of `seq` in bytes                                  */
+    int32_t seq_fmt;                 /* PLO_SEQ_BAM4 / PLO_SEQ_ASCII                            */
+
+    /* read split segments (SeqOrderSplitReadSegment) */
+    uint32_t n_segs;
+    const uint32_t *seg_read;        /* [n_segs] index of the owning read                      */
+    const uint32_t *seg_contig;      /* [n_segs] chrom_index = contig the segment is aligned to */
+    const int64_t *seg_pos;          /* [n_segs] 0-based position on the forward contig         */
+    const uint8_t *seg_is_fwd_strand;/* [n_segs]                                                */
+    const uint32_t *seg_cigar_off;   /* [n_segs+1] CSR into `cigar`                             */
+    const uint32_t *cigar;           /* read->contig CIGARs                                     */
+
+    /* Optional explicit item list.  NULL: the engine enumerates items itself with the overlap rule of
+       get_contig_split_segments_from_read_mapping (read_alignment_scanner.rs:80-103).  Non-NULL: item i pairs
+       read segment item_seg[i] with contig segment item_cseg[i] (index *within the contig's segment list*). */
+    uint32_t n_items;
+    const uint32_t *item_seg;
+    const uint32_t *item_cseg;
+} plo_batch_in;
+
+/* Batch output (SoA, one entry per item, ordered by (read segment, contig segment index)).
+ * plo_liftover_batch: pointers are host (pinned) memory owned by the context.
+ * plo_liftover_batch_dev: pointers are device memory owned by the context. */
+typedef struct plo_batch_out {
+    uint32_t n_items;
+    const uint32_t *item_seg;          /* read segment index                                                  */
+    const uint32_t *item_cseg;         /* contig_segment_index (as used in the PS tag, :257-262)              */
+    const uint8_t *item_status;        /* PLO_ITEM_*                                                          */
+    const uint8_t *item_need_flipped;  /* need_flipped_read_alignment (:153-157)                              */
+    const uint8_t *item_mapq;          /* contig segment MAPQ adopted by the record (:250-252)                */
+    const uint32_t *item_chrom_index;  /* tid of the lifted record (:232-247)                                 */
+    const int64_t *item_ref_pos;       /* lifted 0-based position (valid when LIFTED/LEN_MISMATCH)            */
+    const uint64_t *item_cigar_off;    /* offset of the item's CIGAR inside `cigar`                           */
+    const uint32_t *item_cigar_len;    /* number of ops                                                       */
+    const uint32_t *cigar;             /* lifted CIGARs                                                       */
+    uint64_t n_cigar;                  /* total ops stored in `cigar`                                         */
+} plo_batch_out;
+
+/* Per-call device timing measured with HIP events on the context's stream */
+typedef struct plo_timing {
+    float total_ms;      /* first kernel start -> last kernel end                                   */
+    float enumerate_ms;  /* item enumeration + scans                                                */
+    float lift_ms;       /* the fused strand/shift/liftover/simplify tile kernel (dominant kernel)   */
+    float big_ms;        /* large-item kernel (0 if not launched)                                   */
+    uint32_t n_items;
+    uint32_t n_big_items;
+    uint64_t n_in_ops;   /* input CIGAR ops over all items                                          */
+    uint64_t n_out_ops;  /* output CIGAR ops                                                        */
+    uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device */
+} plo_timing;
+
+plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);
+void plo_index_destroy(plo_index *index);
+/* number of block-map entries of contig segment `global_seg` (= contig_seg_off[contig] + i), and a copy of them
+   (keys = contig positions, vals = reference positions, INT64_MIN for None) for inspection/tests */
+plo_status plo_index_segment_map(const plo_index *index, uint32_t global_seg, uint32_t cap, int64_t *keys,
+                                 int64_t *vals, uint32_t *n_entries);
+
+/* `hip_stream`: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one */
+plo_status plo_ctx_create(const plo_index *index, void *hip_stream, plo_ctx **out);
+void plo_ctx_destroy(plo_ctx *ctx);
+
+/* Host buffers in, host (pinned, context-owned) buffers out; synchronous. */
+plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
+/* Device buffers in, device (context-owned) buffers out; returns after the result sizes are known, output is
+   complete on the context's stream (call plo_ctx_sync or synchronise the stream before reading it). */
+plo_status plo_liftover_batch_dev(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
+
+plo_status plo_ctx_sync(plo_ctx *ctx);
+plo_status plo_ctx_timing(plo_ctx *ctx, plo_timing *out);
+const char *plo_last_error(const plo_ctx *ctx);
+const char *plo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORTELLO_LIFTOVER_H */
