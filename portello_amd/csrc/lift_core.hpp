@@ -1,0 +1,1007 @@
+// lift_core.hpp -- the liftover tile algorithm, one wavefront per tile.
+//
+// A *tile* is up to 64 consecutive items (one item = one (read segment x contig segment) pair, i.e. one call of
+// get_liftover_alignment_for_read_and_contig_segment, /root/reference/src/read_alignment_scanner.rs:136-288).
+// The CIGAR ops of all items of the tile are laid out as ONE flattened op stream in LDS (item id per element), so
+// every lane has an op to work on whatever the per-item CIGAR length is.  Lane t additionally owns the scalars
+// of item t (position, block-map window, flags); elements fetch them with a cross-lane read (wv::shfl).
+// The sequential state of the reference loops is recast as wave-level scans over the flattened stream:
+//   * positions            : segmented exclusive sums   (add-scan + max-scan of the value at segment heads)
+//   * "last X before me"   : max-scan over indices      (previous mapped piece, previous alive op, previous event)
+//   * left-shift carry     : scan of min-plus function composition
+//   * compaction           : add-scan of emission counts
+// Chunks of 64 elements are processed with a running carry, so the same code serves small tiles (LDS) and
+// single large items (wave-private global scratch).
+//
+// All citations are relative to /root/reference.
+#pragma once
+#include <plo_wave.hpp>
+#include <stdint.h>
+
+#include "lift_types.hpp"
+
+namespace plo {
+
+// Working storage of one tile: LDS for the tile kernel, wave-private global scratch for the large-item kernel.
+struct TileMem {
+    uint32_t *A, *B;    // ping-pong op arrays
+    uint8_t *idA, *idB; // item id of each element (low 6 bits) + 2 flag bits
+    int *T0, *T1, *T2, *T3, *T4;  // per-element temporaries
+    int *itc;  // [64] per-item counters / scratch written by arbitrary lanes
+    int *itf;  // [64] first match index  (clean-up)
+    int *itl;  // [64] last match index   (clean-up)
+    int *its;  // [64] leading-deletion shift (clean-up) / ref2_start (liftover)
+    int *itp;  // [64] panic flags
+    int cap;
+};
+constexpr size_t tile_mem_bytes(int cap) { return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4; }
+
+PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap) {
+    TileMem m;
+    m.A = (uint32_t *)base;
+    m.B = m.A + cap;
+    m.T0 = (int *)(m.B + cap);
+    m.T1 = m.T0 + cap;
+    m.T2 = m.T1 + cap;
+    m.T3 = m.T2 + cap;
+    m.T4 = m.T3 + cap;
+    m.itc = m.T4 + cap;
+    m.itf = m.itc + 64;
+    m.itl = m.itf + 64;
+    m.its = m.itl + 64;
+    m.itp = m.its + 64;
+    m.idA = (uint8_t *)(m.itp + 64);
+    m.idB = m.idA + cap;
+    m.cap = cap;
+    return m;
+}
+
+// ---- op helpers (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:22-47, ignore_hard_clip = false) ----------------
+PLO_DEV int op_type(uint32_t c) { return (int)(c & 15u); }
+PLO_DEV int op_len(uint32_t c) { return (int)(c >> 4); }
+PLO_DEV uint32_t mk_op(int type, int len) { return ((uint32_t)len << 4) | (uint32_t)type; }
+PLO_DEV bool is_match(int t) { return t == OP_M || t == OP_EQ || t == OP_X; }
+PLO_DEV bool ref_consuming(int t) { return (0x18D >> t) & 1; }   // M D N = X
+PLO_DEV bool read_consuming(int t) { return (0x1B3 >> t) & 1; }  // M I S H = X
+PLO_DEV bool is_indel(int t) { return t == OP_I || t == OP_D; }
+
+// ---- sequence access --------------------------------------------------------------------------------------------
+// comp_base, lib/rust-vc-utils/src/seq_util.rs:1-15
+PLO_DEV int comp_base(int b) {
+    switch (b) {
+        case 'A': return 'T';
+        case 'T': return 'A';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        case 'N': return 'N';
+        case 'a': return 't';
+        case 't': return 'a';
+        case 'c': return 'g';
+        case 'g': return 'c';
+        case 'n': return 'n';
+        default: return 'N';
+    }
+}
+// The read as the reference sees it after `record.seq().as_bytes()` (+ rev_comp_in_place when need_flipped),
+// src/read_alignment_scanner.rs:170-173,238-241 -- never materialised: decoded / complemented per probe.
+struct ReadSeq {
+    const uint8_t *p;
+    int len;
+    int fmt;
+    int flip;
+};
+PLO_DEV int read_base(const ReadSeq &r, int i) {
+    int j = r.flip ? (r.len - 1 - i) : i;
+    int c;
+    if (r.fmt == PLO_SEQ_BAM4) {
+        int b = r.p[j >> 1];
+        int nib = (j & 1) ? (b & 15) : (b >> 4);
+        // "=ACMGRSVTWYHKDBN"
+        const unsigned long long lo = 0x565352474d43413dull;  // = A C M G R S V
+        const unsigned long long hi = 0x4e42444b48595754ull;  // T W Y H K D B N
+        c = (int)(((nib & 8) ? hi : lo) >> ((nib & 7) * 8)) & 0xff;
+    } else {
+        c = r.p[j];
+    }
+    return r.flip ? comp_base(c) : c;
+}
+
+PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, int seg, int flip) {
+    uint32_t read = bt.seg_read[seg];
+    ReadSeq r;
+    r.p = bt.seq + bt.read_seq_off[read];
+    r.len = (int)bt.read_seq_len[read];
+    r.fmt = bt.seq_fmt;
+    r.flip = flip;
+    return r;
+}
+
+// ---- block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85) ----------------------------
+PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (kv[mid].key <= x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key >= x, else hi
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (kv[mid].key < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// ---- chunked scans with a running carry ---------------------------------------------------------------------------
+struct AddScan {
+    int carry = 0;
+    PLO_DEV int incl(int x) {
+        int inc = wv::scan_add(x);
+        int r = carry + inc;
+        carry += wv::bcast_last(inc);
+        return r;
+    }
+    PLO_DEV int excl(int x) { return incl(x) - x; }
+};
+struct MaxScan {
+    int carry;
+    int prev_carry;
+    PLO_DEV explicit MaxScan(int init) : carry(init), prev_carry(init) {}
+    PLO_DEV int incl(int x) {
+        int m = wv::imax(wv::scan_max(x), carry);
+        prev_carry = carry;
+        carry = wv::bcast_last(m);
+        return m;
+    }
+    // exclusive value belonging to the last incl() call
+    PLO_DEV int excl_of(int incl_value) { return wv::shfl_up1(incl_value, prev_carry); }
+};
+// segmented exclusive sum of non-negative values: plain prefix minus the prefix at the segment head, the latter
+// propagated by a max-scan (prefixes are non-decreasing)
+struct SegSum {
+    AddScan a;
+    MaxScan m{0};
+    PLO_DEV int excl(int x, bool head) {
+        int p = a.excl(x);
+        int base = m.incl(head ? p : 0);
+        return p - base;
+    }
+};
+
+// Per-item counts/starts of an output array from the inclusive emission prefix E[] stored per *input* element
+// (input items are contiguous: item t = [s, s+c)).
+PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
+    int before = (s > 0) ? E[s - 1] : 0;
+    if (c > 0) {
+        ns = before;
+        nc = E[s + c - 1] - before;
+    } else {
+        ns = before;
+        nc = 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// clean_up_cigar_edge_indels + compress_cigar  (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:265-291, 204-228)
+// X (n elements, items [s,s+c) per lane) -> Y.  Items with active == false are copied verbatim.
+// Returns the leading-deletion shift of the lane's item in `shift`.
+// -------------------------------------------------------------------------------------------------------------------
+PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
+                              bool active, int &shift, int &n_out) {
+    const int lane = wv::lane();
+    m.itf[lane] = IMAX;
+    m.itl[lane] = -1;
+    m.its[lane] = 0;
+    wv::sync();
+    // pass 1: first / last alignment-match element of every item (the edges are everything outside them)
+    {
+        MaxScan lastm(-1);
+        for (int base = 0; base < n; base += 64) {
+            int e = base + lane;
+            bool valid = e < n;
+            int id = valid ? (idX[e] & 63) : 0;
+            int i_s = wv::shfl(s, id);
+            int i_c = wv::shfl(c, id);
+            int i_act = wv::shfl((int)active, id);
+            bool ism = valid && i_act && is_match(op_type(X[e]));
+            int li = lastm.incl(ism ? e : -1);
+            int le = lastm.excl_of(li);
+            if (ism && le < i_s) m.itf[id] = e;                        // first match of the item: single writer
+            if (valid && e == i_s + i_c - 1) m.itl[id] = (li >= i_s) ? li : -1;  // last element publishes the last match
+        }
+    }
+    wv::sync();
+    // pass 2: edge I -> S(len), edge D -> S(0) (+ leading D lengths summed into the position shift); in place
+    for (int base = 0; base < n; base += 64) {
+        int e = base + lane;
+        bool valid = e < n;
+        int id = valid ? (idX[e] & 63) : 0;
+        int i_act = wv::shfl((int)active, id);
+        if (valid) {
+            uint32_t cc = X[e];
+            if (i_act) {
+                int f = m.itf[id], l = m.itl[id];
+                bool lead = e < f;
+                bool trail = e > l;
+                int t = op_type(cc);
+                if (lead || trail) {
+                    if (t == OP_D) {
+                        if (lead) wv::atomic_add(&m.its[id], op_len(cc));
+                        cc = mk_op(OP_S, 0);
+                    } else if (t == OP_I) {
+                        cc = mk_op(OP_S, op_len(cc));
+                    }
+                    X[e] = cc;
+                }
+            }
+            Y[e] = 0;
+            m.T3[e] = 0;  // left clean for the indel-cluster sums of the next stage
+            m.T4[e] = 0;
+        }
+    }
+    wv::sync();
+    // pass 3: drop zero-length ops, merge equal neighbours (head flags + run sums)
+    {
+        MaxScan lasta(-1);
+        AddScan heads;
+        for (int base = 0; base < n; base += 64) {
+            int e = base + lane;
+            bool valid = e < n;
+            int id = valid ? (idX[e] & 63) : 0;
+            int i_s = wv::shfl(s, id);
+            int i_act = wv::shfl((int)active, id);
+            uint32_t cc = valid ? X[e] : 0;
+            int t = op_type(cc), L = op_len(cc);
+            bool alive = valid && (!i_act || L > 0);
+            int ai = lasta.incl(alive ? e : -1);
+            int pa = lasta.excl_of(ai);
+            bool head = false;
+            if (alive) {
+                if (!i_act)
+                    head = true;
+                else
+                    head = (pa < i_s) || (op_type(X[pa]) != t);
+            }
+            int hi = heads.incl(head ? 1 : 0);
+            if (alive) {
+                int r = hi - 1;
+                // Pad is absent from the summing pattern (:210-212): a Pad following a Pad adds nothing
+                uint32_t add = (uint32_t)((t == OP_P && !head) ? 0 : L) << 4;
+                if (head) {
+                    add |= (uint32_t)t;
+                    idY[r] = (uint8_t)id;
+                }
+                wv::atomic_add(&Y[r], add);
+            }
+            if (valid) m.T0[e] = hi;
+        }
+        n_out = heads.carry;
+    }
+    wv::sync();
+    int ns, nc;
+    finish_counts(m.T0, s, c, ns, nc);
+    shift = m.its[lane];
+    s = ns;
+    c = nc;
+    wv::sync();
+}
+
+// left homology of get_indel_breakend_homology_info (lib/rust-vc-utils/src/indel_breakend_homology.rs:32-47),
+// capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133)
+PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound,
+                          bool &panic) {
+    int re = rs + del, qe = qs + ins;
+    int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
+    int maxk = wv::imin(max_left, bound);
+    int k = 0;
+    if (max_left > 0) {
+        // the first probe has the largest indices; out of bounds = slice-index panic in the reference (:38-39)
+        if (re - 1 >= ref_len || qe - 1 >= rd.len) {
+            panic = true;
+            return 0;
+        }
+    }
+    while (k < maxk) {
+        int a = ref[re - 1 - k];
+        int b = read_base(rd, qe - 1 - k);
+        if (a != b) break;
+        ++k;
+    }
+    return k;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// The tile pipeline
+// -------------------------------------------------------------------------------------------------------------------
+PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
+                       int nit, TileMem m, bool big_path, int big_thresh) {
+    const int lane = wv::lane();
+    bool has = lane < nit;
+    const uint32_t g = big_path ? (has ? wk.big_list[item_begin + (uint32_t)lane] : 0u) : item_begin + (uint32_t)lane;
+
+    // ---- item descriptors: lane t <-> item t  (caller glue, src/read_alignment_scanner.rs:146-176) --------------
+    int seg = 0, contig = 0, gseg = 0, n_in = 0, in_off = 0, pos = 0, kv0 = 0, kv1 = 0, chrom = 0, mapq = 0;
+    bool rev = false, do_shift = false, flip = false;
+    if (has) {
+        seg = (int)wk.item_seg[g];
+        int cseg = (int)wk.item_cseg[g];
+        contig = (int)bt.seg_contig[seg];
+        gseg = (int)ix.contig_seg_off[contig] + cseg;
+        uint32_t read = bt.seg_read[seg];
+        in_off = (int)bt.seg_cigar_off[seg];
+        n_in = (int)bt.seg_cigar_off[seg + 1] - in_off;
+        pos = (int)bt.seg_pos[seg];
+        bool contig_fwd = ix.cs_is_fwd[gseg] != 0;
+        if (stages & PLO_STAGE_STRAND) {
+            // need_flipped_read_alignment (:153-157)
+            bool changes = (bt.read_is_reverse[read] != 0) == (bt.seg_is_fwd[seg] != 0);
+            flip = (!contig_fwd) != changes;
+            rev = !contig_fwd;
+        }
+        do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
+        kv0 = (int)ix.cs_kv_off[gseg];
+        kv1 = (int)ix.cs_kv_off[gseg + 1];
+        chrom = (int)ix.cs_chrom[gseg];
+        mapq = ix.cs_mapq[gseg];
+    }
+    // items too long for a shared tile go to the large-item kernel (one item per wave, global scratch)
+    {
+        bool defer = has && !big_path && n_in > big_thresh;
+        unsigned long long dm = wv::ballot(defer);
+        if (dm != 0ull) {
+            int nd = __builtin_popcountll(dm);
+            int slot = 0;
+            if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NBIG], (unsigned long long)nd);
+            slot = wv::bcast_first(slot);
+            if (defer) {
+                int rank = __builtin_popcountll(dm & ((1ull << lane) - 1ull));
+                wk.big_list[slot + rank] = g;
+                wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+                has = false;
+                n_in = 0;
+            }
+        }
+    }
+    int status = PLO_ITEM_LIFTED;
+    bool alive = has;  // still flowing through the pipeline
+    if (has && do_shift && (!ix.contig_revseq || ix.contig_revseq[contig] == nullptr)) {
+        status = PLO_ITEM_PANIC;  // rev_contig_seq.unwrap() on None (:174)
+        alive = false;
+        do_shift = false;
+    }
+    bool overflow = false;
+    unsigned long long algo_bytes = 0;
+
+    // ---- LOAD: flattened op stream of the tile (reversed for reverse-mapped contig segments, :167) --------------
+    int cA = has ? n_in : 0;
+    int incA = wv::scan_add(cA);
+    int sA = incA - cA;
+    int nA = wv::bcast_last(incA);
+    if (nA > m.cap) overflow = true;
+    m.itp[lane] = 0;
+    int span = 0;  // reference span of the input CIGAR (get_cigar_ref_offset, :165)
+    if (!overflow) {
+        for (int base = 0; base < nA; base += 64) {
+            int e = base + lane;
+            if (e < nA) m.T3[e] = 0;
+        }
+        wv::sync();
+        if (has && cA > 0) m.T3[sA] = lane + 1;
+        wv::sync();
+        MaxScan owner(0);
+        AddScan refsum;
+        for (int base = 0; base < nA; base += 64) {
+            int e = base + lane;
+            bool valid = e < nA;
+            int id = owner.incl(valid ? m.T3[e] : 0) - 1;
+            if (id < 0) id = 0;
+            int i_off = wv::shfl(in_off, id), i_n = wv::shfl(n_in, id), i_s = wv::shfl(sA, id);
+            int i_rev = wv::shfl((int)rev, id);
+            uint32_t c = 0;
+            if (valid) {
+                int k = e - i_s;
+                c = bt.cigar[i_off + (i_rev ? (i_n - 1 - k) : k)];
+                m.A[e] = c;
+                m.idA[e] = (uint8_t)id;
+                m.T3[e] = 0;
+                m.T4[e] = 0;
+            }
+            int t = op_type(c);
+            int r = refsum.incl((valid && ref_consuming(t)) ? op_len(c) : 0);
+            if (valid) m.T0[e] = r;
+        }
+        wv::sync();
+        {
+            int ns, nc;
+            finish_counts(m.T0, sA, cA, ns, nc);
+            span = nc;
+        }
+        wv::sync();
+    }
+    // rev_pos = contig_length - read_segment_end (:164-166)
+    int pos1 = pos;
+    if (has && rev) pos1 = ix.contig_len[contig] - (pos + span);
+    const int lo_pos = pos1, hi_pos = pos1 + span;  // superset of every contig position the item touches
+
+    // ---- LEFT SHIFT (left_shift_indels.rs:17-39 + cigar_indel_shifter.rs:10-165), items with do_shift ---------------
+    if (!overflow && wv::ballot(has && do_shift) != 0ull) {
+        // pass A: classes, heads, cluster sums, positions
+        {
+            SegSum sr, sq, sm;
+            MaxScan pnz(-1), heads(-1);
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                bool valid = e < nA;
+                uint32_t c = valid ? m.A[e] : 0;
+                int id = valid ? (m.idA[e] & 63) : 0;
+                int i_do = wv::shfl((int)do_shift, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
+                int t = op_type(c), L = op_len(c);
+                bool on = valid && i_do;
+                bool isC = on && is_indel(t) && L > 0;       // cluster member      (:73-85: len > 0 only)
+                bool isZ = on && is_indel(t) && L == 0;      // invisible to the builder
+                bool isM = on && is_match(t);
+                bool isO = on && !is_indel(t) && !isM;
+                bool ihead = valid && e == i_s;
+                int R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
+                int Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
+                int PM = sm.excl(isM ? L : 0, ihead);
+                int pi = pnz.incl((valid && !isZ) ? e : -1);
+                int pp = pnz.excl_of(pi);
+                bool prevC = false;
+                if (on && pp >= i_s) {
+                    uint32_t pc = m.A[pp];
+                    prevC = is_indel(op_type(pc)) && op_len(pc) > 0;
+                }
+                bool chead = isC && !prevC;
+                bool event = chead || isO;
+                int hidx = heads.incl(chead ? e : -1);
+                if (valid) {
+                    m.T0[e] = i_pos + R;  // indel_block_ref_start
+                    m.T1[e] = Q;          // indel_block_read_start
+                    m.T2[e] = PM;         // match bases of the item before this element
+                    m.idA[e] = (uint8_t)(id | (chead ? 64 : 0) | (event ? 128 : 0));
+                    if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
+                }
+            }
+        }
+        wv::sync();
+        // pass B: homology, carried match run (min-plus scan), emission
+        int nB = 0;
+        {
+            MaxScan ev(-1);
+            AddScan emit;
+            wv::MinPlus carryF = {0, IMAX, 0};
+            int carry_r = 0;
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                bool valid = e < nA;
+                uint32_t c = valid ? m.A[e] : 0;
+                int idf = valid ? m.idA[e] : 0;
+                int id = idf & 63;
+                bool chead = (idf & 64) != 0, event = (idf & 128) != 0;
+                int i_do = wv::shfl((int)do_shift, id), i_s = wv::shfl(sA, id), i_c = wv::shfl(cA, id);
+                int t = op_type(c), L = op_len(c);
+                bool on = valid && i_do;
+                int li = ev.incl((on && event) ? e : -1);
+                int pe = ev.excl_of(li);
+                bool have_prev = pe >= i_s;
+                int pm = valid ? m.T2[e] : 0;
+                int m_e = pm - ((on && have_prev) ? m.T2[pe] : 0);
+                wv::MinPlus f = {0, IMAX, 0};
+                int del = 0, ins = 0, h = 0;
+                if (on && chead) {
+                    del = m.T3[e];
+                    ins = m.T4[e];
+                }
+                // sequences are only needed by cluster heads
+                int i_seg = wv::shfl(seg, id), i_contig = wv::shfl(contig, id), i_flip = wv::shfl((int)flip, id);
+                if (on && chead) {
+                    bool panic = false;
+                    ReadSeq rd = item_read_seq(bt, i_seg, i_flip);
+                    const uint8_t *ref = ix.contig_revseq ? ix.contig_revseq[i_contig] : nullptr;
+                    if (!ref) {
+                        panic = true;  // rev_contig_seq.unwrap() on None (:174)
+                    } else {
+                        h = left_homology(ref, ix.contig_len[i_contig], m.T0[e], del, rd, m.T1[e], ins, pm, panic);
+                        algo_bytes += 2ull * (unsigned)(wv::imin(h + 1, wv::imax(pm, 1)));
+                    }
+                    if (panic) wv::atomic_or(&m.itp[id], 1);
+                    f.a = m_e;
+                    f.b = h;
+                    f.s = have_prev ? 0 : 1;
+                } else if (on && event) {  // add_other: flush, match run restarts at 0 (:155-165)
+                    f.a = m_e;
+                    f.b = 0;
+                    f.s = have_prev ? 0 : 1;
+                }
+                wv::MinPlus F = wv::scan_minplus(f);
+                F = wv::mp_compose(carryF, F);
+                int r_after = wv::imin(F.a, F.b);
+                int r_excl = wv::shfl_up1(r_after, carry_r);
+                carryF = wv::bcast_last(F);
+                carry_r = wv::bcast_last(r_after);
+                int r_before = have_prev ? r_excl : 0;
+                int x = r_before + m_e;
+                uint32_t o[4];
+                int ne = 0;
+                if (valid && !i_do) {
+                    o[ne++] = c;  // item not shifted: copy
+                } else if (on && chead) {
+                    int cs = wv::imin(x, h);  // actual_shift_len (:132)
+                    if (x - cs > 0) o[ne++] = mk_op(OP_M, x - cs);
+                    if (ins > 0) o[ne++] = mk_op(OP_I, ins);  // "nImD" order for the left shift (:141-147)
+                    if (del > 0) o[ne++] = mk_op(OP_D, del);
+                } else if (on && event) {
+                    if (x > 0) o[ne++] = mk_op(OP_M, x);
+                    o[ne++] = c;
+                }
+                if (on && e == i_s + i_c - 1) {  // get_cigar(): final add_other(None) (:54-60)
+                    bool have_le = li >= i_s;
+                    int pm_incl = pm + (is_match(t) ? L : 0);
+                    int m_end = pm_incl - (have_le ? m.T2[li] : 0);
+                    int x_end = (have_le ? r_after : 0) + m_end;
+                    if (x_end > 0) o[ne++] = mk_op(OP_M, x_end);
+                }
+                int ei = emit.incl(ne);
+                int p = ei - ne;
+                if (p + ne > m.cap) {
+                    overflow = true;
+                } else {
+                    for (int k = 0; k < ne; ++k) {
+                        m.B[p + k] = o[k];
+                        m.idB[p + k] = (uint8_t)id;
+                    }
+                }
+                if (valid) m.T0[e] = ei;
+            }
+            nB = emit.carry;
+        }
+        overflow = wv::ballot(overflow) != 0ull;
+        wv::sync();
+        if (!overflow) {
+            int sB, cB;
+            finish_counts(m.T0, sA, cA, sB, cB);
+            wv::sync();
+            int shift = 0, nOut = 0;
+            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, has && do_shift, shift, nOut);
+            sA = sB;
+            cA = cB;
+            nA = nOut;
+            pos1 += shift;
+            if (has && m.itp[lane]) {
+                status = PLO_ITEM_PANIC;
+                alive = false;
+            }
+        }
+    }
+
+    // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ------------------------------------------------------------------
+    if (!overflow && (stages & PLO_STAGE_LIFTOVER)) {
+        // per item: window of the block map that can intersect the item
+        int W0 = kv0, W1 = kv0;
+        if (alive) {
+            int ub = kv_upper_bound(ix.kv, kv0, kv1, lo_pos);
+            W0 = wv::imax(kv0, ub - 1);
+            W1 = kv_lower_bound(ix.kv, W0, kv1, hi_pos);
+            int nb = kv1 - kv0, lg = 0;
+            while ((1 << lg) < nb) ++lg;
+            algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
+        }
+        // pass A: per op, first block f and number of (op x block) pieces
+        int P = 0;
+        {
+            SegSum sr;
+            AddScan pieces;
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                bool valid = e < nA;
+                uint32_t c = valid ? m.A[e] : 0;
+                int id = valid ? (m.idA[e] & 63) : 0;
+                int i_alive = wv::shfl((int)alive, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
+                int i_w0 = wv::shfl(W0, id), i_w1 = wv::shfl(W1, id), i_kv0 = wv::shfl(kv0, id);
+                int t = op_type(c), L = op_len(c);
+                bool on = valid && i_alive;
+                bool rc = ref_consuming(t);
+                int s = i_pos + sr.excl((on && rc) ? L : 0, valid && e == i_s);
+                int cnt = 0, f = 0;
+                if (on) {
+                    if (rc) {
+                        if (L > 0) {
+                            // greatest key <= s (or "no block": index kv0-1) ... greatest key < s+L
+                            f = kv_upper_bound(ix.kv, i_w0, i_w1, s) - 1;
+                            if (f < i_kv0) f = i_kv0 - 1;
+                            int l = kv_lower_bound(ix.kv, i_w0, i_w1, s + L) - 1;
+                            cnt = l - f + 1;
+                        }
+                    } else if (t == OP_I || t == OP_S || t == OP_H) {
+                        cnt = 1;  // :157-160 copied through; Pad (:213) emits nothing
+                    }
+                }
+                int b = pieces.excl(cnt);
+                if (valid) {
+                    m.T0[e] = s;
+                    m.T1[e] = f;
+                    m.T2[e] = cnt > 0 ? b : -1;
+                }
+            }
+            P = pieces.carry;
+        }
+        if (P > m.cap) overflow = true;
+        if (!overflow) {
+            for (int base = 0; base < P; base += 64) {
+                int j = base + lane;
+                if (j < P) m.T3[j] = 0;
+            }
+            m.its[lane] = NONE32;  // ref2_start_pos = None
+            m.itc[lane] = 0;
+            wv::sync();
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                if (e < nA && m.T2[e] >= 0) m.T3[m.T2[e]] = e + 1;
+            }
+            wv::sync();
+            // pass B: one lane per piece (update_ref2_cigar_segment, :35-133)
+            int nB = 0;
+            {
+                MaxScan owner(0), lastmap(-1), lastfm(-1);
+                AddScan emit;
+                for (int base = 0; base < P; base += 64) {
+                    int j = base + lane;
+                    bool valid = j < P;
+                    int i = owner.incl(valid ? m.T3[j] : 0) - 1;
+                    if (i < 0) i = 0;
+                    uint32_t c = valid ? m.A[i] : 0;
+                    int id = valid ? (m.idA[i] & 63) : 0;
+                    int i_kv0 = wv::shfl(kv0, id), i_kv1 = wv::shfl(kv1, id);
+                    int t = op_type(c), L = op_len(c);
+                    bool piece = valid && ref_consuming(t);
+                    bool ism = is_match(t);
+                    bool mapped = false, before = false, fm = false;
+                    int plen = 0, val = NONE32, endval = 0, startval = 0;
+                    if (piece) {
+                        int s = m.T0[i], f = m.T1[i], tt = j - m.T2[i];
+                        int b = f + tt;
+                        before = b < i_kv0;
+                        int kb = 0;
+                        if (!before) {
+                            KV kvb = ix.kv[b];
+                            kb = kvb.key;
+                            val = kvb.val;
+                        }
+                        int pstart = (tt == 0) ? s : kb;
+                        int pend = s + L;
+                        if (b + 1 < i_kv1) {
+                            int kn = ix.kv[b + 1].key;
+                            if (kn < pend) pend = kn;
+                        }
+                        plen = pend - pstart;
+                        mapped = !before && val != NONE32;
+                        fm = mapped && ism;
+                        if (mapped) {
+                            endval = val + (pend - kb);      // :98-100
+                            startval = val + (pstart - kb);  // :84-88
+                        }
+                    }
+                    if (valid) {
+                        m.T3[j] = id | (mapped ? 256 : 0);
+                        m.T4[j] = endval;
+                    }
+                    wv::sync();
+                    int mi = lastmap.incl(mapped ? j : -1);
+                    int pmap = lastmap.excl_of(mi);
+                    int fi = lastfm.incl(fm ? j : -1);
+                    int fe = lastfm.excl_of(fi);
+                    uint32_t o[2];
+                    int ne = 0;
+                    if (valid && !piece) {
+                        o[ne++] = c;
+                    } else if (piece) {
+                        if (mapped) {
+                            bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
+                            bool started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
+                            bool started_before = fe >= 0 && (m.T3[fe] & 63) == id;
+                            if (fm && !started_before) m.its[id] = startval;
+                            if (prev_ok) {  // :91-96
+                                int d = val - m.T4[pmap];
+                                if (d > 0 && started) o[ne++] = mk_op(OP_D, d);
+                            }
+                            if (ism || started) o[ne++] = mk_op(t == OP_D ? OP_D : (t == OP_N ? OP_N : OP_M), plen);  // :102-109
+                        } else if (!before) {
+                            if (ism) o[ne++] = mk_op(OP_I, plen);  // :111-115
+                        } else {
+                            if (ism) o[ne++] = mk_op(OP_S, plen);  // :117-123
+                        }
+                    }
+                    int ei = emit.incl(ne);
+                    int p = ei - ne;
+                    if (p + ne > m.cap) {
+                        overflow = true;
+                    } else {
+                        for (int k = 0; k < ne; ++k) {
+                            m.B[p + k] = o[k];
+                            m.idB[p + k] = (uint8_t)id;
+                        }
+                    }
+                    if (ne > 0) wv::atomic_add(&m.itc[id], ne);
+                }
+                nB = emit.carry;
+            }
+            overflow = wv::ballot(overflow) != 0ull;
+            wv::sync();
+            if (!overflow) {
+                int cB = m.itc[lane];
+                int incB = wv::scan_add(cB);
+                int sB = incB - cB;
+                int r2s = m.its[lane];
+                wv::sync();
+                if (alive && r2s == NONE32) {  // :218 ref2_start_pos.map(...) on None
+                    status = PLO_ITEM_NO_LIFTOVER;
+                    alive = false;
+                }
+                int shift = 0, nOut = 0;
+                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut);  // :219-220
+                sA = sB;
+                cA = cB;
+                nA = nOut;
+                pos1 = r2s + shift;  // :221
+            }
+        }
+    }
+
+    // ---- LENGTH CHECK (src/read_alignment_scanner.rs:204-229) ------------------------------------------------------------------
+    bool simp = alive;
+    if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
+        AddScan rs;
+        for (int base = 0; base < nA; base += 64) {
+            int e = base + lane;
+            bool valid = e < nA;
+            uint32_t c = valid ? m.A[e] : 0;
+            int r = rs.incl((valid && read_consuming(op_type(c))) ? op_len(c) : 0);
+            if (valid) m.T0[e] = r;
+        }
+        wv::sync();
+        int ns, rl;
+        finish_counts(m.T0, sA, cA, ns, rl);
+        wv::sync();
+        if (alive) {
+            uint32_t read = bt.seg_read[seg];
+            if ((int)bt.read_seq_len[read] != rl) {
+                status = PLO_ITEM_LEN_MISMATCH;
+                simp = false;
+            }
+        }
+    }
+
+    // ---- SIMPLIFY (src/simplify_alignment_indels.rs:5-156) ------------------------------------------------------------------
+    if (!overflow && (stages & PLO_STAGE_SIMPLIFY)) {
+        // pass A: clusters = maximal runs of I/D ops; sums at the cluster head
+        {
+            SegSum sr, sq;
+            MaxScan heads(-1);
+            int carry_c = 0;
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                bool valid = e < nA;
+                uint32_t c = valid ? m.A[e] : 0;
+                int id = valid ? (m.idA[e] & 63) : 0;
+                int i_on = wv::shfl((int)simp, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
+                int t = op_type(c), L = op_len(c);
+                bool on = valid && i_on;
+                bool isC = on && is_indel(t);
+                bool ihead = valid && e == i_s;
+                int R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
+                int Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
+                int prevC = wv::shfl_up1((int)isC, carry_c);
+                carry_c = wv::bcast_last((int)isC);
+                bool chead = isC && !(prevC && !ihead);
+                int hidx = heads.incl(chead ? e : -1);
+                if (valid) {
+                    m.T0[e] = i_pos + R;  // block_ref_start
+                    m.T1[e] = Q;          // block_read_start
+                    m.idA[e] = (uint8_t)(id | (chead ? 64 : 0));
+                    if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
+                }
+            }
+        }
+        wv::sync();
+        // pass B: CigarBlockInfo::end_indel per cluster head (:35-111)
+        int nB = 0;
+        {
+            AddScan emit;
+            for (int base = 0; base < nA; base += 64) {
+                int e = base + lane;
+                bool valid = e < nA;
+                uint32_t c = valid ? m.A[e] : 0;
+                int idf = valid ? m.idA[e] : 0;
+                int id = idf & 63;
+                bool chead = (idf & 64) != 0;
+                int i_on = wv::shfl((int)simp, id);
+                int i_seg = wv::shfl(seg, id), i_chrom = wv::shfl(chrom, id), i_flip = wv::shfl((int)flip, id);
+                int t = op_type(c);
+                bool on = valid && i_on;
+                uint32_t o[4];
+                int ne = 0;
+                if (valid && !(on && is_indel(t))) {
+                    o[ne++] = c;  // :144-147 (everything that is not part of a cluster is copied)
+                } else if (on && chead) {
+                    int del = m.T3[e], ins = m.T4[e];
+                    if (del == 0 && ins == 0) {
+                    } else if (del == 0) {
+                        o[ne++] = mk_op(OP_I, ins);
+                    } else if (ins == 0) {
+                        o[ne++] = mk_op(OP_D, del);
+                    } else if (del == 1 && ins == 1) {
+                        o[ne++] = mk_op(OP_M, 1);  // :45-48
+                    } else {
+                        int rs0 = m.T0[e], qs0 = m.T1[e];
+                        ReadSeq rd = item_read_seq(bt, i_seg, i_flip);
+                        const uint8_t *ref = ix.chrom_seq[i_chrom];
+                        int ref_len = ix.chrom_len[i_chrom];
+                        if (rs0 < 0 || rs0 + del - 1 >= ref_len || qs0 + ins - 1 >= rd.len) {
+                            wv::atomic_or(&m.itp[id], 1);  // slice index out of bounds: the reference panics
+                        } else {
+                            int pre = 0, post = 0, cmp = 0;
+                            while (del > 0 && ins > 0) {  // :55-68
+                                ++cmp;
+                                if (ref[rs0 + del - 1] != read_base(rd, qs0 + ins - 1)) break;
+                                --del;
+                                --ins;
+                                ++post;
+                            }
+                            while (del > 0 && ins > 0) {  // :71-85
+                                ++cmp;
+                                if (ref[rs0 + pre] != read_base(rd, qs0 + pre)) break;
+                                --del;
+                                --ins;
+                                ++pre;
+                            }
+                            if (del == 1 && ins == 1) {  // :88-92
+                                del = 0;
+                                ins = 0;
+                                ++post;
+                            }
+                            algo_bytes += 2ull * (unsigned)cmp;
+                            if (pre > 0) o[ne++] = mk_op(OP_M, pre);  // :101-104
+                            if (ins > 0) o[ne++] = mk_op(OP_I, ins);
+                            if (del > 0) o[ne++] = mk_op(OP_D, del);
+                            if (post > 0) o[ne++] = mk_op(OP_M, post);
+                        }
+                    }
+                }
+                int ei = emit.incl(ne);
+                int p = ei - ne;
+                if (p + ne > m.cap) {
+                    overflow = true;
+                } else {
+                    for (int k = 0; k < ne; ++k) {
+                        m.B[p + k] = o[k];
+                        m.idB[p + k] = (uint8_t)id;
+                    }
+                }
+                if (valid) m.T2[e] = ei;
+            }
+            nB = emit.carry;
+        }
+        overflow = wv::ballot(overflow) != 0ull;
+        wv::sync();
+        if (!overflow) {
+            int sB, cB;
+            finish_counts(m.T2, sA, cA, sB, cB);
+            wv::sync();
+            int shift = 0, nOut = 0;
+            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, simp, shift, nOut);  // :153-154
+            sA = sB;
+            cA = cB;
+            nA = nOut;
+            if (simp) pos1 += shift;  // :155
+            if (has && m.itp[lane]) {
+                status = PLO_ITEM_PANIC;
+                alive = false;
+            }
+        }
+    }
+
+    // ---- OUTPUT --------------------------------------------------------------------------------------------------------------
+    overflow = wv::ballot(overflow) != 0ull;
+    if (overflow) {
+        if (big_path) {
+            if (has) {
+                wk.status[g] = PLO_ITEM_PANIC;
+                wk.cig_len[g] = 0;
+                wk.cig_off[g] = 0;
+                wk.pos[g] = -1;
+            }
+            if (lane == 0) wv::atomic_add_global(&wk.counters[CNT_ERROR], 1ull);
+        } else {
+            // tile capacity exceeded: re-queue every item of the tile for the large-item kernel
+            unsigned long long hm = wv::ballot(has);
+            int slot = 0;
+            if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NBIG], (unsigned long long)__builtin_popcountll(hm));
+            slot = wv::bcast_first(slot);
+            if (has) {
+                int rank = __builtin_popcountll(hm & ((1ull << lane) - 1ull));
+                wk.big_list[slot + rank] = g;
+                wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+            }
+        }
+        return;
+    }
+    bool emit_cigar = has && (status == PLO_ITEM_LIFTED || status == PLO_ITEM_LEN_MISMATCH);
+    int oc = emit_cigar ? cA : 0;
+    int inco = wv::scan_add(oc);
+    int oS = inco - oc;
+    int total = wv::bcast_last(inco);
+    unsigned long long gbase = 0;
+    if (lane == 0 && total > 0) gbase = wv::atomic_add_global(&wk.counters[CNT_CIGAR], (unsigned long long)total);
+    {
+        // 64-bit broadcast of the bump-allocated base
+        unsigned lo = (unsigned)wv::bcast_first((int)(unsigned)(gbase & 0xffffffffull));
+        unsigned hi = (unsigned)wv::bcast_first((int)(unsigned)(gbase >> 32));
+        gbase = ((unsigned long long)hi << 32) | lo;
+    }
+    bool fits = gbase + (unsigned long long)total <= wk.out_cap;
+    if (!fits && lane == 0) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
+    for (int base = 0; base < nA; base += 64) {
+        int e = base + lane;
+        bool valid = e < nA;
+        int id = valid ? (m.idA[e] & 63) : 0;
+        int i_em = wv::shfl((int)emit_cigar, id), i_s = wv::shfl(sA, id), i_o = wv::shfl(oS, id);
+        if (valid && i_em && fits) wk.out_cigar[gbase + (unsigned long long)(i_o + (e - i_s))] = m.A[e];
+    }
+    if (has) {
+        wk.status[g] = (uint8_t)status;
+        wk.flip[g] = (uint8_t)flip;
+        wk.mapq[g] = (uint8_t)mapq;
+        wk.chrom[g] = (uint32_t)chrom;
+        wk.pos[g] = emit_cigar ? (int64_t)pos1 : (int64_t)-1;
+        wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
+        wk.cig_len[g] = (uint32_t)oc;
+        algo_bytes += 40ull + 4ull * (unsigned)n_in + 24ull + 4ull * (unsigned)oc;
+    }
+    // statistics: one atomic per tile
+    {
+        unsigned lo = (unsigned)(algo_bytes & 0xffffffffull);
+        int s = wv::reduce_add((int)lo);  // per-tile sums stay far below 2^31
+        int nin = wv::reduce_add(has ? n_in : 0);
+        if (lane == 0) {
+            wv::atomic_add_global(&wk.counters[CNT_ALGO_BYTES], (unsigned long long)(unsigned)s);
+            wv::atomic_add_global(&wk.counters[CNT_IN_OPS], (unsigned long long)(unsigned)nin);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Tile assignment: tile w owns the items whose exclusive input-op prefix lies in [w*window, (w+1)*window), i.e. the
+// flattened input op stream is cut into windows and every item goes to the window its first op falls in.
+// -------------------------------------------------------------------------------------------------------------------
+PLO_DEV uint32_t prefix_lower_bound(const uint32_t *a, uint32_t n, unsigned long long x) {  // first i in [0,n) with a[i] >= x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((unsigned long long)a[mid] < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t tile, int window,
+                         int big_thresh, TileMem m) {
+    unsigned long long w0 = (unsigned long long)tile * (unsigned)window;
+    uint32_t lo = prefix_lower_bound(wk.item_op_prefix, wk.n_items, w0);
+    uint32_t hi = prefix_lower_bound(wk.item_op_prefix, wk.n_items, w0 + (unsigned)window);
+    for (uint32_t b = lo; b < hi; b += 64) {
+        int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
+        lift_tile(ix, bt, wk, stages, b, nit, m, false, big_thresh);
+        wv::sync();
+    }
+}
+
+}  // namespace plo

@@ -214,7 +214,7 @@ def mutate(source: torch.Tensor, starts: torch.Tensor, spans: torch.Tensor, rate
             prev_end[1:] = torch.where(same_r[1:], off[:-1] + consumed[:-1], prev_end[1:])
         keep = (off >= rates.min_gap) & (off - prev_end >= rates.min_gap) & (off + consumed + rates.min_gap <= spans[rid])
         # a dropped predecessor could have shielded an overlap: re-check against the previous kept edit
-        for _ in range(2):
+        for _ in range(64):
             kidx = torch.nonzero(keep).squeeze(1)
             if kidx.numel() < 2:
                 break

@@ -1,0 +1,232 @@
+// tests/emu/plo_wave.hpp -- HOST wave64 emulator with the same interface as portello_amd/csrc/plo_wave.hpp.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the device algorithm (portello_amd/csrc/lift_core.hpp) be compiled with g++
+// and executed lane by lane on the CPU (one ucontext fiber per lane), so that the wave-level decomposition can be
+// diffed against the oracle, run under ASan/UBSan, and checked for wave-uniform use of the primitives -- none of
+// which is possible on the GPU pool.  Every primitive is a rendezvous of all 64 lanes; a lane that calls a
+// different primitive (or none) than its peers aborts the run ("divergent primitive").
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define PLO_DEV inline
+#define PLO_WAVE 64
+#define PLO_EMULATOR 1
+
+namespace wv {
+
+struct EmuWave {
+    static constexpr int N = 64;
+    static constexpr size_t STACK = 512 * 1024;
+    ucontext_t sched;
+    ucontext_t fiber[N];
+    std::vector<char> stacks;
+    bool done[N];
+    int cur = 0;
+    // rendezvous state: double-buffered by primitive parity
+    int64_t slot[2][N][4];
+    int tag[2][N];
+    unsigned long long seq[N];
+    std::function<void()> body;
+    unsigned order_seed = 0;  // != 0: shuffle the lane execution order every round (catches missing wv::sync())
+
+    static EmuWave *&current() {
+        static thread_local EmuWave *w = nullptr;
+        return w;
+    }
+    static void trampoline() {
+        EmuWave *w = current();
+        w->body();
+        w->done[w->cur] = true;
+        swapcontext(&w->fiber[w->cur], &w->sched);
+    }
+    void run(std::function<void()> fn) {
+        body = std::move(fn);
+        stacks.assign(STACK * N, 0);
+        current() = this;
+        for (int l = 0; l < N; ++l) {
+            done[l] = false;
+            seq[l] = 0;
+            getcontext(&fiber[l]);
+            fiber[l].uc_stack.ss_sp = stacks.data() + STACK * l;
+            fiber[l].uc_stack.ss_size = STACK;
+            fiber[l].uc_link = &sched;
+            makecontext(&fiber[l], (void (*)())trampoline, 0);
+        }
+        int order[N];
+        for (int l = 0; l < N; ++l) order[l] = l;
+        unsigned rs = order_seed;
+        for (;;) {
+            bool any = false;
+            if (order_seed) {
+                for (int i = N - 1; i > 0; --i) {
+                    rs = rs * 1664525u + 1013904223u;
+                    int j = (int)((rs >> 8) % (unsigned)(i + 1));
+                    int t = order[i];
+                    order[i] = order[j];
+                    order[j] = t;
+                }
+            }
+            for (int i = 0; i < N; ++i) {
+                int l = order[i];
+                if (done[l]) continue;
+                any = true;
+                cur = l;
+                swapcontext(&sched, &fiber[l]);
+            }
+            if (!any) break;
+        }
+        current() = nullptr;
+    }
+    // rendezvous: publish (tag, payload), wait for everybody, return parity buffer index to read from
+    int rendezvous(int t, const int64_t *payload, int n) {
+        int par = (int)(seq[cur] & 1);
+        for (int i = 0; i < n; ++i) slot[par][cur][i] = payload[i];
+        tag[par][cur] = t;
+        seq[cur]++;
+        int me = cur;
+        swapcontext(&fiber[me], &sched);
+        cur = me;
+        return par;
+    }
+    void check(int par, int t) {
+        for (int l = 0; l < N; ++l) {
+            if (seq[l] < seq[cur] || tag[par][l] != t) {
+                fprintf(stderr, "wave emulator: divergent primitive (lane %d tag %d vs lane %d tag %d, done=%d)\n", cur, t, l,
+                        tag[par][l], (int)done[l]);
+                abort();
+            }
+        }
+    }
+};
+
+inline EmuWave &W() { return *EmuWave::current(); }
+
+inline int lane() { return W().cur; }
+
+enum { T_SYNC = 1, T_SHFL, T_SHFL_UP1, T_BALLOT, T_BCAST_LAST, T_BCAST_FIRST, T_SCAN_ADD, T_SCAN_MAX, T_SCAN_MP };
+
+inline void sync() {
+    int64_t z = 0;
+    int par = W().rendezvous(T_SYNC, &z, 1);
+    W().check(par, T_SYNC);
+}
+
+inline int64_t shfl64(int64_t v, int src) {
+    int par = W().rendezvous(T_SHFL, &v, 1);
+    W().check(par, T_SHFL);
+    return W().slot[par][src & 63][0];
+}
+inline int shfl(int v, int src) { return (int)shfl64(v, src); }
+inline unsigned shfl(unsigned v, int src) { return (unsigned)shfl64((int64_t)v, src); }
+inline long long shfl(long long v, int src) { return (long long)shfl64(v, src); }
+inline unsigned long long shfl(unsigned long long v, int src) { return (unsigned long long)shfl64((int64_t)v, src); }
+
+inline int shfl_up1(int v, int first) {
+    int64_t p = v;
+    int par = W().rendezvous(T_SHFL_UP1, &p, 1);
+    W().check(par, T_SHFL_UP1);
+    int l = lane();
+    return l == 0 ? first : (int)W().slot[par][l - 1][0];
+}
+
+inline unsigned long long ballot(bool p) {
+    int64_t v = p ? 1 : 0;
+    int par = W().rendezvous(T_BALLOT, &v, 1);
+    W().check(par, T_BALLOT);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (W().slot[par][l][0]) m |= 1ull << l;
+    return m;
+}
+inline int bcast_last(int v) {
+    int64_t p = v;
+    int par = W().rendezvous(T_BCAST_LAST, &p, 1);
+    W().check(par, T_BCAST_LAST);
+    return (int)W().slot[par][63][0];
+}
+inline int bcast_first(int v) {
+    int64_t p = v;
+    int par = W().rendezvous(T_BCAST_FIRST, &p, 1);
+    W().check(par, T_BCAST_FIRST);
+    return (int)W().slot[par][0][0];
+}
+inline int imax(int a, int b) { return a > b ? a : b; }
+inline int imin(int a, int b) { return a < b ? a : b; }
+
+inline int scan_add(int x) {
+    int64_t p = x;
+    int par = W().rendezvous(T_SCAN_ADD, &p, 1);
+    W().check(par, T_SCAN_ADD);
+    unsigned s = 0;  // wrap-around like the hardware
+    for (int l = 0; l <= lane(); ++l) s += (unsigned)(int)W().slot[par][l][0];
+    return (int)s;
+}
+inline int scan_max(int x) {
+    int64_t p = x;
+    int par = W().rendezvous(T_SCAN_MAX, &p, 1);
+    W().check(par, T_SCAN_MAX);
+    int m = (int)0x80000000;
+    for (int l = 0; l <= lane(); ++l) m = imax(m, (int)W().slot[par][l][0]);
+    return m;
+}
+inline int reduce_add(int x) { return bcast_last(scan_add(x)); }
+inline int reduce_max(int x) { return bcast_last(scan_max(x)); }
+
+struct MinPlus {
+    int a, b, s;
+};
+inline int sat_add(int x, int y) {
+    long long t = (long long)x + (long long)y;
+    return t > 0x7fffffffLL ? 0x7fffffff : (int)t;
+}
+inline MinPlus mp_compose(MinPlus p, MinPlus c) {
+    MinPlus r;
+    if (c.s) return c;
+    r.a = sat_add(p.a, c.a);
+    r.b = imin(sat_add(p.b, c.a), c.b);
+    r.s = p.s;
+    return r;
+}
+inline MinPlus scan_minplus(MinPlus x) {
+    int64_t p[3] = {x.a, x.b, x.s};
+    int par = W().rendezvous(T_SCAN_MP, p, 3);
+    W().check(par, T_SCAN_MP);
+    MinPlus acc = {0, 0x7fffffff, 0};
+    for (int l = 0; l <= lane(); ++l) {
+        MinPlus c = {(int)W().slot[par][l][0], (int)W().slot[par][l][1], (int)W().slot[par][l][2]};
+        acc = mp_compose(acc, c);
+    }
+    return acc;
+}
+inline MinPlus bcast_last(MinPlus v) {
+    MinPlus r;
+    r.a = bcast_last(v.a);
+    r.b = bcast_last(v.b);
+    r.s = bcast_last(v.s);
+    return r;
+}
+
+inline void atomic_add(int *p, int v) { *p += v; }
+inline void atomic_add(unsigned *p, unsigned v) { *p += v; }
+inline void atomic_min(int *p, int v) { if (v < *p) *p = v; }
+inline void atomic_max(int *p, int v) { if (v > *p) *p = v; }
+inline void atomic_or(int *p, int v) { *p |= v; }
+inline unsigned long long atomic_add_global(unsigned long long *p, unsigned long long v) {
+    unsigned long long o = *p;
+    *p += v;
+    return o;
+}
+inline unsigned atomic_add_global(unsigned *p, unsigned v) {
+    unsigned o = *p;
+    *p += v;
+    return o;
+}
+
+}  // namespace wv
