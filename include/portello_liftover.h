@@ -206,9 +206,14 @@ plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t sta
 plo_status plo_liftover_batch_dev(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
 
 plo_status plo_ctx_sync(plo_ctx *ctx);
+/* Copies `bytes` from device memory (e.g. a plo_liftover_batch_dev output array) to host memory on the context's
+   stream and waits for it. */
+plo_status plo_ctx_download(plo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 plo_status plo_ctx_timing(plo_ctx *ctx, plo_timing *out);
 const char *plo_last_error(const plo_ctx *ctx);
 const char *plo_version(void);
+/* Device self-test of the wavefront primitives (DPP scans, cross-lane reads): 0 = ok. */
+int plo_selftest(int device);
 
 #ifdef __cplusplus
 }

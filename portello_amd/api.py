@@ -60,6 +60,8 @@ def load_library(path: Optional[str] = None):
     L.plo_liftover_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
     L.plo_ctx_sync.restype = C.c_int
     L.plo_ctx_sync.argtypes = [vp]
+    L.plo_ctx_download.restype = C.c_int
+    L.plo_ctx_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.plo_ctx_timing.restype = C.c_int
     L.plo_ctx_timing.argtypes = [vp, C.POINTER(abi.PloTiming)]
     L.plo_last_error.restype = C.c_char_p
@@ -137,6 +139,15 @@ class Engine:
         out = abi.PloBatchOut()
         self._check(self.lib.plo_liftover_batch_dev(self.handle, C.byref(desc), stages, C.byref(out)), "plo_liftover_batch_dev")
         return out
+
+    def download(self, dev_ptr, dtype, count: int) -> np.ndarray:
+        """copy `count` elements of `dtype` from a device pointer (e.g. a plo_batch_out array) to a numpy array"""
+        out = np.zeros(max(1, count), dtype=dtype)
+        addr = C.cast(dev_ptr, C.c_void_p).value if not isinstance(dev_ptr, int) else dev_ptr
+        if count:
+            self._check(self.lib.plo_ctx_download(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(addr),
+                                                  count * out.itemsize), "plo_ctx_download")
+        return out[:count]
 
     def sync(self):
         self._check(self.lib.plo_ctx_sync(self.handle), "plo_ctx_sync")

@@ -1,0 +1,36 @@
+"""Builds libportello_liftover.so (HIP, gfx950) in-tree.  `python -m portello_amd.build`"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libportello_liftover.so")
+SOURCES = ["engine.hip"]
+HEADERS = ["plo_wave.hpp", "lift_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "portello_liftover.h")]
+    stale = (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    if not (force or stale):
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + (extra or [])
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]))

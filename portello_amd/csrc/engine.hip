@@ -1,0 +1,852 @@
+// engine.hip -- gfx950 kernels + the C ABI of include/portello_liftover.h.
+//
+// Kernel pipeline of one batch (all on the context's stream):
+//   k_seg_count      one thread per read split segment: how many contig segments does it touch (a8)
+//   scan             exclusive scan -> item offsets, n_items
+//   k_item_emit      writes the item list (read segment, contig segment index, input op count)
+//   scan             exclusive scan of the input op counts -> item_op_prefix (tile assignment)
+//   k_lift_tiles     DOMINANT KERNEL: one wave per tile of items, whole strand/shift/liftover/simplify pipeline in LDS
+//   k_lift_big       items too long for a shared LDS tile: one wave per item, wave-private global scratch
+// There is no CPU path: every entry point fails with PLO_ERR_NO_DEVICE / PLO_ERR_HIP when the device is unusable.
+#include <hip/hip_runtime.h>
+
+#include <plo_wave.hpp>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "enumerate.hpp"
+#include "index_pack.hpp"
+#include "lift_core.hpp"
+
+using namespace plo;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------------
+
+__global__ void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bt.n_segs) return;
+    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, nullptr, nullptr, 0);
+}
+
+__global__ void k_item_emit(DevIndex ix, DevBatch bt, const uint32_t *seg_off, uint32_t *item_seg, uint32_t *item_cseg,
+                            uint32_t *item_nin) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bt.n_segs) return;
+    if (seg_off[s + 1] == seg_off[s]) return;
+    enumerate_segment(ix, bt, s, item_seg, item_cseg, item_nin, seg_off[s]);
+}
+
+__global__ void k_item_nin(DevBatch bt, const uint32_t *item_seg, uint32_t n_items, uint32_t *item_nin) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t s = item_seg[i];
+    item_nin[i] = bt.seg_cigar_off[s + 1] - bt.seg_cigar_off[s];
+}
+
+// ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_tot /*[4]*/, unsigned &block_total) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = (unsigned)wv::scan_add((int)v);
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += wave_tot[k];
+    block_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return inc + base;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const uint32_t *in, uint32_t n, uint32_t *partial) {
+    __shared__ unsigned wt[4];
+    uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    unsigned s = 0;
+    for (int k = 0; k < SCAN_PER_THREAD; ++k)
+        if (base + k < n) s += in[base + k];
+    unsigned tot;
+    block_scan_incl(s, wt, tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(uint32_t *partial, uint32_t nb, uint32_t *out, uint32_t n) {
+    __shared__ unsigned wt[4];
+    unsigned carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        uint32_t i = b0 + threadIdx.x;
+        unsigned v = i < nb ? partial[i] : 0;
+        unsigned tot;
+        unsigned inc = block_scan_incl(v, wt, tot);
+        if (i < nb) partial[i] = carry + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in, uint32_t n, const uint32_t *partial,
+                                                             uint32_t *out) {
+    __shared__ unsigned wt[4];
+    uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    unsigned v[SCAN_PER_THREAD];
+    unsigned s = 0;
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    unsigned tot;
+    unsigned inc = block_scan_incl(s, wt, tot);
+    unsigned run = partial[blockIdx.x] + inc - s;
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- the dominant kernel: one wave per tile ---------------------------------------------------------------------
+constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its own tile with its own LDS slice
+
+__global__ __launch_bounds__(TILE_WAVES * 64) void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+                                                               uint32_t n_tiles, int window, int big_thresh, int cap,
+                                                               uint32_t lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6;
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD a contiguous
+    // range of tiles so that neighbouring reads (same contig region -> same block-map / reference lines) share an L2.
+    uint32_t nb = gridDim.x;
+    uint32_t per = nb >> 3;
+    uint32_t b = blockIdx.x;
+    uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
+    uint32_t tile = tb * TILE_WAVES + (uint32_t)w;
+    if (tile >= n_tiles) return;
+    TileMem m = carve_tile_mem(smem + (size_t)w * lds_per_wave, cap);
+    lift_window(ix, bt, wk, stages, tile, window, big_thresh, m);
+}
+
+__global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
+                                                 unsigned char *scratch, int big_cap, unsigned long long bytes_per_wave) {
+    TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
+    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
+        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0);
+        wv::sync();
+    }
+}
+
+// ---- self-test of the wave primitives (plo_selftest) -------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_selftest(const int *in, int *out) {
+    int lane = wv::lane();
+    int x = in[lane];
+    out[0 * 64 + lane] = wv::scan_add(x);
+    out[1 * 64 + lane] = wv::scan_max(x);
+    out[2 * 64 + lane] = wv::shfl_up1(x, -7);
+    out[3 * 64 + lane] = wv::shfl(x, (lane * 7 + 3) & 63);
+    out[4 * 64 + lane] = wv::bcast_last(x);
+    out[5 * 64 + lane] = wv::bcast_first(x);
+    wv::MinPlus f;
+    f.a = in[64 + lane];
+    f.b = in[128 + lane];
+    f.s = in[192 + lane];
+    wv::MinPlus F = wv::scan_minplus(f);
+    out[6 * 64 + lane] = F.a;
+    out[7 * 64 + lane] = F.b;
+    out[8 * 64 + lane] = F.s;
+    unsigned long long bm = wv::ballot((x & 1) != 0);
+    out[9 * 64 + lane] = (int)((bm >> lane) & 1ull);
+    AddScan as;
+    MaxScan ms(-1);
+    int a0 = as.excl(x & 15), a1 = as.excl((x >> 4) & 15);
+    int m0 = ms.incl((x & 3) == 0 ? lane : -1);
+    int e0 = ms.excl_of(m0);
+    int m1 = ms.incl((x & 3) == 1 ? 64 + lane : -1);
+    int e1 = ms.excl_of(m1);
+    out[10 * 64 + lane] = a0;
+    out[11 * 64 + lane] = a1;
+    out[12 * 64 + lane] = e0;
+    out[13 * 64 + lane] = e1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
+struct HostBuf {  // pinned
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
+}  // namespace
+
+struct plo_index {
+    int device = 0;
+    PackedIndex host;  // host copy of the packed arrays (plo_index_segment_map, validation)
+    DevIndex d{};
+    std::vector<void *> owned;  // device allocations owned by the index
+    uint32_t max_segs_per_contig = 0;
+};
+
+struct plo_ctx {
+    const plo_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // workspace
+    DevBuf seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch;
+    // outputs (device)
+    DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar;
+    // host staging for plo_liftover_batch
+    DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
+        i_item_seg, i_item_cseg;
+    HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_big = false;
+    plo_timing timing{};
+    // tuning
+    int window = 160, big_thresh = 176, cap = 512;
+};
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                     \
+            return (_e == hipErrorOutOfMemory) ? PLO_ERR_OUT_OF_MEMORY : PLO_ERR_HIP;           \
+        }                                                                                       \
+    } while (0)
+
+static thread_local std::string g_index_err;
+
+template <class T>
+static hipError_t upload(std::vector<void *> &owned, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    owned.push_back(p);
+    if (!v.empty()) {
+        e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    *out = (const T *)p;
+    return hipSuccess;
+}
+
+extern "C" {
+
+const char *plo_version(void) { return "portello-liftover-mi355x 0.1 (gfx950)"; }
+
+plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out) {
+    if (!desc || !out) return PLO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PLO_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PLO_ERR_NO_DEVICE;
+    plo_index *ix = new plo_index();
+    ix->device = device;
+    std::string err;
+    plo_status st = pack_index(desc, ix->host, err);
+    if (st != PLO_OK) {
+        g_index_err = err;
+        delete ix;
+        return st;
+    }
+    for (uint32_t c = 0; c < desc->n_contigs; ++c)
+        ix->max_segs_per_contig = std::max(ix->max_segs_per_contig, ix->host.contig_seg_off[c + 1] - ix->host.contig_seg_off[c]);
+    auto fail = [&](plo_status s) {
+        for (void *p : ix->owned) (void)hipFree(p);
+        delete ix;
+        return s;
+    };
+    DevIndex &d = ix->d;
+    const PackedIndex &h = ix->host;
+    if (upload(ix->owned, h.kv, &d.kv) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_kv_off, &d.cs_kv_off) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_chrom, &d.cs_chrom) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_is_fwd, &d.cs_is_fwd) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_mapq, &d.cs_mapq) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_start, &d.cs_start) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.cs_end, &d.cs_end) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.contig_seg_off, &d.contig_seg_off) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.contig_len, &d.contig_len) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, h.chrom_len, &d.chrom_len) != hipSuccess) return fail(PLO_ERR_HIP);
+    d.n_contigs = desc->n_contigs;
+    d.n_segments = desc->n_segments;
+    d.n_chroms = desc->n_chroms;
+    // sequences: copied from the host or borrowed from the device
+    std::vector<const uint8_t *> chrom_ptr(desc->n_chroms, nullptr), rev_ptr(desc->n_contigs, nullptr);
+    for (uint32_t c = 0; c < desc->n_chroms; ++c) {
+        const uint8_t *src = desc->chrom_seq[c];
+        if (!src && desc->chrom_len[c] > 0) return fail(PLO_ERR_INVALID_ARG);
+        if (desc->seq_mem == PLO_MEM_DEVICE) {
+            chrom_ptr[c] = src;
+        } else {
+            void *p = nullptr;
+            size_t bytes = std::max<size_t>((size_t)desc->chrom_len[c], 16);
+            if (hipMalloc(&p, bytes) != hipSuccess) return fail(PLO_ERR_OUT_OF_MEMORY);
+            ix->owned.push_back(p);
+            if (desc->chrom_len[c] > 0 && hipMemcpy(p, src, (size_t)desc->chrom_len[c], hipMemcpyHostToDevice) != hipSuccess)
+                return fail(PLO_ERR_HIP);
+            chrom_ptr[c] = (const uint8_t *)p;
+        }
+    }
+    for (uint32_t c = 0; c < desc->n_contigs; ++c) {
+        const uint8_t *src = desc->rev_contig_seq ? desc->rev_contig_seq[c] : nullptr;
+        if (!src) continue;
+        if (desc->seq_mem == PLO_MEM_DEVICE) {
+            rev_ptr[c] = src;
+        } else {
+            void *p = nullptr;
+            size_t bytes = std::max<size_t>((size_t)desc->contig_len[c], 16);
+            if (hipMalloc(&p, bytes) != hipSuccess) return fail(PLO_ERR_OUT_OF_MEMORY);
+            ix->owned.push_back(p);
+            if (desc->contig_len[c] > 0 && hipMemcpy(p, src, (size_t)desc->contig_len[c], hipMemcpyHostToDevice) != hipSuccess)
+                return fail(PLO_ERR_HIP);
+            rev_ptr[c] = (const uint8_t *)p;
+        }
+    }
+    if (upload(ix->owned, chrom_ptr, &d.chrom_seq) != hipSuccess) return fail(PLO_ERR_HIP);
+    if (upload(ix->owned, rev_ptr, &d.contig_revseq) != hipSuccess) return fail(PLO_ERR_HIP);
+    *out = ix;
+    return PLO_OK;
+}
+
+void plo_index_destroy(plo_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    for (void *p : ix->owned) (void)hipFree(p);
+    delete ix;
+}
+
+plo_status plo_index_segment_map(const plo_index *ix, uint32_t g, uint32_t cap, int64_t *keys, int64_t *vals, uint32_t *n) {
+    if (!ix || !n || g >= ix->d.n_segments) return PLO_ERR_INVALID_ARG;
+    uint32_t k0 = ix->host.cs_kv_off[g], k1 = ix->host.cs_kv_off[g + 1];
+    *n = k1 - k0;
+    if (keys && vals) {
+        for (uint32_t i = 0; i < std::min(cap, k1 - k0); ++i) {
+            keys[i] = ix->host.kv[k0 + i].key;
+            vals[i] = ix->host.kv[k0 + i].val == NONE32 ? INT64_MIN : (int64_t)ix->host.kv[k0 + i].val;
+        }
+    }
+    return PLO_OK;
+}
+
+plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) {
+    if (!ix || !out) return PLO_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (hipSetDevice(ix->device) != hipSuccess) return PLO_ERR_NO_DEVICE;
+    plo_ctx *c = new plo_ctx();
+    c->ix = ix;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return PLO_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) {
+            delete c;
+            return PLO_ERR_HIP;
+        }
+    (void)hipFuncSetAttribute((const void *)k_lift_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e));
+    if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e));
+    if (const char *e = getenv("PLO_CAP")) c->cap = std::max(64, atoi(e));
+    *out = c;
+    return PLO_OK;
+}
+
+void plo_ctx_destroy(plo_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ix->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->counters, &c->big_list, &c->scratch, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
+                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
+                      &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
+                      &c->i_item_seg, &c->i_item_cseg};
+    for (DevBuf *b : bufs) b->release();
+    HostBuf *hb[] = {&c->h_item_seg, &c->h_item_cseg, &c->h_status, &c->h_flip, &c->h_mapq, &c->h_chrom, &c->h_pos,
+                     &c->h_coff, &c->h_clen, &c->h_cigar, &c->h_counters};
+    for (HostBuf *b : hb) b->release();
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *plo_last_error(const plo_ctx *c) { return c ? c->err.c_str() : g_index_err.c_str(); }
+
+plo_status plo_ctx_sync(plo_ctx *c) {
+    if (!c) return PLO_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PLO_OK;
+}
+
+plo_status plo_ctx_download(plo_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
+    if (!c || (bytes && (!host_dst || !dev_src))) return PLO_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PLO_OK;
+}
+
+static plo_status scan_u32(plo_ctx *c, const uint32_t *in, uint32_t n, uint32_t *out /* n+1 */) {
+    uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb == 0) nb = 1;
+    HIP_TRY(c, c->scan_partial.ensure((size_t)nb * 4));
+    uint32_t *partial = c->scan_partial.as<uint32_t>();
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(SCAN_THREADS), 0, c->stream, in, n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, c->stream, partial, nb, out, n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, c->stream, in, n, (const uint32_t *)partial, out);
+    HIP_TRY(c, hipGetLastError());
+    return PLO_OK;
+}
+
+plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t stages, plo_batch_out *out) {
+    if (!c || !in || !out) return PLO_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    c->err.clear();
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    if (in->n_segs && (!in->seg_read || !in->seg_contig || !in->seg_pos || !in->seg_is_fwd_strand || !in->seg_cigar_off)) {
+        c->err = "plo_batch_in: NULL segment array";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (in->seq_fmt != PLO_SEQ_BAM4 && in->seq_fmt != PLO_SEQ_ASCII) {
+        c->err = "plo_batch_in: unknown seq_fmt";
+        return PLO_ERR_INVALID_ARG;
+    }
+    DevBatch bt;
+    bt.read_is_reverse = in->read_is_reverse;
+    bt.read_seq_len = in->read_seq_len;
+    bt.read_seq_off = in->read_seq_off;
+    bt.seq = in->seq;
+    bt.seq_fmt = in->seq_fmt;
+    bt.seg_read = in->seg_read;
+    bt.seg_contig = in->seg_contig;
+    bt.seg_pos = in->seg_pos;
+    bt.seg_is_fwd = in->seg_is_fwd_strand;
+    bt.seg_cigar_off = in->seg_cigar_off;
+    bt.cigar = in->cigar;
+    bt.n_reads = in->n_reads;
+    bt.n_segs = in->n_segs;
+    const DevIndex &ix = c->ix->d;
+    hipStream_t st = c->stream;
+    memset(&c->timing, 0, sizeof(c->timing));
+    c->ev_big = false;
+
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    // ---- items ----
+    uint32_t n_items = 0;
+    const uint32_t *item_seg = nullptr, *item_cseg = nullptr;
+    HIP_TRY(c, c->h_counters.ensure(64 * 8));
+    if (in->item_seg) {
+        n_items = in->n_items;
+        item_seg = in->item_seg;
+        item_cseg = in->item_cseg;
+        HIP_TRY(c, c->item_nin.ensure((size_t)std::max(1u, n_items) * 4));
+        if (n_items)
+            hipLaunchKernelGGL(k_item_nin, dim3((n_items + 255) / 256), dim3(256), 0, st, bt, item_seg, n_items,
+                               c->item_nin.as<uint32_t>());
+    } else {
+        uint32_t ns = in->n_segs;
+        HIP_TRY(c, c->seg_cnt.ensure((size_t)std::max(1u, ns) * 4));
+        HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
+        if (ns) hipLaunchKernelGGL(k_seg_count, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>());
+        plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
+        if (s != PLO_OK) return s;
+        uint32_t *h = c->h_counters.as<uint32_t>();
+        HIP_TRY(c, hipMemcpyAsync(h, c->seg_off.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        n_items = h[0];
+        HIP_TRY(c, c->item_seg.ensure((size_t)std::max(1u, n_items) * 4));
+        HIP_TRY(c, c->item_cseg.ensure((size_t)std::max(1u, n_items) * 4));
+        HIP_TRY(c, c->item_nin.ensure((size_t)std::max(1u, n_items) * 4));
+        if (ns && n_items)
+            hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt,
+                               (const uint32_t *)c->seg_off.as<uint32_t>(), c->item_seg.as<uint32_t>(),
+                               c->item_cseg.as<uint32_t>(), c->item_nin.as<uint32_t>());
+        item_seg = c->item_seg.as<uint32_t>();
+        item_cseg = c->item_cseg.as<uint32_t>();
+    }
+    HIP_TRY(c, c->op_prefix.ensure((size_t)(n_items + 1) * 4));
+    {
+        plo_status s = scan_u32(c, c->item_nin.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
+        if (s != PLO_OK) return s;
+    }
+    uint32_t total_ops = 0;
+    {
+        uint32_t *h = c->h_counters.as<uint32_t>();
+        HIP_TRY(c, hipMemcpyAsync(h, c->op_prefix.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        total_ops = h[0];
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+
+    // ---- outputs ----
+    size_t ni = std::max(1u, n_items);
+    HIP_TRY(c, c->o_status.ensure(ni));
+    HIP_TRY(c, c->o_flip.ensure(ni));
+    HIP_TRY(c, c->o_mapq.ensure(ni));
+    HIP_TRY(c, c->o_chrom.ensure(ni * 4));
+    HIP_TRY(c, c->o_pos.ensure(ni * 8));
+    HIP_TRY(c, c->o_coff.ensure(ni * 8));
+    HIP_TRY(c, c->o_clen.ensure(ni * 4));
+    HIP_TRY(c, c->big_list.ensure(ni * 4));
+    HIP_TRY(c, c->counters.ensure(CNT_N * 8));
+    size_t want_cigar = (size_t)total_ops * 2 + (size_t)n_items * 8 + 4096;
+    if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
+
+    unsigned long long *hc = c->h_counters.as<unsigned long long>();
+    uint32_t n_big = 0;
+    for (int attempt = 0;; ++attempt) {
+        DevWork wk;
+        wk.n_items = n_items;
+        wk.item_seg = item_seg;
+        wk.item_cseg = item_cseg;
+        wk.item_op_prefix = c->op_prefix.as<uint32_t>();
+        wk.status = c->o_status.as<uint8_t>();
+        wk.flip = c->o_flip.as<uint8_t>();
+        wk.mapq = c->o_mapq.as<uint8_t>();
+        wk.chrom = c->o_chrom.as<uint32_t>();
+        wk.pos = c->o_pos.as<int64_t>();
+        wk.cig_off = c->o_coff.as<uint64_t>();
+        wk.cig_len = c->o_clen.as<uint32_t>();
+        wk.out_cigar = c->o_cigar.as<uint32_t>();
+        wk.out_cap = c->o_cigar.cap / 4;
+        wk.counters = c->counters.as<unsigned long long>();
+        wk.big_list = c->big_list.as<uint32_t>();
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
+        if (attempt == 0) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+        if (n_items) {
+            uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
+            uint32_t nblk = (n_tiles + TILE_WAVES - 1) / TILE_WAVES;
+            nblk = (nblk + 7u) & ~7u;
+            uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
+            hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(TILE_WAVES * 64), lds_per_wave * TILE_WAVES, st, ix, bt, wk, stages,
+                               n_tiles, c->window, c->big_thresh, c->cap, lds_per_wave);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(c->ev[2], st));
+        HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        n_big = (uint32_t)hc[CNT_NBIG];
+        if (n_big) {
+            // size the wave-private scratch from the largest possible intermediate of a single item
+            int big_cap = 1 << 16;
+            if (const char *e = getenv("PLO_BIG_CAP")) big_cap = std::max(1024, atoi(e));
+            unsigned long long bpw = (tile_mem_bytes(big_cap) + 255) & ~(unsigned long long)255;
+            uint32_t nw = std::min<uint32_t>(n_big, 1024u);
+            HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
+            hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_big, c->scratch.as<unsigned char>(),
+                               big_cap, bpw);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->ev[3], st));
+            c->ev_big = true;
+            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        if (hc[CNT_OVERFLOW] == 0) break;
+        if (attempt >= 3) {
+            c->err = "output CIGAR buffer kept overflowing";
+            return PLO_ERR_INTERNAL;
+        }
+        HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + 4096) * 4));
+    }
+    if (hc[CNT_ERROR]) {
+        c->err = "an item exceeded the large-item scratch capacity (raise PLO_BIG_CAP)";
+        return PLO_ERR_INTERNAL;
+    }
+    c->timing.n_items = n_items;
+    c->timing.n_big_items = n_big;
+    c->timing.n_in_ops = hc[CNT_IN_OPS];
+    c->timing.n_out_ops = hc[CNT_CIGAR];
+    c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
+
+    out->n_items = n_items;
+    out->item_seg = item_seg;
+    out->item_cseg = item_cseg;
+    out->item_status = c->o_status.as<uint8_t>();
+    out->item_need_flipped = c->o_flip.as<uint8_t>();
+    out->item_mapq = c->o_mapq.as<uint8_t>();
+    out->item_chrom_index = c->o_chrom.as<uint32_t>();
+    out->item_ref_pos = c->o_pos.as<int64_t>();
+    out->item_cigar_off = c->o_coff.as<uint64_t>();
+    out->item_cigar_len = c->o_clen.as<uint32_t>();
+    out->cigar = c->o_cigar.as<uint32_t>();
+    out->n_cigar = hc[CNT_CIGAR];
+    return PLO_OK;
+}
+
+plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
+    if (!c || !t) return PLO_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float a = 0, b = 0, g = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev[2], c->ev[3]);
+    c->timing.enumerate_ms = a;
+    c->timing.lift_ms = b;
+    c->timing.big_ms = g;
+    c->timing.total_ms = a + b + g;
+    *t = c->timing;
+    return PLO_OK;
+}
+
+plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stages, plo_batch_out *out) {
+    if (!c || !in || !out) return PLO_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    c->err.clear();
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    hipStream_t st = c->stream;
+    uint32_t nr = in->n_reads, ns = in->n_segs;
+    // host-side validation (the device path trusts its inputs)
+    uint32_t n_cigar = ns ? in->seg_cigar_off[ns] : 0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        if (in->seg_read[s] >= nr || in->seg_contig[s] >= c->ix->d.n_contigs || in->seg_cigar_off[s + 1] < in->seg_cigar_off[s]) {
+            c->err = "plo_batch_in: segment index out of range";
+            return PLO_ERR_INVALID_ARG;
+        }
+        if (!fits31(in->seg_pos[s])) {
+            c->err = "plo_batch_in: seg_pos outside the 31-bit BAM range";
+            return PLO_ERR_RANGE;
+        }
+        unsigned long long span = 0;
+        for (uint32_t i = in->seg_cigar_off[s]; i < in->seg_cigar_off[s + 1]; ++i) {
+            if ((in->cigar[i] & 15u) > 8u) {
+                c->err = "plo_batch_in: invalid CIGAR op code";
+                return PLO_ERR_RANGE;
+            }
+            span += in->cigar[i] >> 4;
+        }
+        if (span > 0x3fffffffull) {
+            c->err = "plo_batch_in: CIGAR spans more than 2^30 bases";
+            return PLO_ERR_RANGE;
+        }
+    }
+    for (uint32_t r = 0; r < nr; ++r) {
+        unsigned long long need = in->seq_fmt == PLO_SEQ_BAM4 ? ((unsigned long long)in->read_seq_len[r] + 1) / 2 : in->read_seq_len[r];
+        if (in->read_seq_off[r] + need > in->seq_bytes) {
+            c->err = "plo_batch_in: read sequence outside seq buffer";
+            return PLO_ERR_INVALID_ARG;
+        }
+    }
+    if (in->item_seg) {
+        for (uint32_t i = 0; i < in->n_items; ++i) {
+            uint32_t s = in->item_seg[i];
+            if (s >= ns) {
+                c->err = "plo_batch_in: item_seg out of range";
+                return PLO_ERR_INVALID_ARG;
+            }
+            uint32_t ctg = in->seg_contig[s];
+            if (in->item_cseg[i] >= c->ix->host.contig_seg_off[ctg + 1] - c->ix->host.contig_seg_off[ctg]) {
+                c->err = "plo_batch_in: item_cseg out of range";
+                return PLO_ERR_INVALID_ARG;
+            }
+        }
+    }
+#define UP(buf, src, bytes)                                                                          \
+    do {                                                                                             \
+        HIP_TRY(c, (buf).ensure(std::max<size_t>((bytes), 16)));                                     \
+        if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((buf).p, (src), (bytes), hipMemcpyHostToDevice, st)); \
+    } while (0)
+    UP(c->i_read_rev, in->read_is_reverse, (size_t)nr);
+    UP(c->i_read_len, in->read_seq_len, (size_t)nr * 4);
+    UP(c->i_read_off, in->read_seq_off, (size_t)nr * 8);
+    UP(c->i_seq, in->seq, (size_t)in->seq_bytes);
+    UP(c->i_seg_read, in->seg_read, (size_t)ns * 4);
+    UP(c->i_seg_contig, in->seg_contig, (size_t)ns * 4);
+    UP(c->i_seg_pos, in->seg_pos, (size_t)ns * 8);
+    UP(c->i_seg_fwd, in->seg_is_fwd_strand, (size_t)ns);
+    HIP_TRY(c, c->i_seg_coff.ensure((size_t)(ns + 1) * 4));
+    if (ns) {
+        HIP_TRY(c, hipMemcpyAsync(c->i_seg_coff.p, in->seg_cigar_off, (size_t)(ns + 1) * 4, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->i_seg_coff.p, 0, 4, st));
+    }
+    UP(c->i_cigar, in->cigar, (size_t)n_cigar * 4);
+    plo_batch_in din = *in;
+    din.read_is_reverse = c->i_read_rev.as<uint8_t>();
+    din.read_seq_len = c->i_read_len.as<uint32_t>();
+    din.read_seq_off = c->i_read_off.as<uint64_t>();
+    din.seq = c->i_seq.as<uint8_t>();
+    din.seg_read = c->i_seg_read.as<uint32_t>();
+    din.seg_contig = c->i_seg_contig.as<uint32_t>();
+    din.seg_pos = c->i_seg_pos.as<int64_t>();
+    din.seg_is_fwd_strand = c->i_seg_fwd.as<uint8_t>();
+    din.seg_cigar_off = c->i_seg_coff.as<uint32_t>();
+    din.cigar = c->i_cigar.as<uint32_t>();
+    if (in->item_seg) {
+        UP(c->i_item_seg, in->item_seg, (size_t)in->n_items * 4);
+        UP(c->i_item_cseg, in->item_cseg, (size_t)in->n_items * 4);
+        din.item_seg = c->i_item_seg.as<uint32_t>();
+        din.item_cseg = c->i_item_cseg.as<uint32_t>();
+    }
+#undef UP
+    plo_batch_out dout;
+    plo_status s = plo_liftover_batch_dev(c, &din, stages, &dout);
+    if (s != PLO_OK) return s;
+    size_t ni = dout.n_items, nc = (size_t)dout.n_cigar;
+#define DOWN(hbuf, src, bytes)                                                                        \
+    do {                                                                                              \
+        HIP_TRY(c, (hbuf).ensure(std::max<size_t>((bytes), 16)));                                     \
+        if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((hbuf).p, (src), (bytes), hipMemcpyDeviceToHost, st)); \
+    } while (0)
+    DOWN(c->h_item_seg, dout.item_seg, ni * 4);
+    DOWN(c->h_item_cseg, dout.item_cseg, ni * 4);
+    DOWN(c->h_status, dout.item_status, ni);
+    DOWN(c->h_flip, dout.item_need_flipped, ni);
+    DOWN(c->h_mapq, dout.item_mapq, ni);
+    DOWN(c->h_chrom, dout.item_chrom_index, ni * 4);
+    DOWN(c->h_pos, dout.item_ref_pos, ni * 8);
+    DOWN(c->h_coff, dout.item_cigar_off, ni * 8);
+    DOWN(c->h_clen, dout.item_cigar_len, ni * 4);
+    DOWN(c->h_cigar, dout.cigar, nc * 4);
+#undef DOWN
+    HIP_TRY(c, hipStreamSynchronize(st));
+    out->n_items = dout.n_items;
+    out->item_seg = c->h_item_seg.as<uint32_t>();
+    out->item_cseg = c->h_item_cseg.as<uint32_t>();
+    out->item_status = c->h_status.as<uint8_t>();
+    out->item_need_flipped = c->h_flip.as<uint8_t>();
+    out->item_mapq = c->h_mapq.as<uint8_t>();
+    out->item_chrom_index = c->h_chrom.as<uint32_t>();
+    out->item_ref_pos = c->h_pos.as<int64_t>();
+    out->item_cigar_off = c->h_coff.as<uint64_t>();
+    out->item_cigar_len = c->h_clen.as<uint32_t>();
+    out->cigar = c->h_cigar.as<uint32_t>();
+    out->n_cigar = dout.n_cigar;
+    return PLO_OK;
+}
+
+
+// Runs the wave primitives on the device and checks them against host-computed expectations.
+// 0 = ok, >0 = index of the first failing primitive + 1, <0 = HIP error.
+int plo_selftest(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    std::vector<int> in(256), out(14 * 64, 0), exp(14 * 64, 0);
+    unsigned rs = 12345u;
+    auto rnd = [&]() {
+        rs = rs * 1664525u + 1013904223u;
+        return (int)(rs >> 8);
+    };
+    for (int l = 0; l < 64; ++l) {
+        in[l] = rnd() % 1000 - 300;
+        in[64 + l] = rnd() % 50;
+        in[128 + l] = (rnd() % 4 == 0) ? 0x7fffffff : rnd() % 80;
+        in[192 + l] = (rnd() % 9 == 0) ? 1 : 0;
+    }
+    int acc = 0, mx = (int)0x80000000;
+    int fa = 0, fb = 0x7fffffff, fs = 0;
+    int c0 = 0, c1 = 0, lm = -1;
+    for (int l = 0; l < 64; ++l) c1 += in[l] & 15;
+    for (int l = 0; l < 64; ++l) {
+        int x = in[l];
+        acc += x;
+        mx = std::max(mx, x);
+        exp[0 * 64 + l] = acc;
+        exp[1 * 64 + l] = mx;
+        exp[2 * 64 + l] = l ? in[l - 1] : -7;
+        exp[3 * 64 + l] = in[(l * 7 + 3) & 63];
+        exp[4 * 64 + l] = in[63];
+        exp[5 * 64 + l] = in[0];
+        int a = in[64 + l], b = in[128 + l], sflag = in[192 + l];
+        if (sflag) {
+            fa = a;
+            fb = b;
+            fs = 1;
+        } else {
+            long long na = (long long)fa + a, nb = (long long)fb + a;
+            fa = na > 0x7fffffffLL ? 0x7fffffff : (int)na;
+            int nbb = nb > 0x7fffffffLL ? 0x7fffffff : (int)nb;
+            fb = std::min(nbb, b);
+        }
+        exp[6 * 64 + l] = fa;
+        exp[7 * 64 + l] = fb;
+        exp[8 * 64 + l] = fs;
+        exp[9 * 64 + l] = x & 1;
+        exp[10 * 64 + l] = c0;
+        c0 += x & 15;
+        exp[11 * 64 + l] = c1;
+        c1 += (x >> 4) & 15;
+        exp[12 * 64 + l] = lm;
+        if ((x & 3) == 0) lm = l;
+    }
+    int lm2 = lm;
+    for (int l = 0; l < 64; ++l) {
+        exp[13 * 64 + l] = lm2;
+        if ((in[l] & 3) == 1) lm2 = std::max(lm2, 64 + l);
+    }
+    int *din = nullptr, *dout = nullptr;
+    if (hipMalloc(&din, in.size() * 4) != hipSuccess || hipMalloc(&dout, out.size() * 4) != hipSuccess) return -2;
+    if (hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -3;
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, (const int *)din, dout);
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -5;
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    for (int k = 0; k < 14; ++k)
+        for (int l = 0; l < 64; ++l)
+            if (out[k * 64 + l] != exp[k * 64 + l]) {
+                fprintf(stderr, "plo_selftest: primitive %d lane %d got %d expected %d\n", k, l, out[k * 64 + l], exp[k * 64 + l]);
+                return k + 1;
+            }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""Device-resident batches: builds a ``plo_batch_in`` whose arrays are torch tensors already in HBM (the form the
+bench times: inputs resident on the GPU when the timed region starts), and downloads ``plo_batch_out`` arrays."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import abi
+
+
+def _p(t: torch.Tensor, ctype):
+    return C.cast(C.c_void_p(t.data_ptr()), C.POINTER(ctype))
+
+
+@dataclass
+class DeviceBatch:
+    read_is_reverse: torch.Tensor  # uint8
+    read_seq_len: torch.Tensor     # int32 (bit pattern of uint32)
+    read_seq_off: torch.Tensor     # int64 (bit pattern of uint64)
+    seq: torch.Tensor              # uint8
+    seq_fmt: int
+    seg_read: torch.Tensor         # int32
+    seg_contig: torch.Tensor       # int32
+    seg_pos: torch.Tensor          # int64
+    seg_is_fwd_strand: torch.Tensor  # uint8
+    seg_cigar_off: torch.Tensor    # int32 [n_segs+1]
+    cigar: torch.Tensor            # int32 (bit pattern of uint32)
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_seq_len.numel())
+
+    @property
+    def n_segs(self) -> int:
+        return int(self.seg_read.numel())
+
+    @classmethod
+    def from_workload(cls, w, read_lo: int = 0, read_hi: Optional[int] = None) -> "DeviceBatch":
+        """Slice reads [read_lo, read_hi) of a synth.Workload living on the GPU (offsets re-based)."""
+        dev = w.device
+        assert dev.type == "cuda"
+        hi = w.n_reads if read_hi is None else read_hi
+        lo = read_lo
+        seg_lo = int(torch.searchsorted(w.seg_read, torch.tensor(lo, device=dev)).item())
+        seg_hi = int(torch.searchsorted(w.seg_read, torch.tensor(hi, device=dev)).item())
+        co = w.seg_cigar_off_r[seg_lo: seg_hi + 1]
+        c0 = int(co[0].item()) if co.numel() else 0
+        c1 = int(co[-1].item()) if co.numel() else 0
+        so = w.read_seq_off[lo:hi]
+        sl = w.read_seq_len[lo:hi]
+        if hi > lo:
+            b0 = int(so[0].item())
+            last = int(sl[-1].item())
+            b1 = int(so[-1].item()) + ((last + 1) // 2 if w.cfg.seq_fmt == abi.SEQ_BAM4 else last)
+        else:
+            b0 = b1 = 0
+        return cls(
+            read_is_reverse=w.read_is_reverse[lo:hi].contiguous(), read_seq_len=sl.to(torch.int32).contiguous(),
+            read_seq_off=(so - b0).to(torch.int64).contiguous(), seq=w.seq[b0:b1].contiguous(), seq_fmt=w.cfg.seq_fmt,
+            seg_read=(w.seg_read[seg_lo:seg_hi] - lo).to(torch.int32).contiguous(),
+            seg_contig=w.seg_contig[seg_lo:seg_hi].to(torch.int32).contiguous(),
+            seg_pos=w.seg_pos_r[seg_lo:seg_hi].to(torch.int64).contiguous(),
+            seg_is_fwd_strand=w.seg_is_fwd_r[seg_lo:seg_hi].contiguous(),
+            seg_cigar_off=(co - c0).to(torch.int32).contiguous(), cigar=w.cigar[c0:c1].to(torch.int32).contiguous())
+
+    def desc(self) -> abi.PloBatchIn:
+        b = abi.PloBatchIn()
+        b.n_reads = self.n_reads
+        b.read_is_reverse = _p(self.read_is_reverse, C.c_uint8)
+        b.read_seq_len = _p(self.read_seq_len, C.c_uint32)
+        b.read_seq_off = _p(self.read_seq_off, C.c_uint64)
+        b.seq = _p(self.seq, C.c_uint8)
+        b.seq_bytes = self.seq.numel()
+        b.seq_fmt = self.seq_fmt
+        b.n_segs = self.n_segs
+        b.seg_read = _p(self.seg_read, C.c_uint32)
+        b.seg_contig = _p(self.seg_contig, C.c_uint32)
+        b.seg_pos = _p(self.seg_pos, C.c_int64)
+        b.seg_is_fwd_strand = _p(self.seg_is_fwd_strand, C.c_uint8)
+        b.seg_cigar_off = _p(self.seg_cigar_off, C.c_uint32)
+        b.cigar = _p(self.cigar, C.c_uint32)
+        b.n_items = 0
+        b.item_seg = C.cast(None, C.POINTER(C.c_uint32))
+        b.item_cseg = C.cast(None, C.POINTER(C.c_uint32))
+        return b
+
+
+def download(eng, out: abi.PloBatchOut) -> abi.BatchResult:
+    n, nc = int(out.n_items), int(out.n_cigar)
+    return abi.BatchResult(
+        item_seg=eng.download(out.item_seg, np.uint32, n), item_cseg=eng.download(out.item_cseg, np.uint32, n),
+        item_status=eng.download(out.item_status, np.uint8, n), item_need_flipped=eng.download(out.item_need_flipped, np.uint8, n),
+        item_mapq=eng.download(out.item_mapq, np.uint8, n), item_chrom_index=eng.download(out.item_chrom_index, np.uint32, n),
+        item_ref_pos=eng.download(out.item_ref_pos, np.int64, n), item_cigar_off=eng.download(out.item_cigar_off, np.uint64, n),
+        item_cigar_len=eng.download(out.item_cigar_len, np.uint32, n), cigar=eng.download(out.cigar, np.uint32, nc))
+
+
+def run_and_download(eng, db: DeviceBatch, stages: int = abi.STAGES_ALL) -> abi.BatchResult:
+    torch.cuda.synchronize()
+    out = eng.liftover_batch_dev(db.desc(), stages)
+    return download(eng, out)

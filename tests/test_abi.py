@@ -1,0 +1,55 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/portello_liftover.h declares, and
+fails loudly (no CPU fallback) when no HIP device is usable.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from portello_amd import abi, api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    return build.build()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "portello_liftover.h")).read()
+    return sorted(set(re.findall(r"^(?:plo_status|void|int|const char \*)\s*\*?(plo_[a-z0-9_]+)\(", text, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    L = C.CDLL(lib_path)
+    syms = declared_symbols()
+    assert {"plo_index_create", "plo_ctx_create", "plo_liftover_batch", "plo_liftover_batch_dev", "plo_selftest"} <= set(syms)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in the header but not exported"
+
+
+def test_version_string(lib_path):
+    L = api.load_library(lib_path)
+    assert b"gfx950" in L.plo_version()
+
+
+def test_ctypes_struct_layout_matches_header():
+    # sizes implied by the header on LP64
+    assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8
+    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8
+    assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8
+    assert C.sizeof(abi.PloIndexDesc) == 8 + 2 * 8 + 8 + 8 * 8 + 8 + 3 * 8 + 8
+
+
+def test_fails_loudly_without_gpu(lib_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cs = api.CaseSet()
+    cs.add_liftover(1000, np.array([(100 << 4) | 0], dtype=np.uint32), 10, np.array([(10 << 4) | 0], dtype=np.uint32))
+    with pytest.raises(api.PortelloError) as ei:
+        cs.run(abi.STAGE_LIFTOVER)
+    assert ei.value.status == abi.PLO_ERR_NO_DEVICE

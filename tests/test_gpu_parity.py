@@ -1,0 +1,151 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the reference's golden vectors.
+Bit-exact bar: (status, need_flipped, mapq, chrom, pos, CIGAR ops) of every item."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from portello_amd import abi, api, synth
+from portello_amd import cigar as cg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "gpurun_out")
+
+
+def _dump(name, obj):
+    os.makedirs(DUMP, exist_ok=True)
+    with open(os.path.join(DUMP, name), "w") as fh:
+        json.dump(obj, fh, indent=1)
+
+
+def _assert_same(ref: abi.BatchResult, got: abi.BatchResult, tag: str):
+    a, b = ref.canonical(), got.canonical()
+    bad = []
+    if len(a) != len(b):
+        bad.append({"n_ref": len(a), "n_got": len(b)})
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            bad.append({"i": i, "ref": list(x[:7]) + [cg.decode(np.frombuffer(x[7], dtype=np.uint32))],
+                        "got": list(y[:7]) + [cg.decode(np.frombuffer(y[7], dtype=np.uint32))]})
+    if bad:
+        _dump(f"mismatch_{tag}.json", bad[:50])
+    assert not bad, f"{len(bad)} mismatching items (first: {bad[0]})"
+
+
+def test_wave_primitives_selftest():
+    L = api.load_library()
+    L.plo_selftest.restype = C.c_int
+    L.plo_selftest.argtypes = [C.c_int]
+    assert L.plo_selftest(0) == 0
+
+
+def test_golden_vectors_through_the_c_abi(golden):
+    from test_emu_parity import check_golden
+
+    check_golden(golden, api.hip_backend())
+
+
+def test_reference_named_entry_points(golden):
+    v = golden["liftover"][2]
+    r = api.liftover_read_alignment((v["map"]["pos"], cg.encode(v["map"]["cigar"])), v["start"], cg.encode(v["cigar"]))
+    assert r[0] == v["expect"]["pos"] and cg.decode(r[1]) == v["expect"]["cigar"]
+    v = golden["simplify"][5]
+    r = api.simplify_alignment_indels(v["pos"], cg.encode(v["cigar"]), v["ref"].encode(), v["read"].encode())
+    assert r[0] == v["expect"]["pos"] and cg.decode(r[1]) == v["expect"]["cigar"]
+    v = [x for x in golden["shift"] if x["id"] == "SH9-left"][0]
+    r = api.left_shift_indels(v["pos"], cg.encode(v["cigar"]), v["ref"].encode(), v["read"].encode())
+    assert r[0] == v["expect"]["pos"] and cg.decode(r[1]) == v["expect"]["cigar"]
+    assert api.liftover_read_alignment((0, cg.encode("")), 10, cg.encode("10M")) is None
+
+
+def test_index_block_maps_match_oracle_builder(oracle):
+    w = synth.generate(synth.config("tiny", seed=201))
+    ixd = w.index_data()
+    ix = api.Index(ixd)
+    for g in range(ixd.n_segments):
+        c = ixd.seg_cigar[ixd.seg_cigar_off[g]: ixd.seg_cigar_off[g + 1]]
+        keys, vals = oracle.map_build(int(ixd.seg_pos[g]), c, False)
+        k2, v2 = ix.segment_map(g)
+        assert list(keys.astype(np.int64)) == list(k2) and list(vals) == list(v2)
+    ix.close()
+
+
+@pytest.mark.parametrize("stages", [abi.STAGES_ALL, abi.STAGES_ALL & ~abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LIFTOVER,
+                                    abi.STAGE_LSHIFT, abi.STAGE_SIMPLIFY])
+def test_synthetic_tiny_stage_subsets(oracle, stages):
+    w = synth.generate(synth.config("tiny", n_reads=300, split_read_frac=0.2, seed=202))
+    ix, b = w.index_data(), w.batch_data()
+    got = api.hip_backend()(ix, b, stages)
+    _assert_same(oracle.liftover_batch(ix, b, stages, 1), got, f"tiny_{stages}")
+
+
+def test_synthetic_plumbing_config(oracle):
+    """BASELINE configs[0]: 1 k reads x 10 kb, one contig -> one chromosome"""
+    w = synth.generate(synth.config("plumbing"))
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    got = eng.liftover_batch(b)
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "plumbing")
+    t = eng.timing()
+    assert t.n_items == got.n_items and t.n_in_ops == len(b.cigar)
+    # run it twice on the same context: buffers are reused, results identical
+    _assert_same(got, eng.liftover_batch(b), "plumbing_rerun")
+    eng.close()
+    eng_ix.close()
+
+
+def test_synthetic_indel_dense_large_item_kernel(oracle):
+    cfg = synth.config("tiny", n_reads=200, seed=203, read_len_mean=6000, read_len_sd=1500,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    got = eng.liftover_batch(b)
+    assert eng.timing().n_big_items > 0
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "indel_dense")
+    eng.close()
+    eng_ix.close()
+
+
+def test_empty_and_ragged_inputs(oracle):
+    w = synth.generate(synth.config("tiny", n_reads=50, seed=204))
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    # empty batch
+    empty = abi.BatchData(read_is_reverse=[], read_seq_len=[], read_seq_off=[], seq=[], seq_fmt=abi.SEQ_BAM4, seg_read=[],
+                          seg_contig=[], seg_pos=[], seg_is_fwd_strand=[], seg_cigar_off=[0], cigar=[])
+    assert eng.liftover_batch(empty).n_items == 0
+    # ragged: a read with an empty CIGAR, a read on the contig without any segment, a one-op CIGAR
+    orphan = len(ix.contig_len) - 1
+    rag = abi.BatchData(
+        read_is_reverse=[0, 1, 0], read_seq_len=[0, 100, 50], read_seq_off=[0, 0, 50], seq=np.full(100, 0x11, np.uint8),
+        seq_fmt=abi.SEQ_BAM4, seg_read=[0, 1, 2], seg_contig=[0, orphan, 0], seg_pos=[int(ix.seg_seq_order_start[0]) + 5, 10,
+                                                                                     int(ix.seg_seq_order_start[0]) + 7],
+        seg_is_fwd_strand=[1, 0, 1], seg_cigar_off=[0, 0, 1, 2], cigar=cg.encode("100M50M"))
+    _assert_same(oracle.liftover_batch(ix, rag, abi.STAGES_ALL, 1), eng.liftover_batch(rag), "ragged")
+    eng.close()
+    eng_ix.close()
+
+
+def test_device_resident_api_matches_host_api(oracle):
+    import torch
+
+    w = synth.generate(synth.config("tiny", n_reads=400, seed=205, split_read_frac=0.1), device="cuda")
+    ix_host, b_host = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ix_host, b_host, abi.STAGES_ALL, 4)
+    from portello_amd import devbatch
+
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    res = devbatch.run_and_download(eng, db)
+    _assert_same(ref, res, "device_api")
+    eng.close()
+    eng_ix.close()
