@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- lifted HiFi reads/sec of the MI355X liftover engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload wgs30x|chr20|stress|plumbing] [--reads R]
+
+One *step* = one pass of the hot path (plo_liftover_batch_dev: item enumeration, strand preparation, left-shift,
+liftover, length check, simplify) over one batch of synthetic reads that is already resident in HBM when the timed
+region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank lifts its own shard of
+the same size (weak scaling, reads shard with no data-path collective) and the compact result records are then
+gathered to rank 0 over RCCL (peer -> root send/recv, the path's only exchange step).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from portello_amd import abi, api, devbatch, synth  # noqa: E402
+from portello_amd import gather as plo_gather  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(w, eng, db, got_out, budget_s: float = 12.0):
+    """Times the oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload and
+    checks the GPU result of those reads against it.  Rank 0, N = 1 only."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    cores = os.cpu_count() or 1
+    ixd = w.index_data()  # host copy of the index
+    n_reads = w.n_reads
+    # calibrate on a small slice, then size the sample for ~budget_s of wall time on all cores
+    probe = min(n_reads, 2000)
+    b = w.batch_data(0, probe)
+    t0 = time.perf_counter()
+    pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
+    t_probe = max(1e-4, time.perf_counter() - t0)
+    rate = probe / t_probe
+    sample = int(min(n_reads, max(probe, rate * budget_s)))
+    b = w.batch_data(0, sample)
+    t0 = time.perf_counter()
+    ref = pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pyoracle.liftover_batch(ixd, w.batch_data(0, probe), abi.STAGES_ALL, 1)
+    rate1 = probe / max(1e-4, time.perf_counter() - t0)
+    # parity of the sampled reads: GPU items of reads [0, sample) vs oracle (item order is (segment, contig segment))
+    got = devbatch.download(eng, got_out)
+    n_seg_sample = b.n_segs
+    keep = got.item_seg < n_seg_sample
+    sub = abi.BatchResult(*(getattr(got, f)[keep] if f != "cigar" else got.cigar for f in
+                            ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq", "item_chrom_index",
+                             "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")))
+    ok = sub.canonical() == ref.canonical()
+    return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} reads of the workload, oracle/liboracle.so (C restatement of the reference algorithm, "
+                      f"not the reference binary), {cores} threads; 1 thread: {rate1:.0f} reads/s",
+            "single_thread_value": rate1, "seconds": dt}, ok, int(keep.sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("PLO_BENCH_WORKLOAD", "wgs30x"))
+    ap.add_argument("--reads", type=int, default=0, help="override the workload's read count")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    over = {"seed": synth.config(args.workload).seed + 1000 * rank}
+    if args.reads:
+        over["n_reads"] = args.reads
+    cfg = synth.config(args.workload, **over)
+    t0 = time.perf_counter()
+    w = synth.generate(cfg, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    if rank == 0:
+        log(f"[bench] workload {cfg.name}: {w.n_reads} reads, {w.seg_read.numel()} read segments, {int(w.cigar.numel())} input ops, "
+            f"{len(w.contig_len)} contigs / {len(w.seg_pos)} contig segments, generated on GPU in {t_gen:.1f}s")
+
+    index = api.Index(w.index_data_device(), device=local_rank)
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    desc = db.desc()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        out = eng.liftover_batch_dev(desc)
+        if dist is not None:
+            plo_gather.gather_results(out, dev, dist, rank, world)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    lift_ms, enum_ms, big_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        tm = eng.timing()  # HIP events on the engine's stream (waits for the step)
+        lift_ms.append(tm.lift_ms)
+        enum_ms.append(tm.enumerate_ms)
+        big_ms.append(tm.big_ms)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        nr = torch.tensor([w.n_reads], dtype=torch.float64, device=dev)
+        dist.all_reduce(nr, op=dist.ReduceOp.SUM)
+        total_reads = float(nr.item())
+    else:
+        total_reads = float(w.n_reads)
+
+    tm = eng.timing()
+    dominant = "k_lift_tiles" if sum(lift_ms) >= sum(big_ms) else "k_lift_big"
+    dom_ms = float(np.mean(lift_ms if dominant == "k_lift_tiles" else big_ms))
+    # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over both lift kernels;
+    # attribute them to the dominant kernel in proportion to its share of the lift time
+    share = dom_ms / max(1e-9, float(np.mean(lift_ms)) + float(np.mean(big_ms)))
+    achieved = (tm.algo_bytes * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            tr = json.load(open(prof))
+            traffic = tr.get(cfg.name, {}).get(dominant)
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "lifted HiFi reads/sec (whole node)",
+        "value": total_reads * args.steps / dt,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
+                   "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
+                   "large_items_per_gpu": int(tm.n_big_items), "seq_fmt": "bam4", "parallelism": f"shard{world}",
+                   "gather": "rccl send/recv to rank 0" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
+                     "enumerate_ms": float(np.mean(enum_ms)), "lift_tiles_ms": float(np.mean(lift_ms)),
+                     "lift_big_ms": float(np.mean(big_ms))},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cb, ok, n_checked = cpu_baseline(w, eng, db, out)
+            result["cpu_baseline"] = cb
+            result["parity_sample_items"] = n_checked
+            result["parity_sample_ok"] = bool(ok)
+            if not ok:
+                log("[bench] PARITY FAILURE on the sampled reads")
+        except Exception as e:  # the baseline must never hide the measurement
+            log(f"[bench] cpu_baseline failed: {e!r}")
+            result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    eng.close()
+    index.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
