@@ -51,7 +51,7 @@ def cpu_baseline(w, eng, db, got_out, budget_s: float = 12.0):
     pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
     t_probe = max(1e-4, time.perf_counter() - t0)
     rate = probe / t_probe
-    sample = int(min(n_reads, max(probe, rate * budget_s)))
+    sample = int(min(n_reads, 300_000, max(probe, rate * budget_s)))
     b = w.batch_data(0, sample)
     t0 = time.perf_counter()
     ref = pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)

@@ -518,8 +518,9 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
     clen = np.array(contig_len, dtype=np.int64)
     weights = clen / clen.sum()
     reads_per_contig = rng.multinomial(cfg.n_reads, weights)
-    parts = dict(is_rev=[], seq=[], seq_len=[], seg_read=[], seg_contig=[], seg_pos=[], seg_fwd=[], seg_nops=[], ops=[])
+    parts = dict(is_rev=[], seq=[], seq_off=[], seq_len=[], seg_read=[], seg_contig=[], seg_pos=[], seg_fwd=[], seg_nops=[], ops=[])
     read_base = 0
+    seq_byte_base = 0
     i64 = dict(dtype=torch.long, device=device)
     for c in range(n_contigs):
         R = int(reads_per_contig[c])
@@ -624,7 +625,17 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
             prim_fwd = (~is_rev)[sidx]
             seg_fwd_c[seg_off[sidx] + 1] = torch.where(b_opp, ~prim_fwd, prim_fwd).to(torch.uint8)
         parts["is_rev"].append(is_rev.to(torch.uint8))
-        parts["seq"].append(bases)
+        # pack per contig so that the full-size workloads never hold all bases as ASCII + int64 indices at once
+        so_c = torch.zeros(R + 1, **i64)
+        so_c[1:] = torch.cumsum(total_len, 0)
+        if cfg.seq_fmt == abi.SEQ_BAM4:
+            packed, boff = _pack_bam4(bases, so_c)
+        else:
+            packed, boff = bases, so_c
+        parts["seq"].append(packed)
+        parts["seq_off"].append(boff[:-1] + seq_byte_base)
+        seq_byte_base += int(packed.numel())
+        del bases, run_id, boff, rr, kind
         parts["seq_len"].append(total_len)
         parts["seg_read"].append(seg_read_c)
         parts["seg_contig"].append(torch.full((n_seg_c,), c, **i64))
@@ -640,14 +651,8 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
         return torch.cat(parts[key]).to(dtype)
 
     seq_len = cat("seq_len", torch.long)
-    seq_ascii = cat("seq", torch.uint8)
-    seq_off = torch.zeros(seq_len.numel() + 1, **i64)
-    seq_off[1:] = torch.cumsum(seq_len, 0)
-    if cfg.seq_fmt == abi.SEQ_BAM4:
-        seq, byte_off = _pack_bam4(seq_ascii, seq_off)
-        read_seq_off = byte_off[:-1]
-    else:
-        seq, read_seq_off = seq_ascii, seq_off[:-1]
+    seq = cat("seq", torch.uint8)
+    read_seq_off = cat("seq_off", torch.long)
     seg_nops = cat("seg_nops", torch.long)
     seg_cigar_off_r = torch.zeros(seg_nops.numel() + 1, **i64)
     seg_cigar_off_r[1:] = torch.cumsum(seg_nops, 0)
