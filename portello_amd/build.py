@@ -19,6 +19,15 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def build_timing() -> str:
+    """instrumented variant (per-phase s_memtime accumulation) used by tools/tune.py only"""
+    out = os.path.join(HERE, "libportello_liftover_timing.so")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPLO_PHASE_TIMING", "-I" + CSRC, "-o", out,
+           os.path.join(CSRC, "engine.hip")]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "portello_liftover.h")]
     stale = (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)

@@ -31,22 +31,30 @@ using namespace plo;
 __global__ void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
-    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, nullptr, nullptr, 0);
+    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0);
 }
 
-__global__ void k_item_emit(DevIndex ix, DevBatch bt, const uint32_t *seg_off, uint32_t *item_seg, uint32_t *item_cseg,
-                            uint32_t *item_nin) {
+// thread per read segment: resolve the descriptors of its items (build_item_desc) at their scanned offsets
+__global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
     if (seg_off[s + 1] == seg_off[s]) return;
-    enumerate_segment(ix, bt, s, item_seg, item_cseg, item_nin, seg_off[s]);
+    enumerate_segment(ix, bt, s, &wk, stages, seg_off[s]);
 }
 
-__global__ void k_item_nin(DevBatch bt, const uint32_t *item_seg, uint32_t n_items, uint32_t *item_nin) {
+// explicit item list: thread per item
+__global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *in_seg, const uint32_t *in_cseg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    uint32_t s = item_seg[i];
-    item_nin[i] = bt.seg_cigar_off[s + 1] - bt.seg_cigar_off[s];
+    if (i >= wk.n_items) return;
+    uint32_t seg = in_seg[i];
+    build_item_desc(ix, bt, wk, stages, i, seg, in_cseg[i], segment_ref_len(bt, seg));
+}
+
+// thread per tile: first item whose exclusive op prefix reaches the tile's window (tile_lo[n_tiles] = n_items)
+__global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t *tile_lo) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    tile_lo[t] = prefix_lower_bound(op_prefix, n_items, (unsigned long long)t * (unsigned)window);
 }
 
 // ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
@@ -113,30 +121,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in,
 // ---- the dominant kernel: one wave per tile ---------------------------------------------------------------------
 constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its own tile with its own LDS slice
 
+// Persistent: the grid is sized to the resident capacity of the chip and every wave strides over the tiles, keeping its
+// output slab and statistics in registers (WaveCtx).
 __global__ __launch_bounds__(TILE_WAVES * 64) void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
                                                                uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                uint32_t lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
-    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD a contiguous
-    // range of tiles so that neighbouring reads (same contig region -> same block-map / reference lines) share an L2.
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order); consecutive wave ids -- hence
+    // neighbouring tiles, i.e. reads of the same contig region with the same block-map / reference lines -- share an L2.
     uint32_t nb = gridDim.x;
     uint32_t per = nb >> 3;
     uint32_t b = blockIdx.x;
     uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
-    uint32_t tile = tb * TILE_WAVES + (uint32_t)w;
-    if (tile >= n_tiles) return;
+    const uint32_t tw = blockDim.x >> 6;
+    const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
     TileMem m = carve_tile_mem(smem + (size_t)w * lds_per_wave, cap);
-    lift_window(ix, bt, wk, stages, tile, window, big_thresh, m);
+    WaveCtx ctx;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) lift_window(ix, bt, wk, stages, tile, window, big_thresh, m, ctx);
+    wave_ctx_flush(wk, ctx);
 }
 
 __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
                                                  unsigned char *scratch, int big_cap, unsigned long long bytes_per_wave) {
     TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
+    WaveCtx ctx;
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0);
+        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0, ctx);
         wv::sync();
     }
+    wave_ctx_flush(wk, ctx);
 }
 
 // ---- self-test of the wave primitives (plo_selftest) -------------------------------------------------------------------
@@ -242,7 +256,9 @@ struct plo_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
-    DevBuf seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch;
+    DevBuf seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
+    DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
+        d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
     DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar;
     // host staging for plo_liftover_batch
@@ -252,8 +268,11 @@ struct plo_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_big = false;
     plo_timing timing{};
+    unsigned long long phase_cycles[12] = {0};
     // tuning
     int window = 160, big_thresh = 176, cap = 512;
+    int n_cus = 256;
+    int tile_waves = TILE_WAVES;
 };
 
 #define HIP_TRY(ctx, call)                                                                      \
@@ -401,7 +420,20 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
             delete c;
             return PLO_ERR_HIP;
         }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    }
     (void)hipFuncSetAttribute((const void *)k_lift_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (getenv("PLO_DEBUG")) {
+        for (int cap : {384, 512, 768, 960}) {
+            int nb = -1;
+            size_t lds = ((tile_mem_bytes(cap) + 15) & ~(size_t)15) * TILE_WAVES;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_lift_tiles, TILE_WAVES * 64, lds);
+            fprintf(stderr, "[plo] cap %d: dynamic LDS %zu B/block -> %d blocks/CU (%s)\n", cap, lds, nb, hipGetErrorString(e));
+        }
+    }
+    if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e));
     if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e));
     if (const char *e = getenv("PLO_CAP")) c->cap = std::max(64, atoi(e));
@@ -414,7 +446,9 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipSetDevice(c->ix->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
-                      &c->counters, &c->big_list, &c->scratch, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
+                      &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
+                      &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
+                      &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
                       &c->i_item_seg, &c->i_item_cseg};
@@ -434,6 +468,11 @@ plo_status plo_ctx_sync(plo_ctx *c) {
     if (!c) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PLO_OK;
+}
+
+// debugging aid (timing builds, -DPLO_PHASE_TIMING): shader cycles spent per pipeline phase, summed over waves
+void plo_ctx_phase_cycles(plo_ctx *c, unsigned long long *out12) {
+    for (int k = 0; k < 12; ++k) out12[k] = c ? c->phase_cycles[k] : 0;
 }
 
 plo_status plo_ctx_download(plo_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
@@ -489,20 +528,13 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->ev_big = false;
 
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    // ---- items ----
+    // ---- items: count -> scan -> resolve descriptors -> scan op counts -> tile bounds ----
     uint32_t n_items = 0;
-    const uint32_t *item_seg = nullptr, *item_cseg = nullptr;
-    HIP_TRY(c, c->h_counters.ensure(64 * 8));
+    HIP_TRY(c, c->h_counters.ensure(64 * 8 + CNT_N * 8));
+    uint32_t ns = in->n_segs;
     if (in->item_seg) {
         n_items = in->n_items;
-        item_seg = in->item_seg;
-        item_cseg = in->item_cseg;
-        HIP_TRY(c, c->item_nin.ensure((size_t)std::max(1u, n_items) * 4));
-        if (n_items)
-            hipLaunchKernelGGL(k_item_nin, dim3((n_items + 255) / 256), dim3(256), 0, st, bt, item_seg, n_items,
-                               c->item_nin.as<uint32_t>());
     } else {
-        uint32_t ns = in->n_segs;
         HIP_TRY(c, c->seg_cnt.ensure((size_t)std::max(1u, ns) * 4));
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         if (ns) hipLaunchKernelGGL(k_seg_count, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>());
@@ -512,17 +544,76 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipMemcpyAsync(h, c->seg_off.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         n_items = h[0];
-        HIP_TRY(c, c->item_seg.ensure((size_t)std::max(1u, n_items) * 4));
-        HIP_TRY(c, c->item_cseg.ensure((size_t)std::max(1u, n_items) * 4));
-        HIP_TRY(c, c->item_nin.ensure((size_t)std::max(1u, n_items) * 4));
-        if (ns && n_items)
-            hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt,
-                               (const uint32_t *)c->seg_off.as<uint32_t>(), c->item_seg.as<uint32_t>(),
-                               c->item_cseg.as<uint32_t>(), c->item_nin.as<uint32_t>());
-        item_seg = c->item_seg.as<uint32_t>();
-        item_cseg = c->item_cseg.as<uint32_t>();
     }
+    size_t ni = std::max(1u, n_items);
+    HIP_TRY(c, c->item_seg.ensure(ni * 4));
+    HIP_TRY(c, c->item_cseg.ensure(ni * 4));
+    HIP_TRY(c, c->item_nin.ensure(ni * 4));
     HIP_TRY(c, c->op_prefix.ensure((size_t)(n_items + 1) * 4));
+    HIP_TRY(c, c->d_in_off.ensure(ni * 4));
+    HIP_TRY(c, c->d_n_in.ensure(ni * 4));
+    HIP_TRY(c, c->d_pos1.ensure(ni * 4));
+    HIP_TRY(c, c->d_w0.ensure(ni * 4));
+    HIP_TRY(c, c->d_w1.ensure(ni * 4));
+    HIP_TRY(c, c->d_kv0.ensure(ni * 4));
+    HIP_TRY(c, c->d_kv1.ensure(ni * 4));
+    HIP_TRY(c, c->d_flags.ensure(ni * 4));
+    HIP_TRY(c, c->d_contig.ensure(ni * 4));
+    HIP_TRY(c, c->d_seq_len.ensure(ni * 4));
+    HIP_TRY(c, c->d_seq_off.ensure(ni * 8));
+    HIP_TRY(c, c->d_shift_ref.ensure(ni * 8));
+    HIP_TRY(c, c->d_shift_ref_len.ensure(ni * 4));
+    HIP_TRY(c, c->d_chrom_ref.ensure(ni * 8));
+    HIP_TRY(c, c->d_chrom_ref_len.ensure(ni * 4));
+    HIP_TRY(c, c->o_status.ensure(ni));
+    HIP_TRY(c, c->o_flip.ensure(ni));
+    HIP_TRY(c, c->o_mapq.ensure(ni));
+    HIP_TRY(c, c->o_chrom.ensure(ni * 4));
+    HIP_TRY(c, c->o_pos.ensure(ni * 8));
+    HIP_TRY(c, c->o_coff.ensure(ni * 8));
+    HIP_TRY(c, c->o_clen.ensure(ni * 4));
+    HIP_TRY(c, c->big_list.ensure(ni * 4));
+    HIP_TRY(c, c->counters.ensure(CNT_N * 8));
+    DevWork wk;
+    memset(&wk, 0, sizeof(wk));
+    wk.n_items = n_items;
+    wk.item_seg = c->item_seg.as<uint32_t>();
+    wk.item_cseg = c->item_cseg.as<uint32_t>();
+    wk.item_nin = c->item_nin.as<uint32_t>();
+    wk.item_op_prefix = c->op_prefix.as<uint32_t>();
+    wk.d.in_off = c->d_in_off.as<uint32_t>();
+    wk.d.n_in = c->d_n_in.as<uint32_t>();
+    wk.d.pos1 = c->d_pos1.as<int>();
+    wk.d.w0 = c->d_w0.as<uint32_t>();
+    wk.d.w1 = c->d_w1.as<uint32_t>();
+    wk.d.kv0 = c->d_kv0.as<uint32_t>();
+    wk.d.kv1 = c->d_kv1.as<uint32_t>();
+    wk.d.flags = c->d_flags.as<uint32_t>();
+    wk.d.contig = c->d_contig.as<uint32_t>();
+    wk.d.seq_len = c->d_seq_len.as<uint32_t>();
+    wk.d.seq_off = c->d_seq_off.as<uint64_t>();
+    wk.d.shift_ref = c->d_shift_ref.as<uint64_t>();
+    wk.d.shift_ref_len = c->d_shift_ref_len.as<int>();
+    wk.d.chrom_ref = c->d_chrom_ref.as<uint64_t>();
+    wk.d.chrom_ref_len = c->d_chrom_ref_len.as<int>();
+    wk.status = c->o_status.as<uint8_t>();
+    wk.flip = c->o_flip.as<uint8_t>();
+    wk.mapq = c->o_mapq.as<uint8_t>();
+    wk.chrom = c->o_chrom.as<uint32_t>();
+    wk.pos = c->o_pos.as<int64_t>();
+    wk.cig_off = c->o_coff.as<uint64_t>();
+    wk.cig_len = c->o_clen.as<uint32_t>();
+    wk.counters = c->counters.as<unsigned long long>();
+    wk.big_list = c->big_list.as<uint32_t>();
+    if (n_items) {
+        if (in->item_seg)
+            hipLaunchKernelGGL(k_item_desc, dim3((n_items + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages, in->item_seg,
+                               in->item_cseg);
+        else
+            hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages,
+                               (const uint32_t *)c->seg_off.as<uint32_t>());
+        HIP_TRY(c, hipGetLastError());
+    }
     {
         plo_status s = scan_u32(c, c->item_nin.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
@@ -534,49 +625,35 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipStreamSynchronize(st));
         total_ops = h[0];
     }
+    const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
+    HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
+    hipLaunchKernelGGL(k_tile_bounds, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->op_prefix.as<uint32_t>(),
+                       n_items, n_tiles, c->window, c->tile_lo.as<uint32_t>());
+    wk.tile_lo = c->tile_lo.as<uint32_t>();
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
-    // ---- outputs ----
-    size_t ni = std::max(1u, n_items);
-    HIP_TRY(c, c->o_status.ensure(ni));
-    HIP_TRY(c, c->o_flip.ensure(ni));
-    HIP_TRY(c, c->o_mapq.ensure(ni));
-    HIP_TRY(c, c->o_chrom.ensure(ni * 4));
-    HIP_TRY(c, c->o_pos.ensure(ni * 8));
-    HIP_TRY(c, c->o_coff.ensure(ni * 8));
-    HIP_TRY(c, c->o_clen.ensure(ni * 4));
-    HIP_TRY(c, c->big_list.ensure(ni * 4));
-    HIP_TRY(c, c->counters.ensure(CNT_N * 8));
-    size_t want_cigar = (size_t)total_ops * 2 + (size_t)n_items * 8 + 4096;
+    size_t want_cigar = (size_t)total_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS;
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
     uint32_t n_big = 0;
     for (int attempt = 0;; ++attempt) {
-        DevWork wk;
-        wk.n_items = n_items;
-        wk.item_seg = item_seg;
-        wk.item_cseg = item_cseg;
-        wk.item_op_prefix = c->op_prefix.as<uint32_t>();
-        wk.status = c->o_status.as<uint8_t>();
-        wk.flip = c->o_flip.as<uint8_t>();
-        wk.mapq = c->o_mapq.as<uint8_t>();
-        wk.chrom = c->o_chrom.as<uint32_t>();
-        wk.pos = c->o_pos.as<int64_t>();
-        wk.cig_off = c->o_coff.as<uint64_t>();
-        wk.cig_len = c->o_clen.as<uint32_t>();
         wk.out_cigar = c->o_cigar.as<uint32_t>();
         wk.out_cap = c->o_cigar.cap / 4;
-        wk.counters = c->counters.as<unsigned long long>();
-        wk.big_list = c->big_list.as<uint32_t>();
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
         if (attempt == 0) HIP_TRY(c, hipEventRecord(c->ev[1], st));
         if (n_items) {
-            uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
-            uint32_t nblk = (n_tiles + TILE_WAVES - 1) / TILE_WAVES;
-            nblk = (nblk + 7u) & ~7u;
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
-            hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(TILE_WAVES * 64), lds_per_wave * TILE_WAVES, st, ix, bt, wk, stages,
+            const uint32_t tw = (uint32_t)c->tile_waves;
+            uint32_t nblk = (n_tiles + tw - 1) / tw;
+            // persistent grid: what the chip keeps resident (CUs x blocks per CU), a multiple of 8 for the XCD mapping
+            int occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_tiles, (int)tw * 64,
+                                                             (size_t)lds_per_wave * tw) != hipSuccess || occ < 1)
+                occ = 1;
+            nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
+            nblk = (nblk + 7u) & ~7u;
+            hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages,
                                n_tiles, c->window, c->big_thresh, c->cap, lds_per_wave);
             HIP_TRY(c, hipGetLastError());
         }
@@ -604,7 +681,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             c->err = "output CIGAR buffer kept overflowing";
             return PLO_ERR_INTERNAL;
         }
-        HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + 4096) * 4));
+        HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS) * 4));
     }
     if (hc[CNT_ERROR]) {
         c->err = "an item exceeded the large-item scratch capacity (raise PLO_BIG_CAP)";
@@ -615,10 +692,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_in_ops = hc[CNT_IN_OPS];
     c->timing.n_out_ops = hc[CNT_CIGAR];
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
+    for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
 
     out->n_items = n_items;
-    out->item_seg = item_seg;
-    out->item_cseg = item_cseg;
+    out->item_seg = c->item_seg.as<uint32_t>();
+    out->item_cseg = c->item_cseg.as<uint32_t>();
     out->item_status = c->o_status.as<uint8_t>();
     out->item_need_flipped = c->o_flip.as<uint8_t>();
     out->item_mapq = c->o_mapq.as<uint8_t>();

@@ -19,28 +19,111 @@ PLO_DEV long long segment_ref_len(const DevBatch &bt, uint32_t seg) {
     return r;
 }
 
-// Counts (and, when item_seg != nullptr, writes at out_off) the items of one read segment, in contig-segment order.
-PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint32_t seg, uint32_t *item_seg,
-                                   uint32_t *item_cseg, uint32_t *item_nin, uint32_t out_off) {
+// block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
+PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (kv[mid].key <= x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key >= x, else hi
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (kv[mid].key < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// Resolves everything the tile kernel needs to know about item i = (read segment seg, contig segment cseg):
+// the caller glue of get_liftover_alignment_for_read_and_contig_segment (src/read_alignment_scanner.rs:146-176) --
+// need_flipped (:153-157), rev_pos (:164-166) -- plus the window of the block map the item can touch.
+PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t i, uint32_t seg,
+                             uint32_t cseg, long long ref_len) {
+    uint32_t contig = bt.seg_contig[seg];
+    uint32_t gseg = ix.contig_seg_off[contig] + cseg;
+    uint32_t read = bt.seg_read[seg];
+    uint32_t in_off = bt.seg_cigar_off[seg];
+    uint32_t n_in = bt.seg_cigar_off[seg + 1] - in_off;
+    bool contig_fwd = ix.cs_is_fwd[gseg] != 0;
+    bool flip = false, rev = false;
+    if (stages & PLO_STAGE_STRAND) {
+        bool changes = (bt.read_is_reverse[read] != 0) == (bt.seg_is_fwd[seg] != 0);
+        flip = (!contig_fwd) != changes;
+        rev = !contig_fwd;
+    }
+    long long pos = (long long)bt.seg_pos[seg];
+    long long pos1 = rev ? (long long)ix.contig_len[contig] - (pos + ref_len) : pos;
+    int kv0 = (int)ix.cs_kv_off[gseg], kv1 = (int)ix.cs_kv_off[gseg + 1];
+    // every contig position the item can touch lies in [pos1, pos1 + ref_len]
+    long long lo = pos1 < -0x7fffffffLL ? -0x7fffffffLL : pos1;
+    long long hi = pos1 + ref_len > 0x7fffffffLL ? 0x7fffffffLL : pos1 + ref_len;
+    int ub = kv_upper_bound(ix.kv, kv0, kv1, (int)lo);
+    int w0 = ub - 1 > kv0 ? ub - 1 : kv0;
+    int w1 = kv_lower_bound(ix.kv, w0, kv1, (int)hi);
+    wk.item_seg[i] = seg;
+    wk.item_cseg[i] = cseg;
+    wk.item_nin[i] = n_in;
+    wk.d.in_off[i] = in_off;
+    wk.d.n_in[i] = n_in;
+    wk.d.pos1[i] = (int)pos1;
+    wk.d.w0[i] = (uint32_t)w0;
+    wk.d.w1[i] = (uint32_t)w1;
+    wk.d.kv0[i] = (uint32_t)kv0;
+    wk.d.kv1[i] = (uint32_t)kv1;
+    wk.d.flags[i] = (rev ? (uint32_t)ITF_REV : 0u) | (flip ? (uint32_t)ITF_FLIP : 0u) | (contig_fwd ? (uint32_t)ITF_CONTIG_FWD : 0u);
+    wk.d.contig[i] = contig;
+    wk.d.seq_len[i] = bt.read_seq_len[read];
+    wk.d.seq_off[i] = bt.read_seq_off[read];
+    wk.d.shift_ref[i] = (uint64_t)(uintptr_t)(ix.contig_revseq ? ix.contig_revseq[contig] : nullptr);
+    wk.d.shift_ref_len[i] = ix.contig_len[contig];
+    uint32_t chrom = ix.cs_chrom[gseg];
+    wk.d.chrom_ref[i] = (uint64_t)(uintptr_t)ix.chrom_seq[chrom];
+    wk.d.chrom_ref_len[i] = ix.chrom_len[chrom];
+    // outputs that do not depend on the CIGAR pipeline
+    wk.flip[i] = (uint8_t)flip;
+    wk.mapq[i] = ix.cs_mapq[gseg];
+    wk.chrom[i] = ix.cs_chrom[gseg];
+}
+
+// Counts (and, when wk != nullptr, resolves at out_off) the items of one read segment, in contig-segment order.
+PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint32_t seg, const DevWork *wk, uint32_t stages,
+                                   uint32_t out_off) {
     uint32_t contig = bt.seg_contig[seg];
     if (contig >= ix.n_contigs) return 0;
     uint32_t g0 = ix.contig_seg_off[contig], g1 = ix.contig_seg_off[contig + 1];
     if (g0 == g1) return 0;  // contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
+    long long ref_len = segment_ref_len(bt, seg);
     long long r_start = (long long)bt.seg_pos[seg];
-    long long r_end = r_start + segment_ref_len(bt, seg);
+    long long r_end = r_start + ref_len;
     uint32_t n = 0;
     for (uint32_t g = g0; g < g1; ++g) {
         // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end
         if (r_end >= (long long)ix.cs_start[g] && r_start < (long long)ix.cs_end[g]) {
-            if (item_seg) {
-                item_seg[out_off + n] = seg;
-                item_cseg[out_off + n] = g - g0;
-                item_nin[out_off + n] = bt.seg_cigar_off[seg + 1] - bt.seg_cigar_off[seg];
-            }
+            if (wk) build_item_desc(ix, bt, *wk, stages, out_off + n, seg, g - g0, ref_len);
             ++n;
         }
     }
     return n;
+}
+
+// first i in [0,n) with a[i] >= x
+PLO_DEV uint32_t prefix_lower_bound(const uint32_t *a, uint32_t n, unsigned long long x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((unsigned long long)a[mid] < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
 }
 
 }  // namespace plo

@@ -18,6 +18,7 @@
 #include <plo_wave.hpp>
 #include <stdint.h>
 
+#include "enumerate.hpp"
 #include "lift_types.hpp"
 
 namespace plo {
@@ -32,9 +33,14 @@ struct TileMem {
     int *itl;  // [64] last match index   (clean-up)
     int *its;  // [64] leading-deletion shift (clean-up) / ref2_start (liftover)
     int *itp;  // [64] panic flags
+    int *K, *V;  // [capk] block-map entries (key, val) of the tile's items, staged once per tile
     int cap;
+    int capk;
 };
-constexpr size_t tile_mem_bytes(int cap) { return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4; }
+constexpr int tile_capk(int cap) { return cap / 2; }
+constexpr size_t tile_mem_bytes(int cap) {
+    return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4 + (size_t)tile_capk(cap) * 8;
+}
 
 PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap) {
     TileMem m;
@@ -50,7 +56,10 @@ PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap) {
     m.itl = m.itf + 64;
     m.its = m.itl + 64;
     m.itp = m.its + 64;
-    m.idA = (uint8_t *)(m.itp + 64);
+    m.capk = tile_capk(cap);
+    m.K = m.itp + 64;
+    m.V = m.K + m.capk;
+    m.idA = (uint8_t *)(m.V + m.capk);
     m.idB = m.idA + cap;
     m.cap = cap;
     return m;
@@ -106,36 +115,13 @@ PLO_DEV int read_base(const ReadSeq &r, int i) {
     return r.flip ? comp_base(c) : c;
 }
 
-PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, int seg, int flip) {
-    uint32_t read = bt.seg_read[seg];
+PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, int seq_len, int flip) {
     ReadSeq r;
-    r.p = bt.seq + bt.read_seq_off[read];
-    r.len = (int)bt.read_seq_len[read];
+    r.p = bt.seq + seq_off;
+    r.len = seq_len;
     r.fmt = bt.seq_fmt;
     r.flip = flip;
     return r;
-}
-
-// ---- block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85) ----------------------------
-PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (kv[mid].key <= x)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key >= x, else hi
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (kv[mid].key < x)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
 }
 
 // ---- chunked scans with a running carry ---------------------------------------------------------------------------
@@ -293,9 +279,11 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
 }
 
 // left homology of get_indel_breakend_homology_info (lib/rust-vc-utils/src/indel_breakend_homology.rs:32-47),
-// capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133)
+// capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133).
+// The byte probes are random accesses into HBM-resident sequences: they are issued 8 at a time (independent loads,
+// one latency per batch) instead of one dependent load per compared base.
 PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound,
-                          bool &panic) {
+                          bool &panic, int &probes) {
     int re = rs + del, qe = qs + ins;
     int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
     int maxk = wv::imin(max_left, bound);
@@ -308,47 +296,95 @@ PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, cons
         }
     }
     while (k < maxk) {
-        int a = ref[re - 1 - k];
-        int b = read_base(rd, qe - 1 - k);
-        if (a != b) break;
-        ++k;
+        int n = wv::imin(8, maxk - k);
+        int a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int jj = j < n ? j : 0;
+            a[j] = ref[re - 1 - k - jj];
+            b[j] = read_base(rd, qe - 1 - k - jj);
+        }
+        int adv = n;
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+            if (j < n && a[j] != b[j]) adv = j;
+        probes += wv::imin(adv + 1, n);
+        k += adv;
+        if (adv < n) break;
     }
     return k;
+}
+
+// State a (persistent) wave carries from tile to tile.  All fields except the per-lane statistics are wave-uniform.
+// Output CIGARs are bump-allocated in slabs: one device-scope atomic per SLAB_OPS ops instead of one per tile -- with
+// hundreds of thousands of tiles a single hot counter (~88 atomics/us per address) would otherwise bound the kernel.
+struct WaveCtx {
+    unsigned long long slab_base = 0;  // next free op of the wave's current slab
+    unsigned long long slab_left = 0;  // ops left in it
+    unsigned long long algo_bytes = 0;  // per lane
+    unsigned long long in_ops = 0;      // per lane
+};
+constexpr unsigned long long SLAB_OPS = 16384;
+
+PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx) {
+    // per-lane 64-bit sums -> one atomic per wave per counter
+    unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.algo_bytes & 0xffffffull));
+    unsigned hi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.algo_bytes >> 24));
+    unsigned nlo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.in_ops & 0xffffffull));
+    unsigned nhi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.in_ops >> 24));
+    if (wv::lane() == 0) {
+        wv::atomic_add_global(&wk.counters[CNT_ALGO_BYTES], (unsigned long long)lo + ((unsigned long long)hi << 24));
+        wv::atomic_add_global(&wk.counters[CNT_IN_OPS], (unsigned long long)nlo + ((unsigned long long)nhi << 24));
+    }
+    ctx.algo_bytes = 0;
+    ctx.in_ops = 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------------
 // The tile pipeline
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
-                       int nit, TileMem m, bool big_path, int big_thresh) {
+                       int nit, TileMem m, bool big_path, int big_thresh, WaveCtx &ctx) {
     const int lane = wv::lane();
+#ifdef PLO_PHASE_TIMING
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = wv::clock();
+#define PLO_T(k)                      \
+    {                                 \
+        long long now_ = wv::clock(); \
+        tph[k] += now_ - tlast;       \
+        tlast = now_;                 \
+    }
+#else
+#define PLO_T(k)
+#endif
     bool has = lane < nit;
     const uint32_t g = big_path ? (has ? wk.big_list[item_begin + (uint32_t)lane] : 0u) : item_begin + (uint32_t)lane;
 
-    // ---- item descriptors: lane t <-> item t  (caller glue, src/read_alignment_scanner.rs:146-176) --------------
-    int seg = 0, contig = 0, gseg = 0, n_in = 0, in_off = 0, pos = 0, kv0 = 0, kv1 = 0, chrom = 0, mapq = 0;
+    // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
+    int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;
+    int shift_ref_len = 0, chrom_ref_len = 0;
+    unsigned long long seq_off = 0, shift_ref = 0, chrom_ref = 0;
     bool rev = false, do_shift = false, flip = false;
     if (has) {
-        seg = (int)wk.item_seg[g];
-        int cseg = (int)wk.item_cseg[g];
-        contig = (int)bt.seg_contig[seg];
-        gseg = (int)ix.contig_seg_off[contig] + cseg;
-        uint32_t read = bt.seg_read[seg];
-        in_off = (int)bt.seg_cigar_off[seg];
-        n_in = (int)bt.seg_cigar_off[seg + 1] - in_off;
-        pos = (int)bt.seg_pos[seg];
-        bool contig_fwd = ix.cs_is_fwd[gseg] != 0;
-        if (stages & PLO_STAGE_STRAND) {
-            // need_flipped_read_alignment (:153-157)
-            bool changes = (bt.read_is_reverse[read] != 0) == (bt.seg_is_fwd[seg] != 0);
-            flip = (!contig_fwd) != changes;
-            rev = !contig_fwd;
-        }
+        in_off = (int)wk.d.in_off[g];
+        n_in = (int)wk.d.n_in[g];
+        pos1 = wk.d.pos1[g];
+        W0 = (int)wk.d.w0[g];
+        W1 = (int)wk.d.w1[g];
+        kv0 = (int)wk.d.kv0[g];
+        kv1 = (int)wk.d.kv1[g];
+        uint32_t fl = wk.d.flags[g];
+        seq_len = (int)wk.d.seq_len[g];
+        seq_off = wk.d.seq_off[g];
+        shift_ref = wk.d.shift_ref[g];
+        shift_ref_len = wk.d.shift_ref_len[g];
+        chrom_ref = wk.d.chrom_ref[g];
+        chrom_ref_len = wk.d.chrom_ref_len[g];
+        rev = (fl & ITF_REV) != 0;
+        flip = (fl & ITF_FLIP) != 0;
+        bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
         do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
-        kv0 = (int)ix.cs_kv_off[gseg];
-        kv1 = (int)ix.cs_kv_off[gseg + 1];
-        chrom = (int)ix.cs_chrom[gseg];
-        mapq = ix.cs_mapq[gseg];
     }
     // items too long for a shared tile go to the large-item kernel (one item per wave, global scratch)
     {
@@ -370,7 +406,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
     int status = PLO_ITEM_LIFTED;
     bool alive = has;  // still flowing through the pipeline
-    if (has && do_shift && (!ix.contig_revseq || ix.contig_revseq[contig] == nullptr)) {
+    if (has && do_shift && shift_ref == 0ull) {
         status = PLO_ITEM_PANIC;  // rev_contig_seq.unwrap() on None (:174)
         alive = false;
         do_shift = false;
@@ -378,6 +414,17 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     bool overflow = false;
     unsigned long long algo_bytes = 0;
 
+    // block-map entries of the item's window: issued now, consumed at the liftover stage (hidden behind LOAD / LSHIFT)
+    constexpr int KV_PF = 6;
+    KV kv_pre[KV_PF];
+    const int nk_all = (has && (stages & PLO_STAGE_LIFTOVER)) ? (wv::imin(W1 + 1, kv1) - W0) : 0;
+#pragma unroll
+    for (int k = 0; k < KV_PF; ++k) {
+        kv_pre[k].key = 0;
+        kv_pre[k].val = 0;
+        if (k < nk_all) kv_pre[k] = ix.kv[W0 + k];
+    }
+    PLO_T(0)
     // ---- LOAD: flattened op stream of the tile (reversed for reverse-mapped contig segments, :167) --------------
     int cA = has ? n_in : 0;
     int incA = wv::scan_add(cA);
@@ -385,7 +432,6 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     int nA = wv::bcast_last(incA);
     if (nA > m.cap) overflow = true;
     m.itp[lane] = 0;
-    int span = 0;  // reference span of the input CIGAR (get_cigar_ref_offset, :165)
     if (!overflow) {
         for (int base = 0; base < nA; base += 64) {
             int e = base + lane;
@@ -395,7 +441,6 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         if (has && cA > 0) m.T3[sA] = lane + 1;
         wv::sync();
         MaxScan owner(0);
-        AddScan refsum;
         for (int base = 0; base < nA; base += 64) {
             int e = base + lane;
             bool valid = e < nA;
@@ -403,38 +448,32 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             if (id < 0) id = 0;
             int i_off = wv::shfl(in_off, id), i_n = wv::shfl(n_in, id), i_s = wv::shfl(sA, id);
             int i_rev = wv::shfl((int)rev, id);
-            uint32_t c = 0;
             if (valid) {
                 int k = e - i_s;
-                c = bt.cigar[i_off + (i_rev ? (i_n - 1 - k) : k)];
-                m.A[e] = c;
+                m.T0[e] = i_off + (i_rev ? (i_n - 1 - k) : k);  // source op of the element
                 m.idA[e] = (uint8_t)id;
                 m.T3[e] = 0;
                 m.T4[e] = 0;
             }
-            int t = op_type(c);
-            int r = refsum.incl((valid && ref_consuming(t)) ? op_len(c) : 0);
-            if (valid) m.T0[e] = r;
         }
-        wv::sync();
-        {
-            int ns, nc;
-            finish_counts(m.T0, sA, cA, ns, nc);
-            span = nc;
+        // the gather itself carries no cross-lane dependency: all chunks' loads are in flight together
+#pragma unroll 4
+        for (int base = 0; base < nA; base += 64) {
+            int e = base + lane;
+            if (e < nA) m.A[e] = bt.cigar[m.T0[e]];
         }
         wv::sync();
     }
-    // rev_pos = contig_length - read_segment_end (:164-166)
-    int pos1 = pos;
-    if (has && rev) pos1 = ix.contig_len[contig] - (pos + span);
-    const int lo_pos = pos1, hi_pos = pos1 + span;  // superset of every contig position the item touches
 
+    PLO_T(1)
     // ---- LEFT SHIFT (left_shift_indels.rs:17-39 + cigar_indel_shifter.rs:10-165), items with do_shift ---------------
     if (!overflow && wv::ballot(has && do_shift) != 0ull) {
         // pass A: classes, heads, cluster sums, positions
+        int nH = 0;
         {
             SegSum sr, sq, sm;
             MaxScan pnz(-1), heads(-1);
+            AddScan hcount;
             for (int base = 0; base < nA; base += 64) {
                 int e = base + lane;
                 bool valid = e < nA;
@@ -461,6 +500,11 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 bool chead = isC && !prevC;
                 bool event = chead || isO;
                 int hidx = heads.incl(chead ? e : -1);
+                int hrank = hcount.excl(chead ? 1 : 0);
+                if (chead) {
+                    if (hrank < m.capk) m.K[hrank] = e;  // compact list of cluster heads
+                    else overflow = true;
+                }
                 if (valid) {
                     m.T0[e] = i_pos + R;  // indel_block_ref_start
                     m.T1[e] = Q;          // indel_block_read_start
@@ -469,13 +513,36 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
                 }
             }
+            nH = hcount.carry;
+        }
+        overflow = wv::ballot(overflow) != 0ull;
+        wv::sync();
+        // pass H: one lane per indel cluster (all clusters of the tile at once): left breakend homology.  This is
+        // the only part of the shift that touches the sequences, so the HBM round trips are paid once per tile.
+        for (int base = 0; base < nH && !overflow; base += 64) {
+            int hl = base + lane;
+            bool valid = hl < nH;
+            int e = valid ? m.K[hl] : 0;
+            int id = m.idA[e] & 63;
+            int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(shift_ref_len, id);
+            unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(shift_ref, id);
+            if (valid) {
+                bool panic = false;
+                int probes = 0;
+                ReadSeq rd = item_read_seq(bt, i_soff, i_slen, i_flip);
+                int h = left_homology((const uint8_t *)(uintptr_t)i_ref, i_rlen, m.T0[e], m.T3[e], rd, m.T1[e], m.T4[e], m.T2[e],
+                                      panic, probes);
+                algo_bytes += 2ull * (unsigned)probes;
+                if (panic) wv::atomic_or(&m.itp[id], 1);
+                m.V[hl] = h;
+            }
         }
         wv::sync();
         // pass B: homology, carried match run (min-plus scan), emission
         int nB = 0;
         {
             MaxScan ev(-1);
-            AddScan emit;
+            AddScan emit, hcount;
             wv::MinPlus carryF = {0, IMAX, 0};
             int carry_r = 0;
             for (int base = 0; base < nA; base += 64) {
@@ -499,19 +566,9 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     del = m.T3[e];
                     ins = m.T4[e];
                 }
-                // sequences are only needed by cluster heads
-                int i_seg = wv::shfl(seg, id), i_contig = wv::shfl(contig, id), i_flip = wv::shfl((int)flip, id);
+                int hrank = hcount.excl((on && chead) ? 1 : 0);
                 if (on && chead) {
-                    bool panic = false;
-                    ReadSeq rd = item_read_seq(bt, i_seg, i_flip);
-                    const uint8_t *ref = ix.contig_revseq ? ix.contig_revseq[i_contig] : nullptr;
-                    if (!ref) {
-                        panic = true;  // rev_contig_seq.unwrap() on None (:174)
-                    } else {
-                        h = left_homology(ref, ix.contig_len[i_contig], m.T0[e], del, rd, m.T1[e], ins, pm, panic);
-                        algo_bytes += 2ull * (unsigned)(wv::imin(h + 1, wv::imax(pm, 1)));
-                    }
-                    if (panic) wv::atomic_or(&m.itp[id], 1);
+                    h = hrank < m.capk ? m.V[hrank] : 0;  // left homology from pass H
                     f.a = m_e;
                     f.b = h;
                     f.s = have_prev ? 0 : 1;
@@ -581,17 +638,36 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
     }
 
+    PLO_T(2)
     // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ------------------------------------------------------------------
     if (!overflow && (stages & PLO_STAGE_LIFTOVER)) {
-        // per item: window of the block map that can intersect the item
-        int W0 = kv0, W1 = kv0;
+        // per item: the window [W0, W1) of the block map that can intersect the item was located by build_item_desc;
+        // stage those entries (plus the one after, whose key bounds the last block) in LDS once per tile
         if (alive) {
-            int ub = kv_upper_bound(ix.kv, kv0, kv1, lo_pos);
-            W0 = wv::imax(kv0, ub - 1);
-            W1 = kv_lower_bound(ix.kv, W0, kv1, hi_pos);
             int nb = kv1 - kv0, lg = 0;
             while ((1 << lg) < nb) ++lg;
             algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
+        } else {
+            W1 = W0;
+        }
+        int nk = alive ? nk_all : 0;
+        int inck = wv::scan_add(nk);
+        int kb = inck - nk;
+        const bool staged = wv::bcast_last(inck) <= m.capk;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < KV_PF; ++k) {
+                if (k < nk) {
+                    m.K[kb + k] = kv_pre[k].key;
+                    m.V[kb + k] = kv_pre[k].val;
+                }
+            }
+            for (int k = KV_PF; k < nk; ++k) {
+                KV e = ix.kv[W0 + k];
+                m.K[kb + k] = e.key;
+                m.V[kb + k] = e.val;
+            }
+            wv::sync();
         }
         // pass A: per op, first block f and number of (op x block) pieces
         int P = 0;
@@ -604,7 +680,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 uint32_t c = valid ? m.A[e] : 0;
                 int id = valid ? (m.idA[e] & 63) : 0;
                 int i_alive = wv::shfl((int)alive, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
-                int i_w0 = wv::shfl(W0, id), i_w1 = wv::shfl(W1, id), i_kv0 = wv::shfl(kv0, id);
+                int i_w0 = wv::shfl(W0, id), i_w1 = wv::shfl(W1, id), i_kb = wv::shfl(kb, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_alive;
                 bool rc = ref_consuming(t);
@@ -613,11 +689,22 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 if (on) {
                     if (rc) {
                         if (L > 0) {
-                            // greatest key <= s (or "no block": index kv0-1) ... greatest key < s+L
-                            f = kv_upper_bound(ix.kv, i_w0, i_w1, s) - 1;
-                            if (f < i_kv0) f = i_kv0 - 1;
-                            int l = kv_lower_bound(ix.kv, i_w0, i_w1, s + L) - 1;
-                            cnt = l - f + 1;
+                            // window-relative block indices: f = greatest key <= s (or -1: no block, only possible when
+                            // the window starts at the map's first entry), l = greatest key < s+L
+                            int nw = i_w1 - i_w0, lo = 0, hi = nw;
+                            while (lo < hi) {  // upper bound of s
+                                int mid = (lo + hi) >> 1;
+                                int key = staged ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
+                                if (key <= s) lo = mid + 1; else hi = mid;
+                            }
+                            f = lo - 1;
+                            hi = nw;  // lower bound of s+L (>= the upper bound of s)
+                            while (lo < hi) {
+                                int mid = (lo + hi) >> 1;
+                                int key = staged ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
+                                if (key < s + L) lo = mid + 1; else hi = mid;
+                            }
+                            cnt = (lo - 1) - f + 1;
                         }
                     } else if (t == OP_I || t == OP_S || t == OP_H) {
                         cnt = 1;  // :157-160 copied through; Pad (:213) emits nothing
@@ -632,6 +719,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             P = pieces.carry;
         }
+        PLO_T(3)
         if (P > m.cap) overflow = true;
         if (!overflow) {
             for (int base = 0; base < P; base += 64) {
@@ -658,7 +746,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (i < 0) i = 0;
                     uint32_t c = valid ? m.A[i] : 0;
                     int id = valid ? (m.idA[i] & 63) : 0;
-                    int i_kv0 = wv::shfl(kv0, id), i_kv1 = wv::shfl(kv1, id);
+                    int i_w0 = wv::shfl(W0, id), i_kv1 = wv::shfl(kv1, id), i_kb = wv::shfl(kb, id);
                     int t = op_type(c), L = op_len(c);
                     bool piece = valid && ref_consuming(t);
                     bool ism = is_match(t);
@@ -666,26 +754,31 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     int plen = 0, val = NONE32, endval = 0, startval = 0;
                     if (piece) {
                         int s = m.T0[i], f = m.T1[i], tt = j - m.T2[i];
-                        int b = f + tt;
-                        before = b < i_kv0;
-                        int kb = 0;
+                        int b = f + tt;  // window-relative block index, -1 = before the first block of the map
+                        before = b < 0;
+                        int bkey = 0;
                         if (!before) {
-                            KV kvb = ix.kv[b];
-                            kb = kvb.key;
-                            val = kvb.val;
+                            if (staged) {
+                                bkey = m.K[i_kb + b];
+                                val = m.V[i_kb + b];
+                            } else {
+                                KV kvb = ix.kv[i_w0 + b];
+                                bkey = kvb.key;
+                                val = kvb.val;
+                            }
                         }
-                        int pstart = (tt == 0) ? s : kb;
+                        int pstart = (tt == 0) ? s : bkey;
                         int pend = s + L;
-                        if (b + 1 < i_kv1) {
-                            int kn = ix.kv[b + 1].key;
+                        if (i_w0 + b + 1 < i_kv1) {
+                            int kn = staged ? m.K[i_kb + b + 1] : ix.kv[i_w0 + b + 1].key;
                             if (kn < pend) pend = kn;
                         }
                         plen = pend - pstart;
                         mapped = !before && val != NONE32;
                         fm = mapped && ism;
                         if (mapped) {
-                            endval = val + (pend - kb);      // :98-100
-                            startval = val + (pstart - kb);  // :84-88
+                            endval = val + (pend - bkey);      // :98-100
+                            startval = val + (pstart - bkey);  // :84-88
                         }
                     }
                     if (valid) {
@@ -734,6 +827,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             overflow = wv::ballot(overflow) != 0ull;
             wv::sync();
+            PLO_T(4)
             if (!overflow) {
                 int cB = m.itc[lane];
                 int incB = wv::scan_add(cB);
@@ -754,6 +848,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
     }
 
+    PLO_T(5)
     // ---- LENGTH CHECK (src/read_alignment_scanner.rs:204-229) ------------------------------------------------------------------
     bool simp = alive;
     if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
@@ -770,20 +865,22 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         finish_counts(m.T0, sA, cA, ns, rl);
         wv::sync();
         if (alive) {
-            uint32_t read = bt.seg_read[seg];
-            if ((int)bt.read_seq_len[read] != rl) {
+            if (seq_len != rl) {
                 status = PLO_ITEM_LEN_MISMATCH;
                 simp = false;
             }
         }
     }
 
+    PLO_T(6)
     // ---- SIMPLIFY (src/simplify_alignment_indels.rs:5-156) ------------------------------------------------------------------
     if (!overflow && (stages & PLO_STAGE_SIMPLIFY)) {
-        // pass A: clusters = maximal runs of I/D ops; sums at the cluster head
+        // pass A: clusters = maximal runs of I/D ops; sums at the cluster head; compact list of cluster heads
+        int nH = 0;
         {
             SegSum sr, sq;
             MaxScan heads(-1);
+            AddScan hcount;
             int carry_c = 0;
             for (int base = 0; base < nA; base += 64) {
                 int e = base + lane;
@@ -801,6 +898,11 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 carry_c = wv::bcast_last((int)isC);
                 bool chead = isC && !(prevC && !ihead);
                 int hidx = heads.incl(chead ? e : -1);
+                int hrank = hcount.excl(chead ? 1 : 0);
+                if (chead) {
+                    if (hrank < m.capk) m.K[hrank] = e;
+                    else overflow = true;
+                }
                 if (valid) {
                     m.T0[e] = i_pos + R;  // block_ref_start
                     m.T1[e] = Q;          // block_read_start
@@ -808,12 +910,91 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
                 }
             }
+            nH = hcount.carry;
+        }
+        overflow = wv::ballot(overflow) != 0ull;
+        wv::sync();
+        // pass H: one lane per cluster; only complex clusters (both I and D, not 1/1) look at the sequences
+        // (CigarBlockInfo::end_indel :49-105).  Results overwrite the head's slots: T0 pre, T1 post, T3 del, T4 ins.
+        for (int base = 0; base < nH && !overflow; base += 64) {
+            int hl = base + lane;
+            bool valid = hl < nH;
+            int e = valid ? m.K[hl] : 0;
+            int id = m.idA[e] & 63;
+            int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(chrom_ref_len, id);
+            unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(chrom_ref, id);
+            if (valid) {
+                int del = m.T3[e], ins = m.T4[e];
+                int complex_done = 0;
+                if (del > 0 && ins > 0 && !(del == 1 && ins == 1)) {
+                    int rs0 = m.T0[e], qs0 = m.T1[e];
+                    ReadSeq rd = item_read_seq(bt, i_soff, i_slen, i_flip);
+                    const uint8_t *ref = (const uint8_t *)(uintptr_t)i_ref;
+                    if (rs0 < 0 || rs0 + del - 1 >= i_rlen || qs0 + ins - 1 >= rd.len) {
+                        wv::atomic_or(&m.itp[id], 1);  // slice index out of bounds: the reference panics (:58-60)
+                    } else {
+                        int pre = 0, post = 0, cmp = 0;
+                        for (;;) {  // :55-68, probes issued 8 at a time
+                            int n = wv::imin(8, wv::imin(del, ins));
+                            if (n <= 0) break;
+                            int a[8], b[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                int jj = j < n ? j : 0;
+                                a[j] = ref[rs0 + del - 1 - jj];
+                                b[j] = read_base(rd, qs0 + ins - 1 - jj);
+                            }
+                            int adv = n;
+#pragma unroll
+                            for (int j = 7; j >= 0; --j)
+                                if (j < n && a[j] != b[j]) adv = j;
+                            cmp += wv::imin(adv + 1, n);
+                            del -= adv;
+                            ins -= adv;
+                            post += adv;
+                            if (adv < n) break;
+                        }
+                        for (;;) {  // :71-85
+                            int n = wv::imin(8, wv::imin(del, ins));
+                            if (n <= 0) break;
+                            int a[8], b[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                int jj = j < n ? j : 0;
+                                a[j] = ref[rs0 + pre + jj];
+                                b[j] = read_base(rd, qs0 + pre + jj);
+                            }
+                            int adv = n;
+#pragma unroll
+                            for (int j = 7; j >= 0; --j)
+                                if (j < n && a[j] != b[j]) adv = j;
+                            cmp += wv::imin(adv + 1, n);
+                            del -= adv;
+                            ins -= adv;
+                            pre += adv;
+                            if (adv < n) break;
+                        }
+                        if (del == 1 && ins == 1) {  // :88-92
+                            del = 0;
+                            ins = 0;
+                            ++post;
+                        }
+                        algo_bytes += 2ull * (unsigned)cmp;
+                        m.T0[e] = pre;
+                        m.T1[e] = post;
+                        m.T3[e] = del;
+                        m.T4[e] = ins;
+                        complex_done = 1;
+                    }
+                }
+                m.V[hl] = complex_done;
+            }
         }
         wv::sync();
-        // pass B: CigarBlockInfo::end_indel per cluster head (:35-111)
+        // pass B: emission
         int nB = 0;
         {
-            AddScan emit;
+            AddScan emit, hcount;
             for (int base = 0; base < nA; base += 64) {
                 int e = base + lane;
                 bool valid = e < nA;
@@ -822,57 +1003,31 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 int id = idf & 63;
                 bool chead = (idf & 64) != 0;
                 int i_on = wv::shfl((int)simp, id);
-                int i_seg = wv::shfl(seg, id), i_chrom = wv::shfl(chrom, id), i_flip = wv::shfl((int)flip, id);
                 int t = op_type(c);
                 bool on = valid && i_on;
+                int hrank = hcount.excl((on && chead) ? 1 : 0);
                 uint32_t o[4];
                 int ne = 0;
                 if (valid && !(on && is_indel(t))) {
                     o[ne++] = c;  // :144-147 (everything that is not part of a cluster is copied)
                 } else if (on && chead) {
                     int del = m.T3[e], ins = m.T4[e];
-                    if (del == 0 && ins == 0) {
+                    int was_complex = hrank < m.capk ? m.V[hrank] : 0;
+                    if (was_complex) {
+                        int pre = m.T0[e], post = m.T1[e];
+                        if (pre > 0) o[ne++] = mk_op(OP_M, pre);  // :101-104
+                        if (ins > 0) o[ne++] = mk_op(OP_I, ins);
+                        if (del > 0) o[ne++] = mk_op(OP_D, del);
+                        if (post > 0) o[ne++] = mk_op(OP_M, post);
+                    } else if (del == 0 && ins == 0) {
                     } else if (del == 0) {
                         o[ne++] = mk_op(OP_I, ins);
                     } else if (ins == 0) {
                         o[ne++] = mk_op(OP_D, del);
                     } else if (del == 1 && ins == 1) {
                         o[ne++] = mk_op(OP_M, 1);  // :45-48
-                    } else {
-                        int rs0 = m.T0[e], qs0 = m.T1[e];
-                        ReadSeq rd = item_read_seq(bt, i_seg, i_flip);
-                        const uint8_t *ref = ix.chrom_seq[i_chrom];
-                        int ref_len = ix.chrom_len[i_chrom];
-                        if (rs0 < 0 || rs0 + del - 1 >= ref_len || qs0 + ins - 1 >= rd.len) {
-                            wv::atomic_or(&m.itp[id], 1);  // slice index out of bounds: the reference panics
-                        } else {
-                            int pre = 0, post = 0, cmp = 0;
-                            while (del > 0 && ins > 0) {  // :55-68
-                                ++cmp;
-                                if (ref[rs0 + del - 1] != read_base(rd, qs0 + ins - 1)) break;
-                                --del;
-                                --ins;
-                                ++post;
-                            }
-                            while (del > 0 && ins > 0) {  // :71-85
-                                ++cmp;
-                                if (ref[rs0 + pre] != read_base(rd, qs0 + pre)) break;
-                                --del;
-                                --ins;
-                                ++pre;
-                            }
-                            if (del == 1 && ins == 1) {  // :88-92
-                                del = 0;
-                                ins = 0;
-                                ++post;
-                            }
-                            algo_bytes += 2ull * (unsigned)cmp;
-                            if (pre > 0) o[ne++] = mk_op(OP_M, pre);  // :101-104
-                            if (ins > 0) o[ne++] = mk_op(OP_I, ins);
-                            if (del > 0) o[ne++] = mk_op(OP_D, del);
-                            if (post > 0) o[ne++] = mk_op(OP_M, post);
-                        }
                     }
+                    // (a complex cluster that would have panicked emits nothing; the item is reported PANIC)
                 }
                 int ei = emit.incl(ne);
                 int p = ei - ne;
@@ -890,6 +1045,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         overflow = wv::ballot(overflow) != 0ull;
         wv::sync();
+        PLO_T(7)
         if (!overflow) {
             int sB, cB;
             finish_counts(m.T2, sA, cA, sB, cB);
@@ -907,6 +1063,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
     }
 
+    PLO_T(8)
     // ---- OUTPUT --------------------------------------------------------------------------------------------------------------
     overflow = wv::ballot(overflow) != 0ull;
     if (overflow) {
@@ -937,14 +1094,18 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     int inco = wv::scan_add(oc);
     int oS = inco - oc;
     int total = wv::bcast_last(inco);
-    unsigned long long gbase = 0;
-    if (lane == 0 && total > 0) gbase = wv::atomic_add_global(&wk.counters[CNT_CIGAR], (unsigned long long)total);
-    {
-        // 64-bit broadcast of the bump-allocated base
-        unsigned lo = (unsigned)wv::bcast_first((int)(unsigned)(gbase & 0xffffffffull));
-        unsigned hi = (unsigned)wv::bcast_first((int)(unsigned)(gbase >> 32));
-        gbase = ((unsigned long long)hi << 32) | lo;
+    if ((unsigned long long)total > ctx.slab_left) {  // wave-uniform: reserve a new slab
+        unsigned long long want = (unsigned long long)total > SLAB_OPS ? (unsigned long long)total : SLAB_OPS;
+        unsigned long long nb = 0;
+        if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want);
+        unsigned lo = (unsigned)wv::bcast_first((int)(unsigned)(nb & 0xffffffffull));
+        unsigned hi = (unsigned)wv::bcast_first((int)(unsigned)(nb >> 32));
+        ctx.slab_base = ((unsigned long long)hi << 32) | lo;
+        ctx.slab_left = want;
     }
+    const unsigned long long gbase = ctx.slab_base;
+    ctx.slab_base += (unsigned long long)total;
+    ctx.slab_left -= (unsigned long long)total;
     bool fits = gbase + (unsigned long long)total <= wk.out_cap;
     if (!fits && lane == 0) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
     for (int base = 0; base < nA; base += 64) {
@@ -956,50 +1117,33 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
     if (has) {
         wk.status[g] = (uint8_t)status;
-        wk.flip[g] = (uint8_t)flip;
-        wk.mapq[g] = (uint8_t)mapq;
-        wk.chrom[g] = (uint32_t)chrom;
         wk.pos[g] = emit_cigar ? (int64_t)pos1 : (int64_t)-1;
         wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
         wk.cig_len[g] = (uint32_t)oc;
         algo_bytes += 40ull + 4ull * (unsigned)n_in + 24ull + 4ull * (unsigned)oc;
     }
-    // statistics: one atomic per tile
-    {
-        unsigned lo = (unsigned)(algo_bytes & 0xffffffffull);
-        int s = wv::reduce_add((int)lo);  // per-tile sums stay far below 2^31
-        int nin = wv::reduce_add(has ? n_in : 0);
-        if (lane == 0) {
-            wv::atomic_add_global(&wk.counters[CNT_ALGO_BYTES], (unsigned long long)(unsigned)s);
-            wv::atomic_add_global(&wk.counters[CNT_IN_OPS], (unsigned long long)(unsigned)nin);
-        }
-    }
+    // statistics stay in registers until the wave retires (wave_ctx_flush)
+    ctx.algo_bytes += algo_bytes;
+    ctx.in_ops += has ? (unsigned long long)n_in : 0ull;
+    PLO_T(9)
+#ifdef PLO_PHASE_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 12; ++k) wv::atomic_add_global(&wk.counters[CNT_PHASE0 + k], (unsigned long long)tph[k]);
+#endif
+#undef PLO_T
 }
 
 // -------------------------------------------------------------------------------------------------------------------
 // Tile assignment: tile w owns the items whose exclusive input-op prefix lies in [w*window, (w+1)*window), i.e. the
 // flattened input op stream is cut into windows and every item goes to the window its first op falls in.
 // -------------------------------------------------------------------------------------------------------------------
-PLO_DEV uint32_t prefix_lower_bound(const uint32_t *a, uint32_t n, unsigned long long x) {  // first i in [0,n) with a[i] >= x
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((unsigned long long)a[mid] < x)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
 PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t tile, int window,
-                         int big_thresh, TileMem m) {
-    unsigned long long w0 = (unsigned long long)tile * (unsigned)window;
-    uint32_t lo = prefix_lower_bound(wk.item_op_prefix, wk.n_items, w0);
-    uint32_t hi = prefix_lower_bound(wk.item_op_prefix, wk.n_items, w0 + (unsigned)window);
+                         int big_thresh, TileMem m, WaveCtx &ctx) {
+    (void)window;
+    uint32_t lo = wk.tile_lo[tile], hi = wk.tile_lo[tile + 1];  // written by k_tile_bounds
     for (uint32_t b = lo; b < hi; b += 64) {
         int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-        lift_tile(ix, bt, wk, stages, b, nit, m, false, big_thresh);
+        lift_tile(ix, bt, wk, stages, b, nit, m, false, big_thresh, ctx);
         wv::sync();
     }
 }

@@ -49,14 +49,36 @@ struct DevBatch {
     uint32_t n_reads, n_segs;
 };
 
-enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_N = 8 };
+enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_PHASE0 = 8, CNT_N = 24 };
+
+// Resolved per-item descriptors, written once per batch by the item kernels (thread per item, full occupancy) so that
+// the tile kernel starts from ONE level of coalesced loads instead of chasing item -> segment -> contig -> block map.
+struct ItemDesc {
+    uint32_t *in_off;   // first input CIGAR op of the item's read segment
+    uint32_t *n_in;     // number of input ops
+    int *pos1;          // start on the map strand: seg_pos, or rev_pos for reverse-mapped contig segments (STRAND)
+    uint32_t *w0, *w1;  // window [w0, w1) of the contig segment's block map that can intersect the item
+    uint32_t *kv0, *kv1;  // the contig segment's whole block map
+    uint32_t *flags;    // bit0 reverse the CIGAR, bit1 need_flipped, bit2 contig segment maps forward
+    uint32_t *contig;
+    uint32_t *seq_len;
+    uint64_t *seq_off;
+    uint64_t *shift_ref;   // rev_contig_seq of the contig (device address, 0 = none): ref_seq of left_shift_indels
+    int *shift_ref_len;    // contig length
+    uint64_t *chrom_ref;   // reference[chrom_index]: ref_seq of simplify_alignment_indels
+    int *chrom_ref_len;
+};
+enum { ITF_REV = 1, ITF_FLIP = 2, ITF_CONTIG_FWD = 4 };
 
 // The item work list and the per-item outputs (all device memory)
 struct DevWork {
     uint32_t n_items;
-    const uint32_t *item_seg;
-    const uint32_t *item_cseg;
+    uint32_t *item_seg;
+    uint32_t *item_cseg;
+    uint32_t *item_nin;              // input op count per item (scanned into item_op_prefix)
     const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix of the items' input op counts
+    const uint32_t *tile_lo;         // [n_tiles+1] first item of every tile (window of the flattened op stream)
+    ItemDesc d;
     uint8_t *status;
     uint8_t *flip;
     uint8_t *mapq;

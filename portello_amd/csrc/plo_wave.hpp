@@ -14,6 +14,7 @@
 namespace wv {
 
 PLO_DEV int lane() { return (int)__lane_id(); }
+PLO_DEV long long clock() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 // LDS (or wave-private global scratch) hand-off between lanes of ONE wave: DS operations of a wave execute in
 // order, so all that is needed is to stop the compiler from moving memory accesses across this point.

@@ -137,7 +137,11 @@ def make_reference(length: int, tract_frac: float, gen: torch.Generator, device)
         return seq
     mean_tract = 14
     n_tr = max(1, int(length * tract_frac / mean_tract))
-    start = torch.randint(0, max(1, length - 64), (n_tr,), generator=gen, device=device)
+    # one tract per stride-sized cell (never overlapping: duplicate scatter targets would make the result depend on
+    # the thread schedule)
+    stride = max(32, length // n_tr)
+    n_tr = max(1, (length - 64) // stride)
+    start = torch.arange(n_tr, device=device) * stride + torch.randint(0, max(1, stride - 30), (n_tr,), generator=gen, device=device)
     tlen = torch.randint(3, 25, (n_tr,), generator=gen, device=device)
     unit = torch.randint(1, 7, (n_tr,), generator=gen, device=device)
     unit = torch.where(torch.rand(n_tr, generator=gen, device=device) < 0.6, torch.ones_like(unit), unit)

@@ -62,28 +62,20 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     bt.n_segs = in->n_segs;
 
     Out *o = new Out();
-    std::vector<uint32_t> item_nin;
+    // ---- item list: count, then resolve descriptors (what k_seg_count / k_item_emit / k_item_desc do on the GPU) ----
+    std::vector<uint32_t> seg_cnt(in->n_segs, 0);
+    uint32_t n_items = 0;
     if (in->item_seg) {
-        o->item_seg.assign(in->item_seg, in->item_seg + in->n_items);
-        o->item_cseg.assign(in->item_cseg, in->item_cseg + in->n_items);
-        for (uint32_t i = 0; i < in->n_items; ++i)
-            item_nin.push_back(in->seg_cigar_off[in->item_seg[i] + 1] - in->seg_cigar_off[in->item_seg[i]]);
+        n_items = in->n_items;
     } else {
         for (uint32_t s = 0; s < in->n_segs; ++s) {
-            uint32_t n = enumerate_segment(ix, bt, s, nullptr, nullptr, nullptr, 0);
-            size_t base = o->item_seg.size();
-            o->item_seg.resize(base + n);
-            o->item_cseg.resize(base + n);
-            item_nin.resize(base + n);
-            enumerate_segment(ix, bt, s, o->item_seg.data(), o->item_cseg.data(), item_nin.data(), (uint32_t)base);
+            seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0);
+            n_items += seg_cnt[s];
         }
     }
-    uint32_t n_items = (uint32_t)o->item_seg.size();
-    std::vector<uint32_t> prefix(n_items + 1, 0);
-    for (uint32_t i = 0; i < n_items; ++i) prefix[i + 1] = prefix[i] + item_nin[i];
-    uint64_t total_ops = prefix[n_items];
-
     size_t a = n_items ? n_items : 1;
+    o->item_seg.assign(a, 0);
+    o->item_cseg.assign(a, 0);
     o->status.assign(a, 0xEE);
     o->flip.assign(a, 0);
     o->mapq.assign(a, 0);
@@ -91,51 +83,102 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     o->pos.assign(a, 0);
     o->cig_off.assign(a, 0);
     o->cig_len.assign(a, 0);
-    uint64_t out_cap = 4 * total_ops + 64ull * n_items + 1024;
-    for (uint32_t g = 0; g < ixd->n_segments; ++g) out_cap += 0;  // (blocks add pieces; bounded below by retry)
-    std::vector<uint32_t> big_list(a, 0);
+    std::vector<uint32_t> item_nin(a, 0), d_in_off(a), d_n_in(a), d_w0(a), d_w1(a), d_kv0(a), d_kv1(a), d_flags(a), d_contig(a),
+        d_seq_len(a), big_list(a, 0);
+    std::vector<int> d_pos1(a);
+    std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
+    std::vector<int> d_shift_ref_len(a), d_chrom_ref_len(a);
     unsigned long long counters[CNT_N];
+    memset(counters, 0, sizeof(counters));
 
+    DevWork wk;
+    memset(&wk, 0, sizeof(wk));
+    wk.n_items = n_items;
+    wk.item_seg = o->item_seg.data();
+    wk.item_cseg = o->item_cseg.data();
+    wk.item_nin = item_nin.data();
+    wk.d.in_off = d_in_off.data();
+    wk.d.n_in = d_n_in.data();
+    wk.d.pos1 = d_pos1.data();
+    wk.d.w0 = d_w0.data();
+    wk.d.w1 = d_w1.data();
+    wk.d.kv0 = d_kv0.data();
+    wk.d.kv1 = d_kv1.data();
+    wk.d.flags = d_flags.data();
+    wk.d.contig = d_contig.data();
+    wk.d.seq_len = d_seq_len.data();
+    wk.d.seq_off = d_seq_off.data();
+    wk.d.shift_ref = d_shift_ref.data();
+    wk.d.shift_ref_len = d_shift_ref_len.data();
+    wk.d.chrom_ref = d_chrom_ref.data();
+    wk.d.chrom_ref_len = d_chrom_ref_len.data();
+    wk.status = o->status.data();
+    wk.flip = o->flip.data();
+    wk.mapq = o->mapq.data();
+    wk.chrom = o->chrom.data();
+    wk.pos = o->pos.data();
+    wk.cig_off = o->cig_off.data();
+    wk.cig_len = o->cig_len.data();
+    wk.counters = counters;
+    wk.big_list = big_list.data();
+    if (in->item_seg) {
+        for (uint32_t i = 0; i < n_items; ++i)
+            build_item_desc(ix, bt, wk, stages, i, in->item_seg[i], in->item_cseg[i], segment_ref_len(bt, in->item_seg[i]));
+    } else {
+        uint32_t off = 0;
+        for (uint32_t s = 0; s < in->n_segs; ++s) {
+            if (seg_cnt[s]) enumerate_segment(ix, bt, s, &wk, stages, off);
+            off += seg_cnt[s];
+        }
+    }
+    std::vector<uint32_t> prefix(n_items + 1, 0);
+    for (uint32_t i = 0; i < n_items; ++i) prefix[i + 1] = prefix[i] + item_nin[i];
+    uint64_t total_ops = prefix[n_items];
+    wk.item_op_prefix = prefix.data();
+    uint32_t n_tiles = (uint32_t)(total_ops / (uint64_t)window) + 1;
+    std::vector<uint32_t> tile_lo(n_tiles + 1);
+    for (uint32_t t = 0; t <= n_tiles; ++t)
+        tile_lo[t] = prefix_lower_bound(prefix.data(), n_items, (unsigned long long)t * (unsigned)window);  // k_tile_bounds
+    wk.tile_lo = tile_lo.data();
+
+    uint64_t out_cap = 4 * total_ops + 64ull * n_items + 1024 + 8 * SLAB_OPS;
     for (int attempt = 0; attempt < 6; ++attempt) {
         o->cigar.assign(out_cap, 0);
         memset(counters, 0, sizeof(counters));
-        DevWork wk;
-        wk.n_items = n_items;
-        wk.item_seg = o->item_seg.data();
-        wk.item_cseg = o->item_cseg.data();
-        wk.item_op_prefix = prefix.data();
-        wk.status = o->status.data();
-        wk.flip = o->flip.data();
-        wk.mapq = o->mapq.data();
-        wk.chrom = o->chrom.data();
-        wk.pos = o->pos.data();
-        wk.cig_off = o->cig_off.data();
-        wk.cig_len = o->cig_len.data();
         wk.out_cigar = o->cigar.data();
         wk.out_cap = out_cap;
-        wk.counters = counters;
-        wk.big_list = big_list.data();
-
-        uint32_t n_tiles = (uint32_t)(total_ops / (uint64_t)window) + 1;
         std::vector<unsigned char> lds(tile_mem_bytes(cap) + 64);
-        for (uint32_t t = 0; t < n_tiles && n_items; ++t) {
+        const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
+        for (uint32_t wv_id = 0; wv_id < n_waves && n_items; ++wv_id) {
             wv::EmuWave w;
-            w.order_seed = order_seed ? order_seed + t : 0;
+            w.order_seed = order_seed ? order_seed + wv_id : 0;
             TileMem m = carve_tile_mem(lds.data(), cap);
-            w.run([&]() { lift_window(ix, bt, wk, stages, t, window, big_thresh, m); });
+            w.run([&]() {
+                WaveCtx ctx;
+                for (uint32_t t = wv_id; t < n_tiles; t += n_waves) lift_window(ix, bt, wk, stages, t, window, big_thresh, m, ctx);
+                wave_ctx_flush(wk, ctx);
+            });
         }
         uint32_t n_big = (uint32_t)counters[CNT_NBIG];
         if (n_big) {
             std::vector<unsigned char> scratch(tile_mem_bytes(big_cap) + 64);
-            for (uint32_t i = 0; i < n_big; ++i) {
+            const uint32_t n_bw = 2;
+            for (uint32_t wv_id = 0; wv_id < n_bw; ++wv_id) {
                 wv::EmuWave w;
-                w.order_seed = order_seed ? order_seed + 7777 + i : 0;
+                w.order_seed = order_seed ? order_seed + 7777 + wv_id : 0;
                 TileMem m = carve_tile_mem(scratch.data(), big_cap);
-                w.run([&]() { lift_tile(ix, bt, wk, stages, i, 1, m, true, 0); });
+                w.run([&]() {
+                    WaveCtx ctx;
+                    for (uint32_t i = wv_id; i < n_big; i += n_bw) {
+                        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0, ctx);
+                        wv::sync();
+                    }
+                    wave_ctx_flush(wk, ctx);
+                });
             }
         }
         if (counters[CNT_OVERFLOW] == 0) break;
-        out_cap = counters[CNT_CIGAR] + 1024;
+        out_cap = counters[CNT_CIGAR] + 8 * SLAB_OPS;
     }
     if (counters_out) memcpy(counters_out, counters, sizeof(counters));
 
@@ -151,9 +194,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     out->item_cigar_len = o->cig_len.data();
     out->cigar = o->cigar.data();
     out->n_cigar = counters[CNT_CIGAR];
-    // the Out object is leaked into the caller's hands; emu_free releases it
-    static_assert(sizeof(void *) == 8, "");
-    ((void **)&out->n_cigar)[0] = ((void **)&out->n_cigar)[0];
+    // the Out object stays alive until emu_free_last()
     extern void *g_last_emu_out;
     g_last_emu_out = o;
     return counters[CNT_ERROR] ? 2 : 0;

@@ -109,6 +109,7 @@ struct EmuWave {
 inline EmuWave &W() { return *EmuWave::current(); }
 
 inline int lane() { return W().cur; }
+inline long long clock() { return 0; }
 
 enum { T_SYNC = 1, T_SHFL, T_SHFL_UP1, T_BALLOT, T_BCAST_LAST, T_BCAST_FIRST, T_SCAN_ADD, T_SCAN_MAX, T_SCAN_MP };
 

@@ -19,7 +19,7 @@ def build(force=False, sanitize=False):
         os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
-        cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "emu"),
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "emu"),
                "-o", _LIB, srcs[0]]
         if sanitize:
             cmd[1:1] = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
@@ -45,7 +45,7 @@ def liftover_batch(index: abi.IndexData, batch: abi.BatchData, stages=abi.STAGES
     d = index.to_desc()
     b = batch.to_desc()
     out = abi.PloBatchOut()
-    counters = (C.c_ulonglong * 8)()
+    counters = (C.c_ulonglong * 24)()
     rc = lib().emu_liftover_batch(C.byref(d), C.byref(b), stages, cap, window, big_thresh, big_cap, order_seed, C.byref(out), counters)
     res = abi.result_from_out(out)
     lib().emu_free_last()
