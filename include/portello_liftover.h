@@ -172,7 +172,8 @@ typedef struct plo_batch_out {
     const uint64_t *item_cigar_off;    /* offset of the item's CIGAR inside `cigar`                           */
     const uint32_t *item_cigar_len;    /* number of ops                                                       */
     const uint32_t *cigar;             /* lifted CIGARs                                                       */
-    uint64_t n_cigar;                  /* total ops stored in `cigar`                                         */
+    uint64_t n_cigar;                  /* extent of `cigar` in ops (items index it through item_cigar_off; the
+                                          buffer is slab-allocated on the device and may contain unused gaps)  */
 } plo_batch_out;
 
 /* Per-call device timing measured with HIP events on the context's stream */

@@ -690,7 +690,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_items = n_items;
     c->timing.n_big_items = n_big;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
-    c->timing.n_out_ops = hc[CNT_CIGAR];
+    c->timing.n_out_ops = hc[CNT_OUT_OPS];
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
     for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
 

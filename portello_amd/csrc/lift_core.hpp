@@ -323,6 +323,7 @@ struct WaveCtx {
     unsigned long long slab_left = 0;  // ops left in it
     unsigned long long algo_bytes = 0;  // per lane
     unsigned long long in_ops = 0;      // per lane
+    unsigned long long out_ops = 0;     // per lane
 };
 constexpr unsigned long long SLAB_OPS = 16384;
 
@@ -336,8 +337,12 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx) {
         wv::atomic_add_global(&wk.counters[CNT_ALGO_BYTES], (unsigned long long)lo + ((unsigned long long)hi << 24));
         wv::atomic_add_global(&wk.counters[CNT_IN_OPS], (unsigned long long)nlo + ((unsigned long long)nhi << 24));
     }
+    unsigned olo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops & 0xffffffull));
+    unsigned ohi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops >> 24));
+    if (wv::lane() == 0) wv::atomic_add_global(&wk.counters[CNT_OUT_OPS], (unsigned long long)olo + ((unsigned long long)ohi << 24));
     ctx.algo_bytes = 0;
     ctx.in_ops = 0;
+    ctx.out_ops = 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1125,6 +1130,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // statistics stay in registers until the wave retires (wave_ctx_flush)
     ctx.algo_bytes += algo_bytes;
     ctx.in_ops += has ? (unsigned long long)n_in : 0ull;
+    ctx.out_ops += (unsigned long long)oc;
     PLO_T(9)
 #ifdef PLO_PHASE_TIMING
     if (lane == 0)

@@ -92,7 +92,7 @@ def test_synthetic_plumbing_config(oracle):
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "plumbing")
     t = eng.timing()
     n_in = (b.seg_cigar_off[1:] - b.seg_cigar_off[:-1])[got.item_seg]
-    assert t.n_items == got.n_items and t.n_in_ops == int(n_in.sum()) and t.n_out_ops == len(got.cigar)
+    assert t.n_items == got.n_items and t.n_in_ops == int(n_in.sum()) and t.n_out_ops == int(got.item_cigar_len.sum())
     assert t.algo_bytes >= 64 * got.n_items
     # run it twice on the same context: buffers are reused, results identical
     _assert_same(got, eng.liftover_batch(b), "plumbing_rerun")
