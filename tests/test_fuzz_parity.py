@@ -1,0 +1,47 @@
+"""Adversarial random batches (tests/fuzz_cases.py): every op code, zero-length ops, edge indels, tiny alphabets,
+inconsistent lengths, out-of-range positions.  CPU: device algorithm under the emulator vs oracle.  GPU: HIP vs oracle."""
+import numpy as np
+import pytest
+
+import emu_lib
+import fuzz_cases
+from portello_amd import abi, api
+from portello_amd import cigar as cg
+
+STAGE_SETS = (31, 15, 5, 2, 16, 7, 27)
+
+
+def _diff(ref, got, b, tag):
+    a, c = ref.canonical(), got.canonical()
+    assert len(a) == len(c), tag
+    for x, y in zip(a, c):
+        if x != y:
+            s = x[0]
+            raise AssertionError(f"{tag}: seg {s} in {cg.decode(b.cigar[b.seg_cigar_off[s]:b.seg_cigar_off[s + 1]])} pos {b.seg_pos[s]}\n"
+                                 f" ref {x[:7]} {cg.decode(np.frombuffer(x[7], np.uint32))}\n got {y[:7]} {cg.decode(np.frombuffer(y[7], np.uint32))}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_emulated_device_algorithm(oracle, seed):
+    for alpha in (b"ACGT", b"AC", b"A"):
+        ix, b = fuzz_cases.make(100 + seed, alphabet=alpha, explicit=(seed % 3 == 0),
+                                seq_fmt=(abi.SEQ_BAM4 if seed % 4 == 1 else abi.SEQ_ASCII))
+        for stages in STAGE_SETS:
+            ref = oracle.liftover_batch(ix, b, stages, 1)
+            rc, got, _ = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096)
+            assert rc == 0
+            _diff(ref, got, b, f"seed {seed} alpha {alpha} stages {stages}")
+
+
+@pytest.mark.gpu
+def test_fuzz_hip(oracle):
+    for seed in range(40):
+        alpha = (b"ACGT", b"AC", b"A")[seed % 3]
+        ix, b = fuzz_cases.make(1000 + seed, alphabet=alpha, n_reads=120, explicit=(seed % 3 == 0),
+                                seq_fmt=(abi.SEQ_BAM4 if seed % 4 == 1 else abi.SEQ_ASCII))
+        index = api.Index(ix)
+        eng = api.Engine(index)
+        for stages in STAGE_SETS:
+            _diff(oracle.liftover_batch(ix, b, stages, 1), eng.liftover_batch(b, stages), b, f"seed {seed} stages {stages}")
+        eng.close()
+        index.close()

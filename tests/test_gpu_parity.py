@@ -151,3 +151,58 @@ def test_device_resident_api_matches_host_api(oracle):
     _assert_same(ref, res, "device_api")
     eng.close()
     eng_ix.close()
+
+
+def test_full_size_properties_chr20(oracle):
+    """BASELINE configs[1] at full size: size-independent properties of every lifted record + oracle parity on a sample"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("chr20"), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    res = devbatch.run_and_download(eng, db)
+    assert res.n_items >= w.n_reads * 0.9
+    lifted = res.item_status == abi.ITEM_LIFTED
+    assert lifted.mean() > 0.95 and (res.item_status <= abi.ITEM_NO_LIFTOVER).all()
+    # flattened view of all lifted CIGARs
+    lens = res.item_cigar_len.astype(np.int64)
+    idx = np.repeat(res.item_cigar_off.astype(np.int64), lens) + (np.arange(lens.sum()) - np.repeat(np.cumsum(lens) - lens, lens))
+    ops = res.cigar[idx]
+    item = np.repeat(np.arange(res.n_items), lens)
+    t, L = ops & 15, (ops >> 4).astype(np.int64)
+    # (1) read length of the lifted CIGAR == seq_len (the reference's own sanity check, read_alignment_scanner.rs:206-207)
+    rl = np.bincount(item, weights=L * np.isin(t, [0, 1, 4, 5, 7, 8]), minlength=res.n_items).astype(np.int64)
+    seq_len = w.read_seq_len.cpu().numpy()[w.seg_read.cpu().numpy()[res.item_seg]]
+    assert (rl[lifted] == seq_len[lifted]).all()
+    # (2) canonical form: no zero-length op, no equal neighbours, only M I D N S H (=/X become M)
+    assert (L > 0).all() and np.isin(t, [0, 1, 2, 3, 4, 5]).all()
+    same_item = item[1:] == item[:-1]
+    assert not (same_item & (t[1:] == t[:-1])).any()
+    # (3) no indel at the alignment edges: the first and the last non-clip op of every record is a match
+    nonclip = ~np.isin(t, [4, 5])
+    first = np.full(res.n_items, -1)
+    last = np.full(res.n_items, -1)
+    pos = np.nonzero(nonclip)[0]
+    first[item[pos][::-1]] = t[pos][::-1]
+    last[item[pos]] = t[pos]
+    assert (first[lifted] == 0).all() and (last[lifted] == 0).all()
+    # (4) the lifted alignment stays inside its chromosome
+    ref_span = np.bincount(item, weights=L * np.isin(t, [0, 2, 3]), minlength=res.n_items).astype(np.int64)
+    clen = np.array([s.numel() for s in w.chrom_seq])[res.item_chrom_index]
+    assert (res.item_ref_pos[lifted] >= 0).all() and ((res.item_ref_pos + ref_span)[lifted] <= clen[lifted]).all()
+    # (5) idempotence: the pipeline is a pure function of its inputs
+    res2 = devbatch.run_and_download(eng, db)
+    assert res2.canonical()[:2000] == res.canonical()[:2000] and (res2.item_ref_pos == res.item_ref_pos).all()
+    # (6) oracle parity on the first 3000 reads
+    b = w.batch_data(0, 3000)
+    ref = oracle.liftover_batch(w.index_data(), b, abi.STAGES_ALL, 8)
+    keep = res.item_seg < b.n_segs
+    sub = abi.BatchResult(**{f: (getattr(res, f)[keep] if f != "cigar" else res.cigar) for f in
+                             ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq", "item_chrom_index",
+                              "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")})
+    _assert_same(ref, sub, "chr20_sample")
+    eng.close()
+    eng_ix.close()
