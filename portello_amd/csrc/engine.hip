@@ -28,18 +28,18 @@ using namespace plo;
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
 
-__global__ void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt) {
+__global__ void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
-    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0);
+    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0, seg_reflen);
 }
 
 // thread per read segment: resolve the descriptors of its items (build_item_desc) at their scanned offsets
-__global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off) {
+__global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off, int *seg_reflen) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
     if (seg_off[s + 1] == seg_off[s]) return;
-    enumerate_segment(ix, bt, s, &wk, stages, seg_off[s]);
+    enumerate_segment(ix, bt, s, &wk, stages, seg_off[s], seg_reflen);
 }
 
 // explicit item list: thread per item
@@ -50,11 +50,33 @@ __global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stage
     build_item_desc(ix, bt, wk, stages, i, seg, in_cseg[i], segment_ref_len(bt, seg));
 }
 
+// class order: cls0[i] = 1 for items that skip the shift stage (scanned into rank0), then the permutation itself
+__global__ void k_class_flags(const uint32_t *item_cls, uint32_t n, uint32_t *cls0) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cls0[i] = item_cls[i] ? 0u : 1u;
+}
+__global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *rank0, uint32_t n, uint32_t *perm,
+                          uint32_t *nin_p) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t j = class_order_pos(i, item_cls[i], rank0[i], rank0[n]);
+    perm[j] = i;
+    nin_p[j] = item_nin[i];
+}
+
 // thread per tile: first item whose exclusive op prefix reaches the tile's window (tile_lo[n_tiles] = n_items)
 __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t *tile_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
     tile_lo[t] = prefix_lower_bound(op_prefix, n_items, (unsigned long long)t * (unsigned)window);
+}
+
+// maximum of a uint32 array (one atomic per wave); *out must be zeroed
+__global__ void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = in[i] > m ? in[i] : m;
+    int r = wv::reduce_max((int)(m & 0x7fffffffu));
+    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(out, (uint32_t)r);
 }
 
 // ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
@@ -256,7 +278,7 @@ struct plo_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
-    DevBuf seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
+    DevBuf misc, item_cls, cls0, rank0, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
@@ -445,7 +467,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->ix->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+    DevBuf *bufs[] = {&c->misc, &c->item_cls, &c->cls0, &c->rank0, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -537,7 +559,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     } else {
         HIP_TRY(c, c->seg_cnt.ensure((size_t)std::max(1u, ns) * 4));
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
-        if (ns) hipLaunchKernelGGL(k_seg_count, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>());
+        HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
+        if (ns)
+            hipLaunchKernelGGL(k_seg_count, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>(),
+                               c->seg_reflen.as<int>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
         uint32_t *h = c->h_counters.as<uint32_t>();
@@ -549,6 +574,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->item_seg.ensure(ni * 4));
     HIP_TRY(c, c->item_cseg.ensure(ni * 4));
     HIP_TRY(c, c->item_nin.ensure(ni * 4));
+    HIP_TRY(c, c->item_cls.ensure(ni * 4));
+    HIP_TRY(c, c->cls0.ensure(ni * 4));
+    HIP_TRY(c, c->rank0.ensure((ni + 1) * 4));
+    HIP_TRY(c, c->perm.ensure(ni * 4));
+    HIP_TRY(c, c->nin_p.ensure(ni * 4));
     HIP_TRY(c, c->op_prefix.ensure((size_t)(n_items + 1) * 4));
     HIP_TRY(c, c->d_in_off.ensure(ni * 4));
     HIP_TRY(c, c->d_n_in.ensure(ni * 4));
@@ -580,6 +610,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.item_seg = c->item_seg.as<uint32_t>();
     wk.item_cseg = c->item_cseg.as<uint32_t>();
     wk.item_nin = c->item_nin.as<uint32_t>();
+    wk.item_cls = c->item_cls.as<uint32_t>();
+    wk.perm = c->perm.as<uint32_t>();
     wk.item_op_prefix = c->op_prefix.as<uint32_t>();
     wk.d.in_off = c->d_in_off.as<uint32_t>();
     wk.d.n_in = c->d_n_in.as<uint32_t>();
@@ -611,19 +643,33 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                in->item_cseg);
         else
             hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages,
-                               (const uint32_t *)c->seg_off.as<uint32_t>());
+                               (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>());
         HIP_TRY(c, hipGetLastError());
     }
     {
-        plo_status s = scan_u32(c, c->item_nin.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
+        if (n_items) hipLaunchKernelGGL(k_class_flags, dim3((n_items + 255) / 256), dim3(256), 0, st,
+                                        (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>());
+        plo_status s = scan_u32(c, c->cls0.as<uint32_t>(), n_items, c->rank0.as<uint32_t>());
+        if (s != PLO_OK) return s;
+        if (n_items) hipLaunchKernelGGL(k_permute, dim3((n_items + 255) / 256), dim3(256), 0, st,
+                                        (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
+                                        (const uint32_t *)c->rank0.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>());
+        s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
     }
-    uint32_t total_ops = 0;
+    uint32_t total_ops = 0, max_nin = 0;
     {
+        HIP_TRY(c, c->misc.ensure(64));
+        HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 64, st));
+        if (n_items)
+            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 1024u)), dim3(256), 0, st,
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>());
         uint32_t *h = c->h_counters.as<uint32_t>();
         HIP_TRY(c, hipMemcpyAsync(h, c->op_prefix.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 1, c->misc.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         total_ops = h[0];
+        max_nin = h[1];
     }
     const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
     HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
@@ -663,10 +709,14 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         n_big = (uint32_t)hc[CNT_NBIG];
         if (n_big) {
             // size the wave-private scratch from the largest possible intermediate of a single item
-            int big_cap = 1 << 16;
+            // (pieces <= ops + blocks, raw ops <= 2 x pieces); an item that still overflows is reported (CNT_ERROR)
+            int big_cap = 4096;
+            while (big_cap < (1 << 22) && (unsigned long long)big_cap < 6ull * max_nin + 2048ull) big_cap <<= 1;
             if (const char *e = getenv("PLO_BIG_CAP")) big_cap = std::max(1024, atoi(e));
             unsigned long long bpw = (tile_mem_bytes(big_cap) + 255) & ~(unsigned long long)255;
-            uint32_t nw = std::min<uint32_t>(n_big, 1024u);
+            // as many waves as the chip keeps resident (register-limited: 3 per SIMD), bounded by a 4 GiB scratch
+            uint32_t nw = std::min<uint32_t>(n_big, (uint32_t)c->n_cus * 12u);
+            nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
             HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
             hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_big, c->scratch.as<unsigned char>(),
                                big_cap, bpw);

@@ -70,6 +70,7 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
     wk.item_nin[i] = n_in;
+    wk.item_cls[i] = ((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u;
     wk.d.in_off[i] = in_off;
     wk.d.n_in[i] = n_in;
     wk.d.pos1[i] = (int)pos1;
@@ -93,13 +94,20 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
 }
 
 // Counts (and, when wk != nullptr, resolves at out_off) the items of one read segment, in contig-segment order.
+// `ref_len_cache`: per-segment reference spans; written by the counting pass (wk == nullptr), read by the emit pass.
 PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint32_t seg, const DevWork *wk, uint32_t stages,
-                                   uint32_t out_off) {
+                                   uint32_t out_off, int *ref_len_cache = nullptr) {
     uint32_t contig = bt.seg_contig[seg];
     if (contig >= ix.n_contigs) return 0;
     uint32_t g0 = ix.contig_seg_off[contig], g1 = ix.contig_seg_off[contig + 1];
     if (g0 == g1) return 0;  // contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
-    long long ref_len = segment_ref_len(bt, seg);
+    long long ref_len;
+    if (wk && ref_len_cache) {
+        ref_len = ref_len_cache[seg];
+    } else {
+        ref_len = segment_ref_len(bt, seg);
+        if (ref_len_cache) ref_len_cache[seg] = (int)ref_len;
+    }
     long long r_start = (long long)bt.seg_pos[seg];
     long long r_end = r_start + ref_len;
     uint32_t n = 0;
@@ -112,6 +120,9 @@ PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint3
     }
     return n;
 }
+
+// position of item i in class order, given the exclusive count rank0 of class-0 items before it and their total n0
+PLO_DEV uint32_t class_order_pos(uint32_t i, uint32_t cls, uint32_t rank0, uint32_t n0) { return cls ? n0 + (i - rank0) : rank0; }
 
 // first i in [0,n) with a[i] >= x
 PLO_DEV uint32_t prefix_lower_bound(const uint32_t *a, uint32_t n, unsigned long long x) {

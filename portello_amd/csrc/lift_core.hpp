@@ -364,7 +364,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 #define PLO_T(k)
 #endif
     bool has = lane < nit;
-    const uint32_t g = big_path ? (has ? wk.big_list[item_begin + (uint32_t)lane] : 0u) : item_begin + (uint32_t)lane;
+    const uint32_t g = has ? (big_path ? wk.big_list[item_begin + (uint32_t)lane] : wk.perm[item_begin + (uint32_t)lane]) : 0u;
 
     // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
     int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;

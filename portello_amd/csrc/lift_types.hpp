@@ -75,9 +75,13 @@ struct DevWork {
     uint32_t n_items;
     uint32_t *item_seg;
     uint32_t *item_cseg;
-    uint32_t *item_nin;              // input op count per item (scanned into item_op_prefix)
-    const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix of the items' input op counts
-    const uint32_t *tile_lo;         // [n_tiles+1] first item of every tile (window of the flattened op stream)
+    uint32_t *item_nin;              // input op count per item
+    uint32_t *item_cls;              // 1 = the item goes through the left-shift stage (reverse-mapped contig segment)
+    // Tiles are cut from the items in *class order* (all class-0 items in input order, then all class-1 items), so that
+    // a tile is strand-homogeneous and forward tiles skip the shift stage altogether; outputs keep the input order.
+    const uint32_t *perm;            // [n_items] class order -> item index
+    const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix of the input op counts in class order
+    const uint32_t *tile_lo;         // [n_tiles+1] first class-order position of every tile (window of the op stream)
     ItemDesc d;
     uint8_t *status;
     uint8_t *flip;

@@ -83,7 +83,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     o->pos.assign(a, 0);
     o->cig_off.assign(a, 0);
     o->cig_len.assign(a, 0);
-    std::vector<uint32_t> item_nin(a, 0), d_in_off(a), d_n_in(a), d_w0(a), d_w1(a), d_kv0(a), d_kv1(a), d_flags(a), d_contig(a),
+    std::vector<uint32_t> item_cls(a, 0), item_nin(a, 0), d_in_off(a), d_n_in(a), d_w0(a), d_w1(a), d_kv0(a), d_kv1(a), d_flags(a), d_contig(a),
         d_seq_len(a), big_list(a, 0);
     std::vector<int> d_pos1(a);
     std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
@@ -97,6 +97,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.item_seg = o->item_seg.data();
     wk.item_cseg = o->item_cseg.data();
     wk.item_nin = item_nin.data();
+    wk.item_cls = item_cls.data();
     wk.d.in_off = d_in_off.data();
     wk.d.n_in = d_n_in.data();
     wk.d.pos1 = d_pos1.data();
@@ -131,8 +132,17 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             off += seg_cnt[s];
         }
     }
+    // class order (k_class_flags + scan + k_permute on the GPU)
+    std::vector<uint32_t> rank0(n_items + 1, 0), perm(a, 0), nin_p(a, 0);
+    for (uint32_t i = 0; i < n_items; ++i) rank0[i + 1] = rank0[i] + (item_cls[i] ? 0u : 1u);
+    for (uint32_t i = 0; i < n_items; ++i) {
+        uint32_t j = class_order_pos(i, item_cls[i], rank0[i], rank0[n_items]);
+        perm[j] = i;
+        nin_p[j] = item_nin[i];
+    }
+    wk.perm = perm.data();
     std::vector<uint32_t> prefix(n_items + 1, 0);
-    for (uint32_t i = 0; i < n_items; ++i) prefix[i + 1] = prefix[i] + item_nin[i];
+    for (uint32_t i = 0; i < n_items; ++i) prefix[i + 1] = prefix[i] + nin_p[i];
     uint64_t total_ops = prefix[n_items];
     wk.item_op_prefix = prefix.data();
     uint32_t n_tiles = (uint32_t)(total_ops / (uint64_t)window) + 1;
