@@ -206,3 +206,22 @@ def test_full_size_properties_chr20(oracle):
     _assert_same(ref, sub, "chr20_sample")
     eng.close()
     eng_ix.close()
+
+
+def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
+    """bench.py's N > 1 path wraps the engine's device outputs as torch tensors (no copy) before the RCCL gather"""
+    import torch
+
+    from portello_amd import devbatch, gather
+
+    w = synth.generate(synth.config("tiny", n_reads=300, seed=206), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    out = eng.liftover_batch_dev(devbatch.DeviceBatch.from_workload(w).desc())
+    eng.sync()
+    t = gather.tensors_from_out(out, torch.device("cuda", 0))
+    via_views = gather.to_result(gather.unpack(gather.pack(t), int(out.n_items), int(out.n_cigar)))
+    _assert_same(devbatch.download(eng, out), via_views, "views")
+    _assert_same(oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, 2), via_views, "views_vs_oracle")
+    eng.close()
+    eng_ix.close()
