@@ -130,7 +130,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    lift_ms, enum_ms, big_ms = [], [], []
+    lift_ms, enum_ms, big_ms, lanes_ms, retry_ms = [], [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -138,6 +138,8 @@ def main():
         lift_ms.append(tm.lift_ms)
         enum_ms.append(tm.enumerate_ms)
         big_ms.append(tm.big_ms)
+        lanes_ms.append(tm.lanes_ms)
+        retry_ms.append(tm.retry_ms)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -153,11 +155,13 @@ def main():
         total_reads = float(w.n_reads)
 
     tm = eng.timing()
-    dominant = "k_lift_tiles" if sum(lift_ms) >= sum(big_ms) else "k_lift_big"
-    dom_ms = float(np.mean(lift_ms if dominant == "k_lift_tiles" else big_ms))
-    # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over both lift kernels;
+    kms = {"k_lift_lanes": float(np.mean(lanes_ms)), "k_lift_tiles": float(np.mean(lift_ms)), "k_lift_big": float(np.mean(big_ms)),
+           "k_lift_retry": float(np.mean(retry_ms))}
+    dominant = max(kms, key=kms.get)
+    dom_ms = kms[dominant]
+    # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
     # attribute them to the dominant kernel in proportion to its share of the lift time
-    share = dom_ms / max(1e-9, float(np.mean(lift_ms)) + float(np.mean(big_ms)))
+    share = dom_ms / max(1e-9, sum(kms.values()))
     achieved = (tm.algo_bytes * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -183,13 +187,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
                    "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
-                   "large_items_per_gpu": int(tm.n_big_items), "seq_fmt": "bam4", "parallelism": f"shard{world}",
+                   "large_items_per_gpu": int(tm.n_big_items), "lane_items_per_gpu": int(tm.n_lane_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}",
                    "gather": "rccl send/recv to rank 0" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
                      "enumerate_ms": float(np.mean(enum_ms)), "lift_tiles_ms": float(np.mean(lift_ms)),
-                     "lift_big_ms": float(np.mean(big_ms))},
+                     "lift_big_ms": float(np.mean(big_ms)), "lift_lanes_ms": float(np.mean(lanes_ms)),
+                     "lift_retry_ms": float(np.mean(retry_ms))},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -180,13 +180,17 @@ typedef struct plo_batch_out {
 typedef struct plo_timing {
     float total_ms;      /* first kernel start -> last kernel end                                   */
     float enumerate_ms;  /* item enumeration + scans                                                */
-    float lift_ms;       /* the fused strand/shift/liftover/simplify tile kernel (dominant kernel)   */
+    float lift_ms;       /* the wave-cooperative tile kernel (longer CIGARs)                         */
     float big_ms;        /* large-item kernel (0 if not launched)                                   */
     uint32_t n_items;
     uint32_t n_big_items;
     uint64_t n_in_ops;   /* input CIGAR ops over all items                                          */
     uint64_t n_out_ops;  /* output CIGAR ops                                                        */
     uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device */
+    float lanes_ms;      /* lane-per-item kernel (short CIGARs)                                      */
+    float retry_ms;      /* items re-run by the tile code after overflowing the lane kernel          */
+    uint32_t n_lane_items;
+    uint32_t n_retry_items;
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

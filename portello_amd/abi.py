@@ -117,6 +117,10 @@ class PloTiming(C.Structure):
         ("n_in_ops", C.c_uint64),
         ("n_out_ops", C.c_uint64),
         ("algo_bytes", C.c_uint64),
+        ("lanes_ms", C.c_float),
+        ("retry_ms", C.c_float),
+        ("n_lane_items", C.c_uint32),
+        ("n_retry_items", C.c_uint32),
     ]
 
 

@@ -20,6 +20,7 @@
 
 #include "enumerate.hpp"
 #include "index_pack.hpp"
+#include "lane_core.hpp"
 #include "lift_core.hpp"
 
 using namespace plo;
@@ -50,33 +51,51 @@ __global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stage
     build_item_desc(ix, bt, wk, stages, i, seg, in_cseg[i], segment_ref_len(bt, seg));
 }
 
-// class order: cls0[i] = 1 for items that skip the shift stage (scanned into rank0), then the permutation itself
-__global__ void k_class_flags(const uint32_t *item_cls, uint32_t n, uint32_t *cls0) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cls0[i] = item_cls[i] ? 0u : 1u;
-}
-__global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *rank0, uint32_t n, uint32_t *perm,
-                          uint32_t *nin_p) {
+// class order (lift_types.hpp DevWork): flags of classes 0,1,2 (scanned into ranks), then the permutation itself
+__global__ void k_class_flags(const uint32_t *item_cls, uint32_t n, uint32_t *f0, uint32_t *f1, uint32_t *f2) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t j = class_order_pos(i, item_cls[i], rank0[i], rank0[n]);
+    uint32_t c = item_cls[i];
+    f0[i] = c == 0;
+    f1[i] = c == 1;
+    f2[i] = c == 2;
+}
+__global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *r0, const uint32_t *r1,
+                          const uint32_t *r2, uint32_t n, uint32_t *perm, uint32_t *nin_p) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = item_cls[i];
+    uint32_t j = class_order_pos(i, c, r0[i], r1[i], r2[i], r0[n], r1[n], r2[n]);
     perm[j] = i;
-    nin_p[j] = item_nin[i];
+    nin_p[j] = c >= 2 ? item_nin[i] : 0u;  // only the large items are tiled
 }
 
-// thread per tile: first item whose exclusive op prefix reaches the tile's window (tile_lo[n_tiles] = n_items)
-__global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t *tile_lo) {
+// thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
+__global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, const uint32_t *r0,
+                              const uint32_t *r1, uint32_t *tile_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    tile_lo[t] = prefix_lower_bound(op_prefix, n_items, (unsigned long long)t * (unsigned)window);
+    uint32_t n_small = r0[n_items] + r1[n_items];
+    uint32_t lo = prefix_lower_bound(op_prefix, n_items, (unsigned long long)t * (unsigned)window);
+    tile_lo[t] = lo > n_small ? lo : n_small;
 }
 
-// maximum of a uint32 array (one atomic per wave); *out must be zeroed
+// maximum (out[0]) and 64-bit sum (out[2..3]) of a uint32 array, one atomic pair per wave; out must be zeroed
 __global__ void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out) {
     uint32_t m = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = in[i] > m ? in[i] : m;
+    unsigned long long sum = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t v = in[i];
+        m = v > m ? v : m;
+        sum += v;
+    }
     int r = wv::reduce_max((int)(m & 0x7fffffffu));
-    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(out, (uint32_t)r);
+    unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(sum & 0xffffffull));
+    unsigned hi = (unsigned)wv::reduce_add((int)(unsigned)(sum >> 24));
+    if ((threadIdx.x & 63) == 0) {
+        if (r > 0) atomicMax(out, (uint32_t)r);
+        atomicAdd((unsigned long long *)(out + 2), (unsigned long long)lo + ((unsigned long long)hi << 24));
+    }
 }
 
 // ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
@@ -164,12 +183,48 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void k_lift_tiles(DevIndex ix, Dev
     wave_ctx_flush(wk, ctx);
 }
 
+// Short-CIGAR fast path: one lane per item, 64 items per wave (lane_core.hpp); persistent waves over groups of 64.
+constexpr int LANE_WAVES = 2;
+__global__ __launch_bounds__(LANE_WAVES * 64) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+                                                               uint32_t lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6;
+    uint32_t nb = gridDim.x, per = nb >> 3, b = blockIdx.x;
+    uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
+    const uint32_t wave = tb * LANE_WAVES + (uint32_t)w, n_waves = nb * LANE_WAVES;
+    const uint32_t n_groups = (wk.n_small + 63u) / 64u;
+    LaneMem m = carve_lane_mem(smem + (size_t)w * lds_per_wave);
+    WaveCtx ctx;
+    for (uint32_t gi = wave; gi < n_groups; gi += n_waves) {
+        uint32_t b0 = gi * 64u;
+        uint32_t left = wk.n_small - b0;
+        lift_lanes(ix, bt, wk, stages, b0, (int)(left < 64u ? left : 64u), m, ctx);
+        wv::sync();
+    }
+    wave_ctx_flush(wk, ctx);
+}
+
+// Items of the lane kernel whose intermediates overflowed its per-lane capacity: the tile code, RETRY_PER items per wave
+constexpr uint32_t RETRY_PER = 6;
+__global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_retry,
+                                                   int big_thresh, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileMem m = carve_tile_mem(smem, cap);
+    WaveCtx ctx;
+    for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
+        uint32_t left = n_retry - r;
+        lift_tile(ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, false, big_thresh, ctx);
+        wv::sync();
+    }
+    wave_ctx_flush(wk, ctx);
+}
+
 __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
                                                  unsigned char *scratch, int big_cap, unsigned long long bytes_per_wave) {
     TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
     WaveCtx ctx;
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0, ctx);
+        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, true, 0, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx);
@@ -278,7 +333,7 @@ struct plo_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
-    DevBuf misc, item_cls, cls0, rank0, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
+    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
@@ -287,7 +342,7 @@ struct plo_ctx {
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
     HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_big = false;
     plo_timing timing{};
     unsigned long long phase_cycles[12] = {0};
@@ -295,6 +350,10 @@ struct plo_ctx {
     int window = 160, big_thresh = 176, cap = 512;
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
+    // routing threshold of the lane-per-item kernel (k_lift_lanes).  Measured on MI355X (wgs30x): forward items run 1.6x
+    // faster there than in the tile kernel, reverse items 0.8x (per-lane homology probes serialise HBM latency), the mix
+    // is a net loss -> off by default (-1); PLO_LANE_MAX_IN=40 enables it.
+    int lane_max_in = -1;
 };
 
 #define HIP_TRY(ctx, call)                                                                      \
@@ -437,7 +496,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
         }
         c->own_stream = true;
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) {
             delete c;
             return PLO_ERR_HIP;
@@ -455,6 +514,9 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
             fprintf(stderr, "[plo] cap %d: dynamic LDS %zu B/block -> %d blocks/CU (%s)\n", cap, lds, nb, hipGetErrorString(e));
         }
     }
+    if (const char *e = getenv("PLO_LANE_MAX_IN")) c->lane_max_in = std::min(atoi(e), LANE_CAP);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_retry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e));
     if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e));
@@ -467,7 +529,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->ix->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->misc, &c->item_cls, &c->cls0, &c->rank0, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+    DevBuf *bufs[] = {&c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -478,7 +540,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     HostBuf *hb[] = {&c->h_item_seg, &c->h_item_cseg, &c->h_status, &c->h_flip, &c->h_mapq, &c->h_chrom, &c->h_pos,
                      &c->h_coff, &c->h_clen, &c->h_cigar, &c->h_counters};
     for (HostBuf *b : hb) b->release();
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -576,7 +638,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->item_nin.ensure(ni * 4));
     HIP_TRY(c, c->item_cls.ensure(ni * 4));
     HIP_TRY(c, c->cls0.ensure(ni * 4));
+    HIP_TRY(c, c->cls1.ensure(ni * 4));
+    HIP_TRY(c, c->cls2.ensure(ni * 4));
     HIP_TRY(c, c->rank0.ensure((ni + 1) * 4));
+    HIP_TRY(c, c->rank1.ensure((ni + 1) * 4));
+    HIP_TRY(c, c->rank2.ensure((ni + 1) * 4));
+    HIP_TRY(c, c->retry_list.ensure(ni * 4));
     HIP_TRY(c, c->perm.ensure(ni * 4));
     HIP_TRY(c, c->nin_p.ensure(ni * 4));
     HIP_TRY(c, c->op_prefix.ensure((size_t)(n_items + 1) * 4));
@@ -612,6 +679,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.item_nin = c->item_nin.as<uint32_t>();
     wk.item_cls = c->item_cls.as<uint32_t>();
     wk.perm = c->perm.as<uint32_t>();
+    wk.retry_list = c->retry_list.as<uint32_t>();
+    wk.lane_max_in = c->lane_max_in;
     wk.item_op_prefix = c->op_prefix.as<uint32_t>();
     wk.d.in_off = c->d_in_off.as<uint32_t>();
     wk.d.n_in = c->d_n_in.as<uint32_t>();
@@ -648,16 +717,23 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     }
     {
         if (n_items) hipLaunchKernelGGL(k_class_flags, dim3((n_items + 255) / 256), dim3(256), 0, st,
-                                        (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>());
+                                        (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>(),
+                                        c->cls1.as<uint32_t>(), c->cls2.as<uint32_t>());
         plo_status s = scan_u32(c, c->cls0.as<uint32_t>(), n_items, c->rank0.as<uint32_t>());
+        if (s != PLO_OK) return s;
+        s = scan_u32(c, c->cls1.as<uint32_t>(), n_items, c->rank1.as<uint32_t>());
+        if (s != PLO_OK) return s;
+        s = scan_u32(c, c->cls2.as<uint32_t>(), n_items, c->rank2.as<uint32_t>());
         if (s != PLO_OK) return s;
         if (n_items) hipLaunchKernelGGL(k_permute, dim3((n_items + 255) / 256), dim3(256), 0, st,
                                         (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
-                                        (const uint32_t *)c->rank0.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>());
+                                        (const uint32_t *)c->rank0.as<uint32_t>(), (const uint32_t *)c->rank1.as<uint32_t>(),
+                                        (const uint32_t *)c->rank2.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>());
         s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
     }
-    uint32_t total_ops = 0, max_nin = 0;
+    uint32_t total_ops = 0, max_nin = 0, n_small = 0;
+    unsigned long long all_ops = 0;
     {
         HIP_TRY(c, c->misc.ensure(64));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 64, st));
@@ -667,28 +743,49 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         uint32_t *h = c->h_counters.as<uint32_t>();
         HIP_TRY(c, hipMemcpyAsync(h, c->op_prefix.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(h + 1, c->misc.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 4, c->misc.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 2, c->rank0.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 3, c->rank1.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        total_ops = h[0];
+        total_ops = h[0];  // ops of the large (tiled) items
         max_nin = h[1];
+        n_small = n_items ? h[2] + h[3] : 0;
+        all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
     }
     const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
     HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
     hipLaunchKernelGGL(k_tile_bounds, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->op_prefix.as<uint32_t>(),
-                       n_items, n_tiles, c->window, c->tile_lo.as<uint32_t>());
+                       n_items, n_tiles, c->window, (const uint32_t *)c->rank0.as<uint32_t>(), (const uint32_t *)c->rank1.as<uint32_t>(),
+                       c->tile_lo.as<uint32_t>());
     wk.tile_lo = c->tile_lo.as<uint32_t>();
+    wk.n_small = n_small;
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
-    size_t want_cigar = (size_t)total_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS;
+    size_t want_cigar = (size_t)all_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS;
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
-    uint32_t n_big = 0;
+    uint32_t n_big = 0, n_retry = 0;
     for (int attempt = 0;; ++attempt) {
         wk.out_cigar = c->o_cigar.as<uint32_t>();
         wk.out_cap = c->o_cigar.cap / 4;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
         if (attempt == 0) HIP_TRY(c, hipEventRecord(c->ev[1], st));
-        if (n_items) {
+        if (n_small) {
+            uint32_t lpw = (uint32_t)((lane_mem_bytes() + 15) & ~(size_t)15);
+            uint32_t groups = (n_small + 63u) / 64u;
+            uint32_t nblk = (groups + LANE_WAVES - 1) / LANE_WAVES;
+            int occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_lanes, LANE_WAVES * 64,
+                                                             (size_t)lpw * LANE_WAVES) != hipSuccess || occ < 1)
+                occ = 1;
+            nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
+            nblk = (nblk + 7u) & ~7u;
+            hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lpw * LANE_WAVES, st, ix, bt, wk, stages, lpw);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(c->ev[4], st));
+        if (n_items > n_small) {
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
             const uint32_t tw = (uint32_t)c->tile_waves;
             uint32_t nblk = (n_tiles + tw - 1) / tw;
@@ -706,6 +803,16 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipEventRecord(c->ev[2], st));
         HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        n_retry = (uint32_t)hc[CNT_NRETRY];
+        if (n_retry) {
+            uint32_t lds = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
+            uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 8u);
+            hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, c->cap);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev[5], st));
         n_big = (uint32_t)hc[CNT_NBIG];
         if (n_big) {
             // size the wave-private scratch from the largest possible intermediate of a single item
@@ -739,6 +846,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     }
     c->timing.n_items = n_items;
     c->timing.n_big_items = n_big;
+    c->timing.n_lane_items = n_small;
+    c->timing.n_retry_items = n_retry;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
     c->timing.n_out_ops = hc[CNT_OUT_OPS];
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
@@ -762,14 +871,18 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
 plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     if (!c || !t) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float a = 0, b = 0, g = 0;
+    float a = 0, l = 0, b = 0, r = 0, g = 0;
     (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-    if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&l, c->ev[1], c->ev[4]);
+    (void)hipEventElapsedTime(&b, c->ev[4], c->ev[2]);
+    (void)hipEventElapsedTime(&r, c->ev[2], c->ev[5]);
+    if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev[5], c->ev[3]);
     c->timing.enumerate_ms = a;
+    c->timing.lanes_ms = l;
     c->timing.lift_ms = b;
+    c->timing.retry_ms = r;
     c->timing.big_ms = g;
-    c->timing.total_ms = a + b + g;
+    c->timing.total_ms = a + l + b + r + g;
     *t = c->timing;
     return PLO_OK;
 }

@@ -70,7 +70,8 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
     wk.item_nin[i] = n_in;
-    wk.item_cls[i] = ((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u;
+    wk.item_cls[i] = (((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u) |
+                     ((wk.lane_max_in < 0 || n_in > (uint32_t)wk.lane_max_in) ? 2u : 0u);
     wk.d.in_off[i] = in_off;
     wk.d.n_in[i] = n_in;
     wk.d.pos1[i] = (int)pos1;
@@ -121,8 +122,17 @@ PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint3
     return n;
 }
 
-// position of item i in class order, given the exclusive count rank0 of class-0 items before it and their total n0
-PLO_DEV uint32_t class_order_pos(uint32_t i, uint32_t cls, uint32_t rank0, uint32_t n0) { return cls ? n0 + (i - rank0) : rank0; }
+// position of item i in class order, given the exclusive counts r0,r1,r2 of class-0/1/2 items before it and the class
+// totals n0,n1,n2
+PLO_DEV uint32_t class_order_pos(uint32_t i, uint32_t cls, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t n0, uint32_t n1,
+                                 uint32_t n2) {
+    switch (cls) {
+        case 0: return r0;
+        case 1: return n0 + r1;
+        case 2: return n0 + n1 + r2;
+        default: return n0 + n1 + n2 + (i - r0 - r1 - r2);
+    }
+}
 
 // first i in [0,n) with a[i] >= x
 PLO_DEV uint32_t prefix_lower_bound(const uint32_t *a, uint32_t n, unsigned long long x) {

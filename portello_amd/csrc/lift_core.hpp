@@ -349,7 +349,7 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx) {
 // The tile pipeline
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
-                       int nit, TileMem m, bool big_path, int big_thresh, WaveCtx &ctx) {
+                       int nit, TileMem m, const uint32_t *list, bool last_resort, int big_thresh, WaveCtx &ctx) {
     const int lane = wv::lane();
 #ifdef PLO_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -364,7 +364,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 #define PLO_T(k)
 #endif
     bool has = lane < nit;
-    const uint32_t g = has ? (big_path ? wk.big_list[item_begin + (uint32_t)lane] : wk.perm[item_begin + (uint32_t)lane]) : 0u;
+    // `list` maps positions to item indices: the class-order permutation (tiles), the retry list, or the large-item list
+    const uint32_t g = has ? list[item_begin + (uint32_t)lane] : 0u;
 
     // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
     int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;
@@ -393,7 +394,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
     // items too long for a shared tile go to the large-item kernel (one item per wave, global scratch)
     {
-        bool defer = has && !big_path && n_in > big_thresh;
+        bool defer = has && !last_resort && n_in > big_thresh;
         unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int nd = __builtin_popcountll(dm);
@@ -1072,7 +1073,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // ---- OUTPUT --------------------------------------------------------------------------------------------------------------
     overflow = wv::ballot(overflow) != 0ull;
     if (overflow) {
-        if (big_path) {
+        if (last_resort) {
             if (has) {
                 wk.status[g] = PLO_ITEM_PANIC;
                 wk.cig_len[g] = 0;
@@ -1149,7 +1150,7 @@ PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &
     uint32_t lo = wk.tile_lo[tile], hi = wk.tile_lo[tile + 1];  // written by k_tile_bounds
     for (uint32_t b = lo; b < hi; b += 64) {
         int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-        lift_tile(ix, bt, wk, stages, b, nit, m, false, big_thresh, ctx);
+        lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, false, big_thresh, ctx);
         wv::sync();
     }
 }

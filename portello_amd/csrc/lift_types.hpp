@@ -49,7 +49,7 @@ struct DevBatch {
     uint32_t n_reads, n_segs;
 };
 
-enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_PHASE0 = 8, CNT_N = 24 };
+enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_N = 24 };
 
 // Resolved per-item descriptors, written once per batch by the item kernels (thread per item, full occupancy) so that
 // the tile kernel starts from ONE level of coalesced loads instead of chasing item -> segment -> contig -> block map.
@@ -76,12 +76,17 @@ struct DevWork {
     uint32_t *item_seg;
     uint32_t *item_cseg;
     uint32_t *item_nin;              // input op count per item
-    uint32_t *item_cls;              // 1 = the item goes through the left-shift stage (reverse-mapped contig segment)
-    // Tiles are cut from the items in *class order* (all class-0 items in input order, then all class-1 items), so that
-    // a tile is strand-homogeneous and forward tiles skip the shift stage altogether; outputs keep the input order.
+    uint32_t *item_cls;              // bit0: the item goes through the left-shift stage (reverse-mapped contig segment),
+                                     // bit1: too many ops for the lane-per-item path
+    // Work is cut from the items in *class order* (class 0, 1, 2, 3, each in input order): the first n_small positions
+    // (classes 0-1) go to the lane-per-item kernel in groups of 64, the rest to the tile kernel; groups and tiles are
+    // strand-homogeneous so that forward ones skip the shift stage altogether.  Outputs keep the input order.
     const uint32_t *perm;            // [n_items] class order -> item index
-    const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix of the input op counts in class order
-    const uint32_t *tile_lo;         // [n_tiles+1] first class-order position of every tile (window of the op stream)
+    uint32_t n_small;                // positions [0, n_small) of perm: lane-per-item kernel
+    int lane_max_in;                 // largest input op count routed to the lane-per-item kernel
+    const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix, in class order, of the op counts of the large items
+    const uint32_t *tile_lo;         // [n_tiles+1] first class-order position (>= n_small) of every tile
+    uint32_t *retry_list;            // items of the lane kernel whose intermediates overflowed: re-run by the tile code
     ItemDesc d;
     uint8_t *status;
     uint8_t *flip;

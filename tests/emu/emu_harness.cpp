@@ -7,6 +7,7 @@
 
 #include "../../portello_amd/csrc/enumerate.hpp"
 #include "../../portello_amd/csrc/index_pack.hpp"
+#include "../../portello_amd/csrc/lane_core.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
 
 using namespace plo;
@@ -21,7 +22,7 @@ struct Out {
 }  // namespace
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
-                                  int big_thresh, int big_cap, unsigned order_seed, plo_batch_out *out,
+                                  int big_thresh, int big_cap, unsigned order_seed, int lane_max_in, plo_batch_out *out,
                                   unsigned long long *counters_out) {
     PackedIndex pk;
     std::string err;
@@ -94,6 +95,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     DevWork wk;
     memset(&wk, 0, sizeof(wk));
     wk.n_items = n_items;
+    wk.lane_max_in = lane_max_in;
     wk.item_seg = o->item_seg.data();
     wk.item_cseg = o->item_cseg.data();
     wk.item_nin = item_nin.data();
@@ -132,24 +134,34 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             off += seg_cnt[s];
         }
     }
-    // class order (k_class_flags + scan + k_permute on the GPU)
-    std::vector<uint32_t> rank0(n_items + 1, 0), perm(a, 0), nin_p(a, 0);
-    for (uint32_t i = 0; i < n_items; ++i) rank0[i + 1] = rank0[i] + (item_cls[i] ? 0u : 1u);
+    // class order (k_class_flags + scans + k_permute on the GPU)
+    std::vector<uint32_t> r0(n_items + 1, 0), r1(n_items + 1, 0), r2(n_items + 1, 0), perm(a, 0), nin_p(a, 0), retry_list(a, 0);
     for (uint32_t i = 0; i < n_items; ++i) {
-        uint32_t j = class_order_pos(i, item_cls[i], rank0[i], rank0[n_items]);
-        perm[j] = i;
-        nin_p[j] = item_nin[i];
+        r0[i + 1] = r0[i] + (item_cls[i] == 0);
+        r1[i + 1] = r1[i] + (item_cls[i] == 1);
+        r2[i + 1] = r2[i] + (item_cls[i] == 2);
     }
+    for (uint32_t i = 0; i < n_items; ++i) {
+        uint32_t j = class_order_pos(i, item_cls[i], r0[i], r1[i], r2[i], r0[n_items], r1[n_items], r2[n_items]);
+        perm[j] = i;
+        nin_p[j] = item_cls[i] >= 2 ? item_nin[i] : 0;  // only the large items are tiled
+    }
+    const uint32_t n_small = r0[n_items] + r1[n_items], n_large = n_items - n_small;
     wk.perm = perm.data();
+    wk.n_small = n_small;
+    wk.retry_list = retry_list.data();
     std::vector<uint32_t> prefix(n_items + 1, 0);
+    uint64_t all_ops = 0;
+    for (uint32_t i = 0; i < n_items; ++i) all_ops += item_nin[i];
     for (uint32_t i = 0; i < n_items; ++i) prefix[i + 1] = prefix[i] + nin_p[i];
     uint64_t total_ops = prefix[n_items];
     wk.item_op_prefix = prefix.data();
     uint32_t n_tiles = (uint32_t)(total_ops / (uint64_t)window) + 1;
     std::vector<uint32_t> tile_lo(n_tiles + 1);
     for (uint32_t t = 0; t <= n_tiles; ++t)
-        tile_lo[t] = prefix_lower_bound(prefix.data(), n_items, (unsigned long long)t * (unsigned)window);  // k_tile_bounds
+        tile_lo[t] = std::max(n_small, prefix_lower_bound(prefix.data(), n_items, (unsigned long long)t * (unsigned)window));  // k_tile_bounds
     wk.tile_lo = tile_lo.data();
+    total_ops = all_ops;
 
     uint64_t out_cap = 4 * total_ops + 64ull * n_items + 1024 + 8 * SLAB_OPS;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -158,8 +170,39 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         wk.out_cigar = o->cigar.data();
         wk.out_cap = out_cap;
         std::vector<unsigned char> lds(tile_mem_bytes(cap) + 64);
+        {   // lane-per-item kernel: groups of 64 class-order positions, persistent waves
+            std::vector<unsigned char> llds(lane_mem_bytes() + 64);
+            const uint32_t n_groups = (n_small + 63) / 64, n_lw = 2;
+            for (uint32_t wv_id = 0; wv_id < n_lw && n_groups; ++wv_id) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 333 + wv_id : 0;
+                LaneMem lm = carve_lane_mem(llds.data());
+                w.run([&]() {
+                    WaveCtx ctx;
+                    for (uint32_t gidx = wv_id; gidx < n_groups; gidx += n_lw) {
+                        uint32_t b0 = gidx * 64;
+                        lift_lanes(ix, bt, wk, stages, b0, (int)std::min<uint32_t>(64u, n_small - b0), lm, ctx);
+                        wv::sync();
+                    }
+                    wave_ctx_flush(wk, ctx);
+                });
+            }
+            // retry list -> tile code, a few items per wave
+            uint32_t n_retry = (uint32_t)counters[CNT_NRETRY];
+            const uint32_t per = 6;
+            for (uint32_t r = 0; r < n_retry; r += per) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 555 + r : 0;
+                TileMem m = carve_tile_mem(lds.data(), cap);
+                w.run([&]() {
+                    WaveCtx ctx;
+                    lift_tile(ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, false, big_thresh, ctx);
+                    wave_ctx_flush(wk, ctx);
+                });
+            }
+        }
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
-        for (uint32_t wv_id = 0; wv_id < n_waves && n_items; ++wv_id) {
+        for (uint32_t wv_id = 0; wv_id < n_waves && n_large; ++wv_id) {
             wv::EmuWave w;
             w.order_seed = order_seed ? order_seed + wv_id : 0;
             TileMem m = carve_tile_mem(lds.data(), cap);
@@ -180,7 +223,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.run([&]() {
                     WaveCtx ctx;
                     for (uint32_t i = wv_id; i < n_big; i += n_bw) {
-                        lift_tile(ix, bt, wk, stages, i, 1, m, true, 0, ctx);
+                        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, true, 0, ctx);
                         wv::sync();
                     }
                     wave_ctx_flush(wk, ctx);

@@ -225,3 +225,28 @@ def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
     _assert_same(oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, 2), via_views, "views_vs_oracle")
     eng.close()
     eng_ix.close()
+
+
+def test_lane_per_item_kernel_when_enabled(oracle, monkeypatch):
+    """the short-CIGAR lane-per-item kernel (off by default) + its overflow retry path"""
+    monkeypatch.setenv("PLO_LANE_MAX_IN", "64")
+    w = synth.generate(synth.config("tiny", n_reads=500, seed=207, split_read_frac=0.1, read_len_mean=25000))
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    got = eng.liftover_batch(b)
+    t = eng.timing()
+    assert t.n_lane_items > 0
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "lanes")
+    eng.close()
+    eng_ix.close()
+    for seed in range(5):
+        import fuzz_cases
+
+        fix, fb = fuzz_cases.make(3000 + seed, n_reads=150, alphabet=b"AC")
+        fi = api.Index(fix)
+        fe = api.Engine(fi)
+        for stages in (31, 7, 18):
+            _assert_same(oracle.liftover_batch(fix, fb, stages, 1), fe.liftover_batch(fb, stages), f"lanes_fuzz_{seed}_{stages}")
+        fe.close()
+        fi.close()
