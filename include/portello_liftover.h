@@ -210,6 +210,53 @@ plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t sta
    complete on the context's stream (call plo_ctx_sync or synchronise the stream before reading it). */
 plo_status plo_liftover_batch_dev(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Record finishing (the part of src/read_alignment_scanner.rs:245-284 and :310-346 that is arithmetic on the
+ * record, not htslib bookkeeping): for the result of the LAST plo_liftover_batch_dev call on this context
+ *   - per lifted item: flags (BAM_FREVERSE toggled when need_flipped :274-276,:126; supplementary set :282, cleared
+ *     on the primary :346), reference end (get_alignment_end, lib/rust-vc-utils/src/bam_utils/bam_record_utils.rs:21-27)
+ *     and bin (bam_reg2bin, lib/rust-vc-utils/src/bam_utils/util.rs:10-35, :278-279);
+ *   - per read: number of lifted records, the primary one (max MAPQ, first wins :338-346), and for reads without any
+ *     lifted record the flags of the unmapped copy (:317-335);
+ *   - reverse_alignment_seq_and_qual (:125-133) for every record that needs it (lifted items with need_flipped,
+ *     unmapped copies of reverse-strand reads): 4-bit reverse complement (decode, comp_base, re-encode) + reversed
+ *     qualities, written into two context-owned buffers.
+ * Requires seg_read to be non-decreasing (segments grouped by read, as get_seq_order_read_split_segments yields them).
+ * All pointers are device pointers.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct plo_finish_in {
+    const uint16_t *read_flags;    /* [n_reads] record.flags() of the primary read->contig records   */
+    const uint8_t *qual;           /* base qualities of all reads (1 byte per base)                  */
+    const uint64_t *read_qual_off; /* [n_reads] byte offset of the read's qualities inside `qual`     */
+    uint64_t qual_bytes;           /* size of `qual`                                                  */
+} plo_finish_in;
+
+#define PLO_NO_FLIP UINT64_MAX
+
+typedef struct plo_finish_out {
+    /* per item (same order as plo_batch_out) */
+    const uint16_t *item_flag;     /* flags of the lifted record (valid for LIFTED items)             */
+    const uint16_t *item_bin;
+    const int64_t *item_ref_end;
+    const uint8_t *item_is_primary;
+    const uint64_t *item_seq_off;  /* byte offset of the flipped bases inside rev_seq, PLO_NO_FLIP if the record keeps
+                                      the read's original seq/qual                                    */
+    const uint64_t *item_qual_off; /* same for rev_qual                                                */
+    /* per read */
+    const uint32_t *read_n_lifted;
+    const uint32_t *read_primary_item; /* item index of the primary record (UINT32_MAX if none)       */
+    const uint16_t *read_unmapped_flag; /* flags of the unmapped copy (valid when read_n_lifted == 0)  */
+    const uint64_t *read_seq_off;  /* flipped bases of the unmapped copy, PLO_NO_FLIP if not needed    */
+    const uint64_t *read_qual_off;
+    /* flipped sequences */
+    const uint8_t *rev_seq;        /* same encoding as the batch's seq_fmt, every record 16-byte aligned */
+    const uint8_t *rev_qual;
+    uint64_t rev_seq_bytes, rev_qual_bytes;
+    float finish_ms, revcomp_ms;   /* HIP-event times of the two kernels groups                        */
+} plo_finish_out;
+
+plo_status plo_finish_batch_dev(plo_ctx *ctx, const plo_batch_in *in, const plo_finish_in *fin, plo_finish_out *out);
+
 plo_status plo_ctx_sync(plo_ctx *ctx);
 /* Copies `bytes` from device memory (e.g. a plo_liftover_batch_dev output array) to host memory on the context's
    stream and waits for it. */

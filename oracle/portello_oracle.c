@@ -999,3 +999,155 @@ void orc_batch_free(plo_batch_out *out) {
     free((void *)out->cigar);
     memset(out, 0, sizeof(*out));
 }
+
+/* ---- record finishing --------------------------------------------------------------------------------------- */
+
+/* lib/rust-vc-utils/src/bam_utils/util.rs:10-27 hts_reg2bin, :33-35 bam_reg2bin */
+static uint64_t hts_reg2bin(uint64_t begin, uint64_t end, unsigned min_shift, unsigned depth) {
+    end = end - 1;
+    unsigned l = depth, s = min_shift;
+    uint64_t t = ((1ull << (depth * 3)) - 1) / 7;
+    while (l > 0) {
+        if ((begin >> s) == (end >> s)) return t + (begin >> s);
+        l -= 1;
+        s += 3;
+        t -= 1ull << (l * 3);
+    }
+    return 0;
+}
+uint16_t orc_bam_reg2bin(uint64_t begin, uint64_t end) { return (uint16_t)hts_reg2bin(begin, end, 14, 5); }
+
+/* rust-htslib 0.50.0 bam::Record::set(): ENCODE_BASE (htslib seq_nt16_table) -- only the letters comp_base can
+ * produce from decoded bases matter here: A C G T N (third-party table, BAM specification 4.2.3) */
+static uint8_t encode_base(uint8_t c) {
+    switch (c) {
+        case '=': return 0;
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'M': case 'm': return 3;
+        case 'G': case 'g': return 4;
+        case 'R': case 'r': return 5;
+        case 'S': case 's': return 6;
+        case 'V': case 'v': return 7;
+        case 'T': case 't': return 8;
+        case 'W': case 'w': return 9;
+        case 'Y': case 'y': return 10;
+        case 'H': case 'h': return 11;
+        case 'K': case 'k': return 12;
+        case 'D': case 'd': return 13;
+        case 'B': case 'b': return 14;
+        default: return 15;
+    }
+}
+
+/* reverse_alignment_seq_and_qual (src/read_alignment_scanner.rs:125-133): seq().as_bytes(), rev_comp_in_place,
+ * qual reversed, record.set() re-encodes */
+static void reverse_seq_and_qual(const plo_batch_in *in, const plo_finish_in *fin, uint32_t read, uint8_t *dst_seq, uint8_t *dst_qual) {
+    uint32_t len = in->read_seq_len[read];
+    uint8_t *s = get_read_seq(in, read, 1);
+    if (in->seq_fmt == PLO_SEQ_BAM4) {
+        for (uint32_t i = 0; i < len; i += 2)
+            dst_seq[i >> 1] = (uint8_t)((encode_base(s[i]) << 4) | (i + 1 < len ? encode_base(s[i + 1]) : 0));
+    } else {
+        memcpy(dst_seq, s, len);
+    }
+    free(s);
+    const uint8_t *q = fin->qual + fin->read_qual_off[read];
+    for (uint32_t i = 0; i < len; ++i) dst_qual[i] = q[len - 1 - i];
+}
+
+static uint64_t pad16(uint64_t x) { return (x + 15) & ~15ull; }
+
+int orc_finish_batch(const plo_batch_in *in, const plo_finish_in *fin, const plo_batch_out *lift, plo_finish_out *out) {
+    memset(out, 0, sizeof(*out));
+    uint32_t ni = lift->n_items, nr = in->n_reads;
+    size_t a = ni ? ni : 1, b = nr ? nr : 1;
+    uint16_t *flag = calloc(a, 2), *bin = calloc(a, 2), *uflag = calloc(b, 2);
+    int64_t *rend = calloc(a, 8);
+    uint8_t *prim = calloc(a, 1);
+    uint64_t *isoff = malloc(a * 8), *iqoff = malloc(a * 8), *rsoff = malloc(b * 8), *rqoff = malloc(b * 8);
+    uint32_t *nl = calloc(b, 4), *pitem = malloc(b * 4);
+    for (uint32_t r = 0; r < nr; ++r) pitem[r] = UINT32_MAX;
+    uint64_t so = 0, qo = 0;
+    /* pass 1: sizes / offsets in entry order (items, then reads) and per-item scalars */
+    for (uint32_t i = 0; i < ni; ++i) {
+        uint32_t r = in->seg_read[lift->item_seg[i]];
+        isoff[i] = iqoff[i] = PLO_NO_FLIP;
+        if (lift->item_status[i] != PLO_ITEM_LIFTED) continue;
+        uint16_t f = fin->read_flags[r];                       /* clone_record :245 */
+        if (lift->item_need_flipped[i]) f ^= 0x10;             /* :274-276 -> :126  */
+        const uint32_t *cg = lift->cigar + lift->item_cigar_off[i];
+        int64_t e = lift->item_ref_pos[i] + orc_cigar_ref_offset(cg, lift->item_cigar_len[i]); /* get_alignment_end :278 */
+        rend[i] = e;
+        bin[i] = orc_bam_reg2bin((uint64_t)lift->item_ref_pos[i], (uint64_t)e); /* :279 */
+        f |= 0x800;                                            /* set_supplementary :282 */
+        flag[i] = f;
+        nl[r] += 1;
+        if (pitem[r] == UINT32_MAX || lift->item_mapq[pitem[r]] < lift->item_mapq[i]) pitem[r] = i; /* :338-345 first max wins */
+        if (lift->item_need_flipped[i]) {
+            uint32_t len = in->read_seq_len[r];
+            isoff[i] = so;
+            iqoff[i] = qo;
+            so += pad16(in->seq_fmt == PLO_SEQ_BAM4 ? (len + 1) / 2 : len);
+            qo += pad16(len);
+        }
+    }
+    for (uint32_t r = 0; r < nr; ++r) {
+        rsoff[r] = rqoff[r] = PLO_NO_FLIP;
+        if (nl[r] > 0) {
+            prim[pitem[r]] = 1;
+            flag[pitem[r]] &= (uint16_t)~0x800;                /* unset_supplementary :346 */
+        } else {                                               /* unmapped copy :321-334 */
+            uint16_t f = fin->read_flags[r];
+            f |= 0x4;
+            f &= (uint16_t)~0x800;
+            if (f & 0x10) {                                    /* :330-332 */
+                f ^= 0x10;
+                uint32_t len = in->read_seq_len[r];
+                rsoff[r] = so;
+                rqoff[r] = qo;
+                so += pad16(in->seq_fmt == PLO_SEQ_BAM4 ? (len + 1) / 2 : len);
+                qo += pad16(len);
+            }
+            uflag[r] = f;
+        }
+    }
+    uint8_t *rs = calloc(so ? so : 1, 1), *rq = calloc(qo ? qo : 1, 1);
+    for (uint32_t i = 0; i < ni; ++i)
+        if (isoff[i] != PLO_NO_FLIP) reverse_seq_and_qual(in, fin, in->seg_read[lift->item_seg[i]], rs + isoff[i], rq + iqoff[i]);
+    for (uint32_t r = 0; r < nr; ++r)
+        if (rsoff[r] != PLO_NO_FLIP) reverse_seq_and_qual(in, fin, r, rs + rsoff[r], rq + rqoff[r]);
+    out->item_flag = flag;
+    out->item_bin = bin;
+    out->item_ref_end = rend;
+    out->item_is_primary = prim;
+    out->item_seq_off = isoff;
+    out->item_qual_off = iqoff;
+    out->read_n_lifted = nl;
+    out->read_primary_item = pitem;
+    out->read_unmapped_flag = uflag;
+    out->read_seq_off = rsoff;
+    out->read_qual_off = rqoff;
+    out->rev_seq = rs;
+    out->rev_qual = rq;
+    out->rev_seq_bytes = so;
+    out->rev_qual_bytes = qo;
+    return 0;
+}
+
+void orc_finish_free(plo_finish_out *out) {
+    free((void *)out->item_flag);
+    free((void *)out->item_bin);
+    free((void *)out->item_ref_end);
+    free((void *)out->item_is_primary);
+    free((void *)out->item_seq_off);
+    free((void *)out->item_qual_off);
+    free((void *)out->read_n_lifted);
+    free((void *)out->read_primary_item);
+    free((void *)out->read_unmapped_flag);
+    free((void *)out->read_seq_off);
+    free((void *)out->read_qual_off);
+    free((void *)out->rev_seq);
+    free((void *)out->rev_qual);
+    memset(out, 0, sizeof(*out));
+}

@@ -76,6 +76,16 @@ int orc_liftover_batch(const plo_index_desc *index, const plo_batch_in *in, uint
                        plo_batch_out *out);
 void orc_batch_free(plo_batch_out *out);
 
+/* lib/rust-vc-utils/src/bam_utils/util.rs:10-35 */
+uint16_t orc_bam_reg2bin(uint64_t begin, uint64_t end);
+/* Record finishing restated from src/read_alignment_scanner.rs:125-133 (reverse_alignment_seq_and_qual), :245-284
+ * (flags / end / bin of a lifted record), :310-346 (primary selection, unmapped copy).  Host pointers; `lift` is the
+ * result of orc_liftover_batch (or a host copy of the engine's result) for the same batch.  Output arrays are
+ * malloc'ed (orc_finish_free).  Layout of rev_seq/rev_qual: records in the order items, then reads; every record
+ * starts on a 16-byte boundary. */
+int orc_finish_batch(const plo_batch_in *in, const plo_finish_in *fin, const plo_batch_out *lift, plo_finish_out *out);
+void orc_finish_free(plo_finish_out *out);
+
 #ifdef __cplusplus
 }
 #endif

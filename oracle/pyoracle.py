@@ -80,6 +80,12 @@ def lib():
         L.orc_liftover_batch.argtypes = [C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, C.POINTER(abi.PloBatchOut)]
         L.orc_batch_free.restype = None
         L.orc_batch_free.argtypes = [C.POINTER(abi.PloBatchOut)]
+        L.orc_bam_reg2bin.restype = C.c_uint16
+        L.orc_bam_reg2bin.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_finish_batch.restype = C.c_int
+        L.orc_finish_batch.argtypes = [C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloBatchOut), C.POINTER(abi.PloFinishOut)]
+        L.orc_finish_free.restype = None
+        L.orc_finish_free.argtypes = [C.POINTER(abi.PloFinishOut)]
         _lib = L
     return _lib
 
@@ -219,4 +225,36 @@ def liftover_batch(index: abi.IndexData, batch: abi.BatchData, stages: int = abi
     assert rc == 0
     res = abi.result_from_out(out)
     lib().orc_batch_free(C.byref(out))
+    return res
+
+
+def finish_batch(batch: abi.BatchData, read_flags, qual, read_qual_off, lift: abi.BatchResult) -> dict:
+    """Record finishing (orc_finish_batch) on host arrays; returns a dict of numpy arrays."""
+    b = batch.to_desc()
+    rf = np.ascontiguousarray(read_flags, dtype=np.uint16)
+    q = np.ascontiguousarray(qual, dtype=np.uint8)
+    qo = np.ascontiguousarray(read_qual_off, dtype=np.uint64)
+    fin = abi.PloFinishIn(_p(rf, C.c_uint16), _p(q, C.c_uint8), _p(qo, C.c_uint64), q.nbytes)
+    arrs = {n: np.ascontiguousarray(getattr(lift, n)) for n in ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq",
+                                                                 "item_chrom_index", "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")}
+    lo = abi.PloBatchOut()
+    lo.n_items = lift.n_items
+    for n, t in (("item_seg", C.c_uint32), ("item_cseg", C.c_uint32), ("item_status", C.c_uint8), ("item_need_flipped", C.c_uint8),
+                 ("item_mapq", C.c_uint8), ("item_chrom_index", C.c_uint32), ("item_ref_pos", C.c_int64), ("item_cigar_off", C.c_uint64),
+                 ("item_cigar_len", C.c_uint32), ("cigar", C.c_uint32)):
+        setattr(lo, n, _p(arrs[n], t))
+    lo.n_cigar = len(arrs["cigar"])
+    out = abi.PloFinishOut()
+    rc = lib().orc_finish_batch(C.byref(b), C.byref(fin), C.byref(lo), C.byref(out))
+    assert rc == 0
+    n, nr = lift.n_items, batch.n_reads
+
+    def cp(p, dt, cnt):
+        return np.ctypeslib.as_array(p, shape=(cnt,)).astype(dt, copy=True) if cnt else np.zeros(0, dt)
+
+    res = {name: cp(getattr(out, name), dt, n) for name, dt in abi.FINISH_ITEM_FIELDS}
+    res.update({name: cp(getattr(out, name), dt, nr) for name, dt in abi.FINISH_READ_FIELDS})
+    res["rev_seq"] = cp(out.rev_seq, np.uint8, int(out.rev_seq_bytes))
+    res["rev_qual"] = cp(out.rev_qual, np.uint8, int(out.rev_qual_bytes))
+    lib().orc_finish_free(C.byref(out))
     return res

@@ -124,6 +124,31 @@ class PloTiming(C.Structure):
     ]
 
 
+_u16p = C.POINTER(C.c_uint16)
+NO_FLIP = 2**64 - 1
+
+
+class PloFinishIn(C.Structure):
+    _fields_ = [("read_flags", _u16p), ("qual", _u8p), ("read_qual_off", _u64p), ("qual_bytes", C.c_uint64)]
+
+
+class PloFinishOut(C.Structure):
+    _fields_ = [
+        ("item_flag", _u16p), ("item_bin", _u16p), ("item_ref_end", _i64p), ("item_is_primary", _u8p),
+        ("item_seq_off", _u64p), ("item_qual_off", _u64p),
+        ("read_n_lifted", _u32p), ("read_primary_item", _u32p), ("read_unmapped_flag", _u16p),
+        ("read_seq_off", _u64p), ("read_qual_off", _u64p),
+        ("rev_seq", _u8p), ("rev_qual", _u8p), ("rev_seq_bytes", C.c_uint64), ("rev_qual_bytes", C.c_uint64),
+        ("finish_ms", C.c_float), ("revcomp_ms", C.c_float),
+    ]
+
+
+FINISH_ITEM_FIELDS = [("item_flag", np.uint16), ("item_bin", np.uint16), ("item_ref_end", np.int64), ("item_is_primary", np.uint8),
+                      ("item_seq_off", np.uint64), ("item_qual_off", np.uint64)]
+FINISH_READ_FIELDS = [("read_n_lifted", np.uint32), ("read_primary_item", np.uint32), ("read_unmapped_flag", np.uint16),
+                      ("read_seq_off", np.uint64), ("read_qual_off", np.uint64)]
+
+
 def _np(a, dtype) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=dtype))
 

@@ -58,6 +58,8 @@ def load_library(path: Optional[str] = None):
     L.plo_liftover_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
     L.plo_liftover_batch_dev.restype = C.c_int
     L.plo_liftover_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
+    L.plo_finish_batch_dev.restype = C.c_int
+    L.plo_finish_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloFinishOut)]
     L.plo_ctx_sync.restype = C.c_int
     L.plo_ctx_sync.argtypes = [vp]
     L.plo_ctx_download.restype = C.c_int
@@ -138,6 +140,12 @@ class Engine:
         """Device pointers in, device pointers out (plo_liftover_batch_dev); asynchronous on the engine's stream."""
         out = abi.PloBatchOut()
         self._check(self.lib.plo_liftover_batch_dev(self.handle, C.byref(desc), stages, C.byref(out)), "plo_liftover_batch_dev")
+        return out
+
+    def finish_batch_dev(self, desc: abi.PloBatchIn, fin: abi.PloFinishIn) -> abi.PloFinishOut:
+        """Record finishing for the last liftover_batch_dev result (plo_finish_batch_dev); device pointers."""
+        out = abi.PloFinishOut()
+        self._check(self.lib.plo_finish_batch_dev(self.handle, C.byref(desc), C.byref(fin), C.byref(out)), "plo_finish_batch_dev")
         return out
 
     def download(self, dev_ptr, dtype, count: int) -> np.ndarray:

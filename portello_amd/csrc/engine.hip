@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "enumerate.hpp"
+#include "finish_core.hpp"
 #include "index_pack.hpp"
 #include "lane_core.hpp"
 #include "lift_core.hpp"
@@ -230,6 +231,42 @@ __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWo
     wave_ctx_flush(wk, ctx);
 }
 
+// ---- record finishing (finish_core.hpp) ----------------------------------------------------------------------------------
+__global__ void k_finish_items(DevBatch bt, DevWork wk, DevFinish f) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wk.n_items) finish_item(bt, wk, f, i);
+}
+__global__ void k_finish_reads(DevBatch bt, DevWork wk, DevFinish f) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < bt.n_reads) finish_read(bt, wk, f, r);
+}
+__global__ void k_finish_offsets(DevBatch bt, DevWork wk, DevFinish f) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = wk.n_items;
+    if (e >= n + bt.n_reads) return;
+    uint64_t so = f.su[e] ? (uint64_t)f.soff[e] * 16u : PLO_NO_FLIP;
+    uint64_t qo = f.qu[e] ? (uint64_t)f.qoff[e] * 16u : PLO_NO_FLIP;
+    if (f.su[e]) f.flist[f.frank[e]] = e;
+    if (e < n) {
+        f.item_seq_off[e] = so;
+        f.item_qual_off[e] = qo;
+    } else {
+        f.read_seq_off[e - n] = so;
+        f.read_qual_off_out[e - n] = qo;
+    }
+}
+// reverse_alignment_seq_and_qual: one workgroup per record that needs it, streaming 16-byte-aligned outputs.
+// HBM-bound: per flipped read L/2 + L bytes in, the same out.
+__global__ __launch_bounds__(256) void k_revcomp(DevBatch bt, DevWork wk, DevFinish f) {
+    uint32_t n = wk.n_items, n_flip = f.frank[n + bt.n_reads];
+    for (uint32_t k = blockIdx.x; k < n_flip; k += gridDim.x) {
+        uint32_t e = f.flist[k];
+        uint32_t read = e < n ? f.item_read[e] : e - n;
+        revcomp_record(bt, f, read, f.rev_seq + (uint64_t)f.soff[e] * 16u, f.rev_qual + (uint64_t)f.qoff[e] * 16u, (int)threadIdx.x,
+                       (int)blockDim.x);
+    }
+}
+
 // ---- self-test of the wave primitives (plo_selftest) -------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_selftest(const int *in, int *out) {
     int lane = wv::lane();
@@ -333,6 +370,12 @@ struct plo_ctx {
     bool own_stream = false;
     std::string err;
     // workspace
+    DevBuf f_flag, f_bin, f_end, f_prim, f_isoff, f_iqoff, f_iread, f_nl, f_pitem, f_uflag, f_rsoff, f_rqoff, f_su, f_qu, f_soff,
+        f_qoff, f_rseq, f_rqual, f_fflag, f_frank, f_flist;
+    DevWork last_wk{};
+    DevBatch last_bt{};
+    bool have_last = false;
+    hipEvent_t fev[3] = {nullptr, nullptr, nullptr};
     DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
@@ -529,7 +572,9 @@ void plo_ctx_destroy(plo_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->ix->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+    DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
+                      &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist,
+                      &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -542,6 +587,8 @@ void plo_ctx_destroy(plo_ctx *c) {
     for (HostBuf *b : hb) b->release();
     for (int i = 0; i < 6; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 3; ++i)
+        if (c->fev[i]) (void)hipEventDestroy(c->fev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -865,6 +912,118 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     out->item_cigar_len = c->o_clen.as<uint32_t>();
     out->cigar = c->o_cigar.as<uint32_t>();
     out->n_cigar = hc[CNT_CIGAR];
+    c->last_wk = wk;
+    c->last_bt = bt;
+    c->have_last = true;
+    return PLO_OK;
+}
+
+plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_finish_in *fin, plo_finish_out *out) {
+    if (!c || !in || !fin || !out) return PLO_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    c->err.clear();
+    if (!c->have_last || c->last_bt.n_segs != in->n_segs || c->last_bt.n_reads != in->n_reads) {
+        c->err = "plo_finish_batch_dev: call plo_liftover_batch_dev on the same batch first";
+        return PLO_ERR_INVALID_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    hipStream_t st = c->stream;
+    for (int i = 0; i < 3; ++i)
+        if (!c->fev[i]) HIP_TRY(c, hipEventCreate(&c->fev[i]));
+    const DevWork &wk = c->last_wk;
+    DevBatch bt = c->last_bt;
+    uint32_t n = wk.n_items, nr = bt.n_reads, ne = n + nr;
+    size_t a = std::max(1u, n), b = std::max(1u, nr), e = std::max(1u, ne);
+    HIP_TRY(c, c->f_flag.ensure(a * 2));
+    HIP_TRY(c, c->f_bin.ensure(a * 2));
+    HIP_TRY(c, c->f_end.ensure(a * 8));
+    HIP_TRY(c, c->f_prim.ensure(a));
+    HIP_TRY(c, c->f_isoff.ensure(a * 8));
+    HIP_TRY(c, c->f_iqoff.ensure(a * 8));
+    HIP_TRY(c, c->f_iread.ensure(a * 4));
+    HIP_TRY(c, c->f_nl.ensure(b * 4));
+    HIP_TRY(c, c->f_pitem.ensure(b * 4));
+    HIP_TRY(c, c->f_uflag.ensure(b * 2));
+    HIP_TRY(c, c->f_rsoff.ensure(b * 8));
+    HIP_TRY(c, c->f_rqoff.ensure(b * 8));
+    HIP_TRY(c, c->f_su.ensure(e * 4));
+    HIP_TRY(c, c->f_qu.ensure(e * 4));
+    HIP_TRY(c, c->f_soff.ensure((e + 1) * 4));
+    HIP_TRY(c, c->f_qoff.ensure((e + 1) * 4));
+    HIP_TRY(c, c->f_fflag.ensure(e * 4));
+    HIP_TRY(c, c->f_frank.ensure((e + 1) * 4));
+    HIP_TRY(c, c->f_flist.ensure(e * 4));
+    DevFinish f;
+    memset(&f, 0, sizeof(f));
+    f.read_flags = fin->read_flags;
+    f.qual = fin->qual;
+    f.read_qual_off = fin->read_qual_off;
+    f.qual_bytes = fin->qual_bytes;
+    f.seq_bytes = in->seq_bytes;
+    f.item_flag = c->f_flag.as<uint16_t>();
+    f.item_bin = c->f_bin.as<uint16_t>();
+    f.item_ref_end = c->f_end.as<int64_t>();
+    f.item_is_primary = c->f_prim.as<uint8_t>();
+    f.item_seq_off = c->f_isoff.as<uint64_t>();
+    f.item_qual_off = c->f_iqoff.as<uint64_t>();
+    f.item_read = c->f_iread.as<uint32_t>();
+    f.read_n_lifted = c->f_nl.as<uint32_t>();
+    f.read_primary_item = c->f_pitem.as<uint32_t>();
+    f.read_unmapped_flag = c->f_uflag.as<uint16_t>();
+    f.read_seq_off = c->f_rsoff.as<uint64_t>();
+    f.read_qual_off_out = c->f_rqoff.as<uint64_t>();
+    f.su = c->f_su.as<uint32_t>();
+    f.qu = c->f_qu.as<uint32_t>();
+    f.soff = c->f_soff.as<uint32_t>();
+    f.qoff = c->f_qoff.as<uint32_t>();
+    f.fflag = c->f_fflag.as<uint32_t>();
+    f.frank = c->f_frank.as<uint32_t>();
+    f.flist = c->f_flist.as<uint32_t>();
+    HIP_TRY(c, hipEventRecord(c->fev[0], st));
+    if (n) hipLaunchKernelGGL(k_finish_items, dim3((n + 255) / 256), dim3(256), 0, st, bt, wk, f);
+    if (nr) hipLaunchKernelGGL(k_finish_reads, dim3((nr + 255) / 256), dim3(256), 0, st, bt, wk, f);
+    HIP_TRY(c, hipGetLastError());
+    plo_status s = scan_u32(c, f.su, ne, c->f_soff.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    s = scan_u32(c, f.qu, ne, c->f_qoff.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    s = scan_u32(c, f.fflag, ne, c->f_frank.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    if (ne) hipLaunchKernelGGL(k_finish_offsets, dim3((ne + 255) / 256), dim3(256), 0, st, bt, wk, f);
+    uint32_t *h = c->h_counters.as<uint32_t>();
+    HIP_TRY(c, hipMemcpyAsync(h, c->f_soff.as<uint32_t>() + ne, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h + 1, c->f_qoff.as<uint32_t>() + ne, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->fev[1], st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    uint64_t sb = (uint64_t)h[0] * 16u, qb = (uint64_t)h[1] * 16u;
+    HIP_TRY(c, c->f_rseq.ensure(std::max<uint64_t>(sb, 16)));
+    HIP_TRY(c, c->f_rqual.ensure(std::max<uint64_t>(qb, 16)));
+    f.rev_seq = c->f_rseq.as<uint8_t>();
+    f.rev_qual = c->f_rqual.as<uint8_t>();
+    if (sb) {
+        uint32_t nblk = std::min<uint32_t>(ne, (uint32_t)c->n_cus * 16u);
+        hipLaunchKernelGGL(k_revcomp, dim3(nblk), dim3(256), 0, st, bt, wk, f);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->fev[2], st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&out->finish_ms, c->fev[0], c->fev[1]);
+    (void)hipEventElapsedTime(&out->revcomp_ms, c->fev[1], c->fev[2]);
+    out->item_flag = f.item_flag;
+    out->item_bin = f.item_bin;
+    out->item_ref_end = f.item_ref_end;
+    out->item_is_primary = f.item_is_primary;
+    out->item_seq_off = f.item_seq_off;
+    out->item_qual_off = f.item_qual_off;
+    out->read_n_lifted = f.read_n_lifted;
+    out->read_primary_item = f.read_primary_item;
+    out->read_unmapped_flag = f.read_unmapped_flag;
+    out->read_seq_off = f.read_seq_off;
+    out->read_qual_off = f.read_qual_off_out;
+    out->rev_seq = f.rev_seq;
+    out->rev_qual = f.rev_qual;
+    out->rev_seq_bytes = sb;
+    out->rev_qual_bytes = qb;
     return PLO_OK;
 }
 

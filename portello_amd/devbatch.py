@@ -103,3 +103,25 @@ def run_and_download(eng, db: DeviceBatch, stages: int = abi.STAGES_ALL) -> abi.
     torch.cuda.synchronize()
     out = eng.liftover_batch_dev(db.desc(), stages)
     return download(eng, out)
+
+
+def finish_inputs(w, db: DeviceBatch, seed: int = 1):
+    """Synthetic record flags + base qualities for the record-finishing stage (device tensors + the plo_finish_in)."""
+    dev = db.seq.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = db.read_seq_len.to(torch.int64)
+    qoff = torch.cumsum(lens, 0) - lens
+    total = int(lens.sum().item())
+    qual = torch.randint(0, 94, (max(1, total),), generator=g, device=dev, dtype=torch.uint8)
+    flags = (db.read_is_reverse.to(torch.int16) * 0x10) | (torch.randint(0, 2, (db.n_reads,), generator=g, device=dev).to(torch.int16) * 0x400)
+    fin = abi.PloFinishIn(_p(flags, C.c_uint16), _p(qual, C.c_uint8), _p(qoff, C.c_uint64), total)
+    return fin, dict(flags=flags, qual=qual, qoff=qoff)
+
+
+def download_finish(eng, fo: abi.PloFinishOut, n_items: int, n_reads: int) -> dict:
+    res = {name: eng.download(getattr(fo, name), dt, n_items) for name, dt in abi.FINISH_ITEM_FIELDS}
+    res.update({name: eng.download(getattr(fo, name), dt, n_reads) for name, dt in abi.FINISH_READ_FIELDS})
+    res["rev_seq"] = eng.download(fo.rev_seq, np.uint8, int(fo.rev_seq_bytes))
+    res["rev_qual"] = eng.download(fo.rev_qual, np.uint8, int(fo.rev_qual_bytes))
+    return res

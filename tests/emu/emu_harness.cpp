@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../portello_amd/csrc/enumerate.hpp"
+#include "../../portello_amd/csrc/finish_core.hpp"
 #include "../../portello_amd/csrc/index_pack.hpp"
 #include "../../portello_amd/csrc/lane_core.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
@@ -258,4 +259,90 @@ void *g_last_emu_out = nullptr;
 extern "C" void emu_free_last() {
     delete (Out *)g_last_emu_out;
     g_last_emu_out = nullptr;
+}
+
+// ---- record finishing (finish_core.hpp) run on the host: what k_finish_items / k_finish_reads / k_finish_offsets /
+// k_revcomp do on the GPU, with plain loops standing in for the threads ------------------------------------------------
+namespace {
+struct FinOut {
+    std::vector<uint16_t> flag, bin, uflag;
+    std::vector<int64_t> rend;
+    std::vector<uint8_t> prim, rseq, rqual;
+    std::vector<uint64_t> isoff, iqoff, rsoff, rqoff;
+    std::vector<uint32_t> iread, nl, pitem, su, qu, soff, qoff, fflag, frank, flist;
+};
+FinOut *g_fin = nullptr;
+}  // namespace
+
+extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin, const plo_batch_out *lift, int nthreads,
+                                plo_finish_out *out) {
+    DevBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.read_seq_len = in->read_seq_len;
+    bt.read_seq_off = in->read_seq_off;
+    bt.seq = in->seq;
+    bt.seq_fmt = in->seq_fmt;
+    bt.seg_read = in->seg_read;
+    bt.n_reads = in->n_reads;
+    bt.n_segs = in->n_segs;
+    DevWork wk;
+    memset(&wk, 0, sizeof(wk));
+    uint32_t n = lift->n_items, nr = in->n_reads, ne = n + nr;
+    wk.n_items = n;
+    wk.item_seg = (uint32_t *)lift->item_seg;
+    wk.status = (uint8_t *)lift->item_status;
+    wk.flip = (uint8_t *)lift->item_need_flipped;
+    wk.mapq = (uint8_t *)lift->item_mapq;
+    wk.pos = (int64_t *)lift->item_ref_pos;
+    wk.cig_off = (uint64_t *)lift->item_cigar_off;
+    wk.cig_len = (uint32_t *)lift->item_cigar_len;
+    wk.out_cigar = (uint32_t *)lift->cigar;
+    delete g_fin;
+    FinOut *o = g_fin = new FinOut();
+    size_t a = n ? n : 1, b = nr ? nr : 1, e = ne ? ne : 1;
+    o->flag.assign(a, 0); o->bin.assign(a, 0); o->rend.assign(a, 0); o->prim.assign(a, 0); o->isoff.assign(a, 0); o->iqoff.assign(a, 0);
+    o->iread.assign(a, 0); o->nl.assign(b, 0); o->pitem.assign(b, 0); o->uflag.assign(b, 0); o->rsoff.assign(b, 0); o->rqoff.assign(b, 0);
+    o->su.assign(e, 0); o->qu.assign(e, 0); o->soff.assign(e + 1, 0); o->qoff.assign(e + 1, 0); o->fflag.assign(e, 0);
+    o->frank.assign(e + 1, 0); o->flist.assign(e, 0);
+    DevFinish f;
+    memset(&f, 0, sizeof(f));
+    f.read_flags = fin->read_flags; f.qual = fin->qual; f.read_qual_off = fin->read_qual_off; f.qual_bytes = fin->qual_bytes;
+    f.seq_bytes = in->seq_bytes;
+    f.item_flag = o->flag.data(); f.item_bin = o->bin.data(); f.item_ref_end = o->rend.data(); f.item_is_primary = o->prim.data();
+    f.item_seq_off = o->isoff.data(); f.item_qual_off = o->iqoff.data(); f.item_read = o->iread.data();
+    f.read_n_lifted = o->nl.data(); f.read_primary_item = o->pitem.data(); f.read_unmapped_flag = o->uflag.data();
+    f.read_seq_off = o->rsoff.data(); f.read_qual_off_out = o->rqoff.data();
+    f.su = o->su.data(); f.qu = o->qu.data(); f.soff = o->soff.data(); f.qoff = o->qoff.data();
+    f.fflag = o->fflag.data(); f.frank = o->frank.data(); f.flist = o->flist.data();
+    for (uint32_t i = 0; i < n; ++i) finish_item(bt, wk, f, i);
+    for (uint32_t r = 0; r < nr; ++r) finish_read(bt, wk, f, r);
+    for (uint32_t k = 0; k < ne; ++k) {
+        o->soff[k + 1] = o->soff[k] + o->su[k];
+        o->qoff[k + 1] = o->qoff[k] + o->qu[k];
+        o->frank[k + 1] = o->frank[k] + o->fflag[k];
+    }
+    for (uint32_t k = 0; k < ne; ++k) {
+        uint64_t so = o->su[k] ? (uint64_t)o->soff[k] * 16u : PLO_NO_FLIP, qo = o->qu[k] ? (uint64_t)o->qoff[k] * 16u : PLO_NO_FLIP;
+        if (o->su[k]) o->flist[o->frank[k]] = k;
+        if (k < n) { o->isoff[k] = so; o->iqoff[k] = qo; } else { o->rsoff[k - n] = so; o->rqoff[k - n] = qo; }
+    }
+    // 16-byte aligned destination buffers (vector of uint64 pairs)
+    o->rseq.assign((size_t)o->soff[ne] * 16 + 32, 0xEE);
+    o->rqual.assign((size_t)o->qoff[ne] * 16 + 32, 0xEE);
+    uint8_t *rs = o->rseq.data() + ((16 - ((uintptr_t)o->rseq.data() & 15)) & 15);
+    uint8_t *rq = o->rqual.data() + ((16 - ((uintptr_t)o->rqual.data() & 15)) & 15);
+    f.rev_seq = rs;
+    f.rev_qual = rq;
+    for (uint32_t k = 0; k < o->frank[ne]; ++k) {
+        uint32_t en = o->flist[k];
+        uint32_t read = en < n ? o->iread[en] : en - n;
+        for (int t = 0; t < nthreads; ++t)
+            revcomp_record(bt, f, read, rs + (uint64_t)o->soff[en] * 16u, rq + (uint64_t)o->qoff[en] * 16u, t, nthreads);
+    }
+    out->item_flag = f.item_flag; out->item_bin = f.item_bin; out->item_ref_end = f.item_ref_end; out->item_is_primary = f.item_is_primary;
+    out->item_seq_off = f.item_seq_off; out->item_qual_off = f.item_qual_off; out->read_n_lifted = f.read_n_lifted;
+    out->read_primary_item = f.read_primary_item; out->read_unmapped_flag = f.read_unmapped_flag; out->read_seq_off = f.read_seq_off;
+    out->read_qual_off = f.read_qual_off_out; out->rev_seq = rs; out->rev_qual = rq;
+    out->rev_seq_bytes = (uint64_t)o->soff[ne] * 16u; out->rev_qual_bytes = (uint64_t)o->qoff[ne] * 16u;
+    return 0;
 }

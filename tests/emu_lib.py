@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False, sanitize=False):
     srcs = [os.path.join(_HERE, "emu", "emu_harness.cpp"), os.path.join(_HERE, "emu", "plo_wave.hpp")] + [
-        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "lane_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
+        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "lane_core.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "emu"),
@@ -35,6 +35,9 @@ def lib():
         L.emu_liftover_batch.restype = C.c_int
         L.emu_liftover_batch.argtypes = [C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(abi.PloBatchOut), C.POINTER(C.c_ulonglong)]
+        L.emu_finish_batch.restype = C.c_int
+        L.emu_finish_batch.argtypes = [C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloBatchOut), C.c_int,
+                                       C.POINTER(abi.PloFinishOut)]
         L.emu_free_last.restype = None
         _lib = L
     return _lib
@@ -50,3 +53,31 @@ def liftover_batch(index: abi.IndexData, batch: abi.BatchData, stages=abi.STAGES
     res = abi.result_from_out(out)
     lib().emu_free_last()
     return rc, res, list(counters)
+
+
+def finish_batch(batch: abi.BatchData, read_flags, qual, read_qual_off, lift: abi.BatchResult, nthreads=7) -> dict:
+    """finish_core.hpp executed on the host (plain loops instead of GPU threads)"""
+    b = batch.to_desc()
+    rf = np.ascontiguousarray(read_flags, dtype=np.uint16)
+    q = np.ascontiguousarray(qual, dtype=np.uint8)
+    qo = np.ascontiguousarray(read_qual_off, dtype=np.uint64)
+    p = lambda arr, t: arr.ctypes.data_as(C.POINTER(t))
+    fin = abi.PloFinishIn(p(rf, C.c_uint16), p(q, C.c_uint8), p(qo, C.c_uint64), q.nbytes)
+    arrs = {n: np.ascontiguousarray(getattr(lift, n)) for n in ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq",
+                                                                 "item_chrom_index", "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")}
+    lo = abi.PloBatchOut()
+    lo.n_items = lift.n_items
+    for n, t in (("item_seg", C.c_uint32), ("item_cseg", C.c_uint32), ("item_status", C.c_uint8), ("item_need_flipped", C.c_uint8),
+                 ("item_mapq", C.c_uint8), ("item_chrom_index", C.c_uint32), ("item_ref_pos", C.c_int64), ("item_cigar_off", C.c_uint64),
+                 ("item_cigar_len", C.c_uint32), ("cigar", C.c_uint32)):
+        setattr(lo, n, p(arrs[n], t))
+    lo.n_cigar = len(arrs["cigar"])
+    out = abi.PloFinishOut()
+    assert lib().emu_finish_batch(C.byref(b), C.byref(fin), C.byref(lo), nthreads, C.byref(out)) == 0
+    n, nr = lift.n_items, batch.n_reads
+    cp = lambda ptr, dt, cnt: np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True) if cnt else np.zeros(0, dt)
+    res = {name: cp(getattr(out, name), dt, n) for name, dt in abi.FINISH_ITEM_FIELDS}
+    res.update({name: cp(getattr(out, name), dt, nr) for name, dt in abi.FINISH_READ_FIELDS})
+    res["rev_seq"] = cp(out.rev_seq, np.uint8, int(out.rev_seq_bytes))
+    res["rev_qual"] = cp(out.rev_qual, np.uint8, int(out.rev_qual_bytes))
+    return res
