@@ -645,6 +645,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     bt.read_seq_off = in->read_seq_off;
     bt.seq = in->seq;
     bt.seq_fmt = in->seq_fmt;
+    bt.seq_bytes = in->seq_bytes;
     bt.seg_read = in->seg_read;
     bt.seg_contig = in->seg_contig;
     bt.seg_pos = in->seg_pos;
@@ -785,7 +786,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->misc.ensure(64));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 64, st));
         if (n_items)
-            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 1024u)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 64u)), dim3(256), 0, st,
                                (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>());
         uint32_t *h = c->h_counters.as<uint32_t>();
         HIP_TRY(c, hipMemcpyAsync(h, c->op_prefix.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
@@ -834,6 +835,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
         if (n_items > n_small) {
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
+            if (const char *e = getenv("PLO_LDS_PAD")) lds_per_wave += (uint32_t)atoi(e) & ~15u;  // occupancy experiments
             const uint32_t tw = (uint32_t)c->tile_waves;
             uint32_t nblk = (n_tiles + tw - 1) / tw;
             // persistent grid: what the chip keeps resident (CUs x blocks per CU), a multiple of 8 for the XCD mapping

@@ -98,6 +98,7 @@ struct ReadSeq {
     int len;
     int fmt;
     int flip;
+    long long lo, hi;  // bytes p[lo .. hi) belong to the batch's seq buffer (bounds for the wide-window loads)
 };
 PLO_DEV int read_base(const ReadSeq &r, int i) {
     int j = r.flip ? (r.len - 1 - i) : i;
@@ -121,6 +122,8 @@ PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, in
     r.len = seq_len;
     r.fmt = bt.seq_fmt;
     r.flip = flip;
+    r.lo = -(long long)seq_off;
+    r.hi = (long long)bt.seq_bytes - (long long)seq_off;
     return r;
 }
 
@@ -293,6 +296,66 @@ PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, cons
         if (re - 1 >= ref_len || qe - 1 >= rd.len) {
             panic = true;
             return 0;
+        }
+    }
+    // First round: 16 reference bytes and 16 read bases fetched as aligned dwords (8 loads, ONE memory round trip) and
+    // compared in registers; homologies longer than 16 fall through to the byte loop below.
+    {
+        const int n16 = wv::imin(16, maxk);
+        const long long r0 = (long long)re - 16;  // window = ref[re-16 .. re)
+        const unsigned rsh = (unsigned)(((unsigned long long)(uintptr_t)ref + (unsigned long long)r0) & 3ull);
+        // read bases qe-1-k, k = 0..15, are the packed/ASCII positions j(k) = flip ? len-qe+k : qe-1-k
+        const long long jmin = rd.flip ? (long long)rd.len - qe : (long long)qe - 16;
+        const long long b0 = rd.fmt == PLO_SEQ_BAM4 ? (jmin >> 1) : jmin;  // first byte of the read window
+        const unsigned qsh = (unsigned)(((unsigned long long)(uintptr_t)rd.p + (unsigned long long)b0) & 3ull);
+        const int qwords = rd.fmt == PLO_SEQ_BAM4 ? 3 : 5;
+        if (n16 > 0 && qe >= 16 && r0 - (long long)rsh >= 0 && r0 - (long long)rsh + 20 <= (long long)ref_len &&
+            b0 - (long long)qsh >= rd.lo && b0 - (long long)qsh + 4 * qwords <= rd.hi) {
+            const uint32_t *pr = (const uint32_t *)(ref + (r0 - (long long)rsh));
+            const uint32_t *pq = (const uint32_t *)(rd.p + (b0 - (long long)qsh));
+            unsigned wr[5], wq[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) wr[u] = pr[u];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) wq[u] = u < qwords ? pq[u] : 0u;
+            // realign once (funnel shifts) so that every later index is a compile-time constant
+            unsigned R[4], Q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                R[u] = (unsigned)((((unsigned long long)wr[u + 1] << 32) | wr[u]) >> (8 * rsh));  // ref[re-16+4u ..]
+                Q[u] = (unsigned)((((unsigned long long)wq[u + 1] << 32) | wq[u]) >> (8 * qsh));  // read window bytes
+            }
+            unsigned N0 = 0, N1 = 0;  // 4-bit: bases jmin .. jmin+15 as a linear nibble stream (base t at nibble t)
+            if (rd.fmt == PLO_SEQ_BAM4) {
+                unsigned s0 = ((Q[0] & 0x0f0f0f0fu) << 4) | ((Q[0] >> 4) & 0x0f0f0f0fu);
+                unsigned s1 = ((Q[1] & 0x0f0f0f0fu) << 4) | ((Q[1] >> 4) & 0x0f0f0f0fu);
+                unsigned s2 = ((Q[2] & 0x0f0f0f0fu) << 4) | ((Q[2] >> 4) & 0x0f0f0f0fu);
+                unsigned par = (unsigned)(jmin & 1);
+                N0 = (unsigned)((((unsigned long long)s1 << 32) | s0) >> (4 * par));
+                N1 = (unsigned)((((unsigned long long)s2 << 32) | s1) >> (4 * par));
+            }
+            int m = n16;
+#pragma unroll
+            for (int kk = 15; kk >= 0; --kk) {
+                unsigned a = (R[(15 - kk) >> 2] >> (8 * ((15 - kk) & 3))) & 0xffu;  // ref[re-1-kk]
+                unsigned bch;
+                if (rd.fmt == PLO_SEQ_BAM4) {
+                    unsigned nf = ((kk < 8 ? N0 : N1) >> (4 * (kk & 7))) & 15u;                  // base jmin+kk      (flip)
+                    unsigned nr = (((15 - kk) < 8 ? N0 : N1) >> (4 * ((15 - kk) & 7))) & 15u;    // base jmin+15-kk
+                    unsigned nib = rd.flip ? nf : nr;
+                    const unsigned long long lo = 0x565352474d43413dull, hi = 0x4e42444b48595754ull;
+                    bch = (unsigned)(((nib & 8) ? hi : lo) >> ((nib & 7) * 8)) & 0xffu;
+                } else {
+                    unsigned bf = (Q[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+                    unsigned br = (Q[(15 - kk) >> 2] >> (8 * ((15 - kk) & 3))) & 0xffu;
+                    bch = rd.flip ? bf : br;
+                }
+                if (rd.flip) bch = (unsigned)comp_base((int)bch);
+                if (kk < n16 && a != bch) m = kk;
+            }
+            probes += wv::imin(m + 1, n16);
+            k = m;
+            if (m < n16) return k;
         }
     }
     while (k < maxk) {
@@ -523,6 +586,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         overflow = wv::ballot(overflow) != 0ull;
         wv::sync();
+        PLO_T(1)
         // pass H: one lane per indel cluster (all clusters of the tile at once): left breakend homology.  This is
         // the only part of the shift that touches the sequences, so the HBM round trips are paid once per tile.
         for (int base = 0; base < nH && !overflow; base += 64) {
@@ -544,6 +608,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
         }
         wv::sync();
+        PLO_T(10)
         // pass B: homology, carried match run (min-plus scan), emission
         int nB = 0;
         {
@@ -627,6 +692,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         overflow = wv::ballot(overflow) != 0ull;
         wv::sync();
+        PLO_T(11)
         if (!overflow) {
             int sB, cB;
             finish_counts(m.T0, sA, cA, sB, cB);

@@ -40,6 +40,7 @@ struct DevBatch {
     const uint64_t *read_seq_off;
     const uint8_t *seq;
     int seq_fmt;
+    uint64_t seq_bytes;  // size of `seq`
     const uint32_t *seg_read;
     const uint32_t *seg_contig;
     const int64_t *seg_pos;

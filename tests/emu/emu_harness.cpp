@@ -54,6 +54,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     bt.read_seq_off = in->read_seq_off;
     bt.seq = in->seq;
     bt.seq_fmt = in->seq_fmt;
+    bt.seq_bytes = in->seq_bytes;
     bt.seg_read = in->seg_read;
     bt.seg_contig = in->seg_contig;
     bt.seg_pos = in->seg_pos;
@@ -282,6 +283,7 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
     bt.read_seq_off = in->read_seq_off;
     bt.seq = in->seq;
     bt.seq_fmt = in->seq_fmt;
+    bt.seq_bytes = in->seq_bytes;
     bt.seg_read = in->seg_read;
     bt.n_reads = in->n_reads;
     bt.n_segs = in->n_segs;

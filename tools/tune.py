@@ -51,6 +51,6 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         ph = (C.c_ulonglong * 12)()
         L.plo_ctx_phase_cycles(eng.handle, ph)
         tot = sum(ph) or 1
-        names = ["desc", "load", "lshift+cc", "lift:stage+passA", "lift:scatter+passB", "lift:cc", "lencheck", "simplify A+B", "simplify cc", "output"]
+        names = ["desc", "load+lshiftA", "lshift cc", "lift:stage+passA", "lift:scatter+passB", "lift:cc", "lencheck", "simplify A+H+B", "simplify cc", "output", "lshift H", "lshift B"]
         print("   phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/tile-wave {tot/ max(1,(t.n_in_ops//int(win)+1)):.0f}", flush=True)
     eng.close()
