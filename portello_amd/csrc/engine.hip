@@ -1,12 +1,16 @@
 // engine.hip -- gfx950 kernels + the C ABI of include/portello_liftover.h.
 //
 // Kernel pipeline of one batch (all on the context's stream):
-//   k_seg_count      one thread per read split segment: how many contig segments does it touch (a8)
-//   scan             exclusive scan -> item offsets, n_items
-//   k_item_emit      writes the item list (read segment, contig segment index, input op count)
-//   scan             exclusive scan of the input op counts -> item_op_prefix (tile assignment)
-//   k_lift_tiles     DOMINANT KERNEL: one wave per tile of items, whole strand/shift/liftover/simplify pipeline in LDS
-//   k_lift_big       items too long for a shared LDS tile: one wave per item, wave-private global scratch
+//   k_seg_count          thread per read split segment: reference span + how many contig segments it touches (a8)
+//   scan                 item offsets, n_items
+//   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3)
+//   k_class_flags/scans/k_permute   class order (strand x size) so that groups and tiles are homogeneous
+//   scan + k_tile_bounds flattened op stream of the tiled items -> first item of every tile
+//   k_lift_lanes         (optional, off by default) lane-per-item fast path for short CIGARs + k_lift_retry
+//   k_lift_tiles         DOMINANT KERNEL: persistent waves, one wave per tile of items, the whole
+//                        shift / liftover / length check / simplify pipeline on a flattened op stream in LDS
+//   k_lift_big           items too long for an LDS tile: one wave per item, wave-private global scratch
+//   k_finish_* / k_revcomp   record finishing (plo_finish_batch_dev)
 // There is no CPU path: every entry point fails with PLO_ERR_NO_DEVICE / PLO_ERR_HIP when the device is unusable.
 #include <hip/hip_runtime.h>
 

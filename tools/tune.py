@@ -19,9 +19,12 @@ ap.add_argument("--settings", default="160:176:512,128:144:384,96:112:320,256:25
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--stages", default="31")
 ap.add_argument("--rev-frac", type=float, default=0.5)
+ap.add_argument("--lib", default="", help="alternative library file name under portello_amd/")
 ap.add_argument("--timing", action="store_true", help="use the instrumented build and print per-phase cycles")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
+if args.lib:
+    api.load_library(os.path.join(ROOT, "portello_amd", args.lib))
 if args.timing:
     import ctypes as C
     from portello_amd import build
