@@ -250,3 +250,48 @@ def test_lane_per_item_kernel_when_enabled(oracle, monkeypatch):
             _assert_same(oracle.liftover_batch(fix, fb, stages, 1), fe.liftover_batch(fb, stages), f"lanes_fuzz_{seed}_{stages}")
         fe.close()
         fi.close()
+
+
+def test_boundary_validation_errors():
+    """the host-buffer entry point validates what it is handed and reports a status instead of computing garbage"""
+    w = synth.generate(synth.config("tiny", n_reads=20, seed=208))
+    ix, b = w.index_data(), w.batch_data()
+    index = api.Index(ix)
+    eng = api.Engine(index)
+    import copy
+
+    bad = copy.deepcopy(b)
+    bad.seg_pos = bad.seg_pos.copy()
+    bad.seg_pos[0] = 2**31 + 5
+    with pytest.raises(api.PortelloError) as e:
+        eng.liftover_batch(bad)
+    assert e.value.status == abi.PLO_ERR_RANGE
+    bad = copy.deepcopy(b)
+    bad.cigar = bad.cigar.copy()
+    bad.cigar[3] = (5 << 4) | 11
+    with pytest.raises(api.PortelloError) as e:
+        eng.liftover_batch(bad)
+    assert e.value.status == abi.PLO_ERR_RANGE
+    bad = copy.deepcopy(b)
+    bad.seg_contig = bad.seg_contig.copy()
+    bad.seg_contig[0] = 10_000
+    with pytest.raises(api.PortelloError) as e:
+        eng.liftover_batch(bad)
+    assert e.value.status == abi.PLO_ERR_INVALID_ARG
+    bad = copy.deepcopy(b)
+    bad.item_seg = np.array([0], dtype=np.uint32)
+    bad.item_cseg = np.array([99], dtype=np.uint32)
+    with pytest.raises(api.PortelloError) as e:
+        eng.liftover_batch(bad)
+    assert e.value.status == abi.PLO_ERR_INVALID_ARG
+    # the context is still usable afterwards
+    assert eng.liftover_batch(b).n_items > 0
+    eng.close()
+    index.close()
+    # index descriptors are validated too
+    ixb = w.index_data()
+    ixb.seg_chrom_index = ixb.seg_chrom_index.copy()
+    ixb.seg_chrom_index[0] = 77
+    with pytest.raises(api.PortelloError) as e:
+        api.Index(ixb)
+    assert e.value.status == abi.PLO_ERR_INVALID_ARG
