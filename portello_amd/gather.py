@@ -2,8 +2,8 @@
 
 Reads shard across GPUs with no data-path collective; after a batch every rank holds compact result records
 (per item: read segment, contig segment, status/flags, chromosome, position, CIGAR).  They are gathered to the writer
-rank with direct peer -> root ``send``/``recv`` (one xGMI link per peer; a ring all-gather would be per-link bound
-for no benefit) after an 8-byte-per-rank size exchange.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the
+rank with direct peer -> root ``isend``/``irecv`` posted as one group (one xGMI link per peer, all links concurrently;
+a ring all-gather would be per-link bound for no benefit) after a 24-byte-per-rank size exchange.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the
 same code runs on CPU tensors over gloo (tests).
 """
 from __future__ import annotations
@@ -93,20 +93,27 @@ def gather_payloads(t: Dict[str, torch.Tensor], dist, rank: int, world: int, roo
     sizes = torch.tensor([t["item_seg"].numel(), t["cigar"].numel(), payload.numel()], dtype=torch.int64, device=dev)
     all_sizes = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
+    # all transfers of the step are posted as ONE group so that the peers' links run concurrently into the root
     if rank != root:
         if payload.numel():
-            dist.send(payload, dst=root)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, root)]):
+                q.wait()
         return None
+    bufs, ops = {}, []
+    for r in range(world):
+        if r == root:
+            continue
+        nb = int(all_sizes[r][2].item())
+        bufs[r] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        if nb:
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     res: List[Dict[str, torch.Tensor]] = []
     for r in range(world):
-        ni, nc, nb = (int(x) for x in all_sizes[r].tolist())
-        if r == root:
-            res.append(unpack(payload, ni, nc))
-            continue
-        buf = torch.empty(nb, dtype=torch.uint8, device=dev)
-        if nb:
-            dist.recv(buf, src=r)
-        res.append(unpack(buf, ni, nc))
+        ni, nc, _ = (int(x) for x in all_sizes[r].tolist())
+        res.append(unpack(payload if r == root else bufs[r], ni, nc))
     return res
 
 
