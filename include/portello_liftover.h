@@ -196,7 +196,8 @@ typedef struct plo_timing {
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);
 void plo_index_destroy(plo_index *index);
 /* number of block-map entries of contig segment `global_seg` (= contig_seg_off[contig] + i), and a copy of them
-   (keys = contig positions, vals = reference positions, INT64_MIN for None) for inspection/tests */
+   (keys = contig positions, vals = reference positions, INT64_MIN for None), downloaded from the device, for
+   inspection/tests */
 plo_status plo_index_segment_map(const plo_index *index, uint32_t global_seg, uint32_t cap, int64_t *keys,
                                  int64_t *vals, uint32_t *n_entries);
 

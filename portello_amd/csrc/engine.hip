@@ -48,6 +48,18 @@ __global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stage
     enumerate_segment(ix, bt, s, &wk, stages, seg_off[s], seg_reflen);
 }
 
+// Block maps of the contig segments, built on the device at index creation: thread per contig split segment walks its
+// contig->reference CIGAR (build_segment_map, enumerate.hpp); count pass, host prefix sum (a few thousand segments),
+// emit pass.
+__global__ void k_map_build(const uint32_t *seg_cigar, const uint32_t *seg_cigar_off, const int64_t *seg_pos, uint32_t n_segments,
+                            const uint32_t *kv_off, KV *kv, int *counts) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_segments) return;
+    uint32_t c0 = seg_cigar_off[g], c1 = seg_cigar_off[g + 1];
+    int cnt = build_segment_map(seg_cigar + c0, c1 - c0, (long long)seg_pos[g], kv ? kv + kv_off[g] : nullptr);
+    if (counts) counts[g] = cnt;
+}
+
 // explicit item list: thread per item
 __global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *in_seg, const uint32_t *in_cseg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,7 +454,7 @@ plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **
     plo_index *ix = new plo_index();
     ix->device = device;
     std::string err;
-    plo_status st = pack_index(desc, ix->host, err);
+    plo_status st = pack_index(desc, ix->host, err, /*build_kv=*/false);
     if (st != PLO_OK) {
         g_index_err = err;
         delete ix;
@@ -457,8 +469,57 @@ plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **
     };
     DevIndex &d = ix->d;
     const PackedIndex &h = ix->host;
-    if (upload(ix->owned, h.kv, &d.kv) != hipSuccess) return fail(PLO_ERR_HIP);
-    if (upload(ix->owned, h.cs_kv_off, &d.cs_kv_off) != hipSuccess) return fail(PLO_ERR_HIP);
+    {   // block maps: built on the device from the contig->reference CIGARs
+        uint32_t ns = desc->n_segments;
+        std::vector<uint32_t> cg(desc->seg_cigar, desc->seg_cigar + (ns ? desc->seg_cigar_off[ns] : 0));
+        std::vector<uint32_t> cgoff(desc->seg_cigar_off, desc->seg_cigar_off + (ns ? ns + 1 : 0));
+        if (!ns) cgoff.assign(1, 0);
+        std::vector<int64_t> spos(desc->seg_pos, desc->seg_pos + ns);
+        std::vector<void *> tmp;
+        const uint32_t *d_cg = nullptr, *d_cgoff = nullptr;
+        const int64_t *d_pos = nullptr;
+        const int *d_cnt = nullptr;
+        std::vector<int> cnt(std::max(1u, ns), 0);
+        auto drop_tmp = [&]() {
+            for (void *p : tmp) (void)hipFree(p);
+        };
+        if (upload(tmp, cg, &d_cg) != hipSuccess || upload(tmp, cgoff, &d_cgoff) != hipSuccess || upload(tmp, spos, &d_pos) != hipSuccess ||
+            upload(tmp, cnt, &d_cnt) != hipSuccess) {
+            drop_tmp();
+            return fail(PLO_ERR_HIP);
+        }
+        if (ns) hipLaunchKernelGGL(k_map_build, dim3((ns + 63) / 64), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, (const uint32_t *)nullptr,
+                                   (KV *)nullptr, (int *)d_cnt);
+        if (hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            drop_tmp();
+            return fail(PLO_ERR_HIP);
+        }
+        ix->host.cs_kv_off.assign(ns + 1, 0);
+        for (uint32_t g = 0; g < ns; ++g) {
+            if (cnt[g] < 0) {
+                g_index_err = "contig segment coordinate outside the 31-bit BAM range or invalid CIGAR op code";
+                drop_tmp();
+                return fail(PLO_ERR_RANGE);
+            }
+            ix->host.cs_kv_off[g + 1] = ix->host.cs_kv_off[g] + (uint32_t)cnt[g];
+        }
+        if (upload(ix->owned, h.cs_kv_off, &d.cs_kv_off) != hipSuccess) {
+            drop_tmp();
+            return fail(PLO_ERR_HIP);
+        }
+        void *kvp = nullptr;
+        if (hipMalloc(&kvp, std::max<size_t>((size_t)h.cs_kv_off[ns] * sizeof(KV), 16)) != hipSuccess) {
+            drop_tmp();
+            return fail(PLO_ERR_OUT_OF_MEMORY);
+        }
+        ix->owned.push_back(kvp);
+        d.kv = (const KV *)kvp;
+        if (ns) hipLaunchKernelGGL(k_map_build, dim3((ns + 63) / 64), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, d.cs_kv_off, (KV *)kvp,
+                                   (int *)nullptr);
+        hipError_t e = hipDeviceSynchronize();
+        drop_tmp();
+        if (e != hipSuccess) return fail(PLO_ERR_HIP);
+    }
     if (upload(ix->owned, h.cs_chrom, &d.cs_chrom) != hipSuccess) return fail(PLO_ERR_HIP);
     if (upload(ix->owned, h.cs_is_fwd, &d.cs_is_fwd) != hipSuccess) return fail(PLO_ERR_HIP);
     if (upload(ix->owned, h.cs_mapq, &d.cs_mapq) != hipSuccess) return fail(PLO_ERR_HIP);
@@ -519,10 +580,13 @@ plo_status plo_index_segment_map(const plo_index *ix, uint32_t g, uint32_t cap, 
     if (!ix || !n || g >= ix->d.n_segments) return PLO_ERR_INVALID_ARG;
     uint32_t k0 = ix->host.cs_kv_off[g], k1 = ix->host.cs_kv_off[g + 1];
     *n = k1 - k0;
-    if (keys && vals) {
+    if (keys && vals && k1 > k0) {
+        if (hipSetDevice(ix->device) != hipSuccess) return PLO_ERR_NO_DEVICE;
+        std::vector<KV> tmp(k1 - k0);  // the maps live on the device only
+        if (hipMemcpy(tmp.data(), ix->d.kv + k0, tmp.size() * sizeof(KV), hipMemcpyDeviceToHost) != hipSuccess) return PLO_ERR_HIP;
         for (uint32_t i = 0; i < std::min(cap, k1 - k0); ++i) {
-            keys[i] = ix->host.kv[k0 + i].key;
-            vals[i] = ix->host.kv[k0 + i].val == NONE32 ? INT64_MIN : (int64_t)ix->host.kv[k0 + i].val;
+            keys[i] = tmp[i].key;
+            vals[i] = tmp[i].val == NONE32 ? INT64_MIN : (int64_t)tmp[i].val;
         }
     }
     return PLO_OK;

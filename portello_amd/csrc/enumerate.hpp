@@ -41,6 +41,55 @@ PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first inde
     return lo;
 }
 
+// Block map of one contig split segment: get_read_segment_to_ref_pos_tree_map
+// (lib/rust-vc-utils/src/bam_utils/read_to_ref_map.rs:101-137, ignore_hard_clip = false as at
+// src/contig_alignment_scanner/mod.rs:98-102).  Every flush of a match run inserts {start -> Some(ref), end -> None};
+// keys arrive in non-decreasing order, so BTreeMap::insert's overwrite can only hit the entry appended last (a
+// deletion in the contig->ref alignment: the previous block's None is replaced by the next block's Some).
+// out == nullptr: count only.  Returns the number of entries, or -1 if a coordinate leaves the 31-bit range / an op
+// code is invalid.
+PLO_HD int build_segment_map(const uint32_t *cigar, uint32_t n, long long ref_pos, KV *out) {
+    long long read_pos = 0, match_len = 0;
+    int cnt = 0;
+    int last_key = -1;
+    bool bad = false;
+    for (uint32_t i = 0; i <= n; ++i) {
+        uint32_t c = i < n ? cigar[i] : 4u;  // a trailing pseudo soft clip of length 0 performs the final flush (:134)
+        int t = (int)(c & 15u);
+        long long len = (long long)(c >> 4);
+        if (t > 8) bad = true;
+        bool is_m = (t == OP_M || t == OP_EQ || t == OP_X);
+        if (is_m) {
+            match_len += len;
+        } else if (match_len > 0) {  // update_map (:105-113)
+            if (read_pos > 0x7ffffff0LL || ref_pos > 0x7ffffff0LL || ref_pos - match_len < 0) {
+                bad = true;
+            } else {
+                int k0 = (int)(read_pos - match_len), v0 = (int)(ref_pos - match_len), k1 = (int)read_pos;
+                if (cnt > 0 && last_key == k0) {
+                    if (out) out[cnt - 1].val = v0;
+                } else {
+                    if (out) {
+                        out[cnt].key = k0;
+                        out[cnt].val = v0;
+                    }
+                    ++cnt;
+                }
+                if (out) {
+                    out[cnt].key = k1;
+                    out[cnt].val = NONE32;
+                }
+                ++cnt;
+                last_key = k1;
+            }
+            match_len = 0;
+        }
+        if ((0x1B3 >> t) & 1) read_pos += len;  // M I S H = X
+        if ((0x18D >> t) & 1) ref_pos += len;   // M D N = X
+    }
+    return bad ? -1 : cnt;
+}
+
 // Resolves everything the tile kernel needs to know about item i = (read segment seg, contig segment cseg):
 // the caller glue of get_liftover_alignment_for_read_and_contig_segment (src/read_alignment_scanner.rs:146-176) --
 // need_flipped (:153-157), rev_pos (:164-166) -- plus the window of the block map the item can touch.

@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "../../include/portello_liftover.h"
+#include <plo_wave.hpp>
+
+#include "enumerate.hpp"
 #include "lift_types.hpp"
 
 namespace plo {
@@ -24,27 +27,7 @@ struct PackedIndex {
 
 inline bool fits31(int64_t v) { return v >= 0 && v <= 0x7ffffff0LL; }
 
-// BTreeMap::insert on a sorted array: overwrite on equal key (read_to_ref_map.rs:105-112)
-inline void kv_insert(std::vector<KV> &m, size_t begin, int key, int val) {
-    size_t lo = begin, hi = m.size();
-    while (lo < hi) {
-        size_t mid = (lo + hi) / 2;
-        if (m[mid].key < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    if (lo < m.size() && m[lo].key == key) {
-        m[lo].val = val;
-        return;
-    }
-    KV e;
-    e.key = key;
-    e.val = val;
-    m.insert(m.begin() + (long)lo, e);
-}
-
-inline plo_status pack_index(const plo_index_desc *d, PackedIndex &out, std::string &err) {
+inline plo_status pack_index(const plo_index_desc *d, PackedIndex &out, std::string &err, bool build_kv = true) {
     if (!d || (d->n_contigs && (!d->contig_len || !d->contig_seg_off)) ||
         (d->n_segments && (!d->seg_chrom_index || !d->seg_pos || !d->seg_is_fwd_strand || !d->seg_mapq || !d->seg_seq_order_start ||
                            !d->seg_seq_order_end || !d->seg_cigar_off || (!d->seg_cigar && d->seg_cigar_off[d->n_segments]))) ||
@@ -103,48 +86,22 @@ inline plo_status pack_index(const plo_index_desc *d, PackedIndex &out, std::str
         out.cs_start[g] = (int)d->seg_seq_order_start[g];
         out.cs_end[g] = (int)d->seg_seq_order_end[g];
 
-        // get_read_segment_to_ref_pos_tree_map (read_to_ref_map.rs:101-137)
-        size_t begin = out.kv.size();
-        out.cs_kv_off[g] = (uint32_t)begin;
-        int64_t ref_pos = d->seg_pos[g];
-        int64_t read_pos = 0, match_len = 0;
+        // get_read_segment_to_ref_pos_tree_map: the same build_segment_map the device kernels run (enumerate.hpp)
         uint32_t c0 = d->seg_cigar_off[g], c1 = d->seg_cigar_off[g + 1];
         if (c1 < c0) {
             err = "seg_cigar_off not monotone";
             return PLO_ERR_INVALID_ARG;
         }
-        bool range_err = false;
-        auto update_map = [&]() {
-            if (match_len > 0) {
-                if (!fits31(read_pos) || !fits31(ref_pos)) {
-                    range_err = true;
-                } else {
-                    kv_insert(out.kv, begin, (int)(read_pos - match_len), (int)(ref_pos - match_len));
-                    kv_insert(out.kv, begin, (int)read_pos, NONE32);
-                }
-                match_len = 0;
-            }
-        };
-        for (uint32_t i = c0; i < c1; ++i) {
-            uint32_t c = d->seg_cigar[i];
-            int t = (int)(c & 15u);
-            int64_t len = (int64_t)(c >> 4);
-            if (t > 8) {
-                err = "invalid CIGAR op code in contig segment";
+        out.cs_kv_off[g] = (uint32_t)out.kv.size();
+        if (build_kv) {
+            int cnt = build_segment_map(d->seg_cigar + c0, c1 - c0, d->seg_pos[g], nullptr);
+            if (cnt < 0) {
+                err = "contig segment coordinate outside the 31-bit BAM range or invalid CIGAR op code";
                 return PLO_ERR_RANGE;
             }
-            bool is_m = (t == OP_M || t == OP_EQ || t == OP_X);
-            if (is_m)
-                match_len += len;
-            else
-                update_map();
-            if ((0x1B3 >> t) & 1) read_pos += len;  // M I S H = X (ignore_hard_clip = false)
-            if ((0x18D >> t) & 1) ref_pos += len;   // M D N = X
-        }
-        update_map();
-        if (range_err) {
-            err = "contig segment coordinate outside the 31-bit BAM range";
-            return PLO_ERR_RANGE;
+            size_t begin = out.kv.size();
+            out.kv.resize(begin + (size_t)cnt);
+            build_segment_map(d->seg_cigar + c0, c1 - c0, d->seg_pos[g], out.kv.data() + begin);
         }
     }
     out.cs_kv_off[ns] = (uint32_t)out.kv.size();

@@ -1207,8 +1207,9 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Tile assignment: tile w owns the items whose exclusive input-op prefix lies in [w*window, (w+1)*window), i.e. the
-// flattened input op stream is cut into windows and every item goes to the window its first op falls in.
+// Tile assignment (k_tile_bounds): the tiled items, in class order, form one flattened input-op stream that is cut into
+// windows of `window` ops; every item goes to the window its first op falls in.  A window with more than 64 items is
+// processed in several passes.
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t tile, int window,
                          int big_thresh, TileMem m, WaveCtx &ctx) {

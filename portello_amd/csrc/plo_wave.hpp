@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #define PLO_DEV __device__ __forceinline__
+#define PLO_HD __host__ __device__ __forceinline__
 #define PLO_WAVE 64
 
 namespace wv {

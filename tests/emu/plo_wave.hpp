@@ -16,6 +16,7 @@
 #include <vector>
 
 #define PLO_DEV inline
+#define PLO_HD inline
 #define PLO_WAVE 64
 #define PLO_EMULATOR 1
 
