@@ -34,10 +34,26 @@ using namespace plo;
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
 
-__global__ void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= bt.n_segs) return;
-    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0, seg_reflen);
+// Eight lanes per read segment: the reference span (get_cigar_ref_offset) is a strided partial sum per lane + a 3-step
+// xor-shuffle reduction, so that one load instruction covers 32 contiguous bytes of every segment's CIGAR; lane 0 of the
+// group then does the overlap test against the contig's segments.
+__global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = t >> 3, sub = t & 7u;
+    long long part = 0;
+    if (s < bt.n_segs) {
+        uint32_t c0 = bt.seg_cigar_off[s], c1 = bt.seg_cigar_off[s + 1];
+        for (uint32_t i = c0 + sub; i < c1; i += 8) {
+            uint32_t c = bt.cigar[i];
+            if ((0x18D >> (c & 15u)) & 1) part += (long long)(c >> 4);
+        }
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (s >= bt.n_segs || sub != 0) return;
+    seg_reflen[s] = (int)part;
+    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0, seg_reflen, /*have_ref_len=*/true);
 }
 
 // thread per read segment: resolve the descriptors of its items (build_item_desc) at their scanned offsets
@@ -739,8 +755,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
         if (ns)
-            hipLaunchKernelGGL(k_seg_count, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>(),
-                               c->seg_reflen.as<int>());
+            hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * 8 + 255) / 256)), dim3(256), 0, st, ix, bt,
+                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
         uint32_t *h = c->h_counters.as<uint32_t>();

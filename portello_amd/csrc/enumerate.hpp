@@ -146,13 +146,13 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
 // Counts (and, when wk != nullptr, resolves at out_off) the items of one read segment, in contig-segment order.
 // `ref_len_cache`: per-segment reference spans; written by the counting pass (wk == nullptr), read by the emit pass.
 PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint32_t seg, const DevWork *wk, uint32_t stages,
-                                   uint32_t out_off, int *ref_len_cache = nullptr) {
+                                   uint32_t out_off, int *ref_len_cache = nullptr, bool have_ref_len = false) {
     uint32_t contig = bt.seg_contig[seg];
     if (contig >= ix.n_contigs) return 0;
     uint32_t g0 = ix.contig_seg_off[contig], g1 = ix.contig_seg_off[contig + 1];
     if (g0 == g1) return 0;  // contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
     long long ref_len;
-    if (wk && ref_len_cache) {
+    if ((wk || have_ref_len) && ref_len_cache) {
         ref_len = ref_len_cache[seg];
     } else {
         ref_len = segment_ref_len(bt, seg);
