@@ -197,7 +197,12 @@ constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its o
 
 // Persistent: the grid is sized to the resident capacity of the chip and every wave strides over the tiles, keeping its
 // output slab and statistics in registers (WaveCtx).
-__global__ __launch_bounds__(TILE_WAVES * 64) void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+#ifdef PLO_TILE_WPE
+#define PLO_TILE_OCC __attribute__((amdgpu_waves_per_eu(PLO_TILE_WPE, PLO_TILE_WPE)))
+#else
+#define PLO_TILE_OCC
+#endif
+__global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
                                                                uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                uint32_t lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -422,7 +427,10 @@ struct plo_ctx {
     plo_timing timing{};
     unsigned long long phase_cycles[12] = {0};
     // tuning
-    int window = 160, big_thresh = 176, cap = 512;
+    // cap sets the LDS slice of a wave (34 B per element + 1.25 KB): 320 -> 12,160 B -> 3 four-wave blocks = 12 waves per CU,
+    // which is also what the kernel's VGPR budget allows; measured on MI355X (wgs30x, 2M reads): cap 512 (8 waves/CU) 8.34 ms,
+    // cap 384 (still 2 blocks) 8.33 ms, cap 320 6.26 ms, cap 256 6.27 ms + overflow items.
+    int window = 160, big_thresh = 176, cap = 320;
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
     // routing threshold of the lane-per-item kernel (k_lift_lanes).  Measured on MI355X (wgs30x): forward items run 1.6x
@@ -634,7 +642,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     }
     (void)hipFuncSetAttribute((const void *)k_lift_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (getenv("PLO_DEBUG")) {
-        for (int cap : {384, 512, 768, 960}) {
+        for (int cap : {256, 320, 384, 512}) {
             int nb = -1;
             size_t lds = ((tile_mem_bytes(cap) + 15) & ~(size_t)15) * TILE_WAVES;
             hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_lift_tiles, TILE_WAVES * 64, lds);
