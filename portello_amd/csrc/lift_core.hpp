@@ -281,84 +281,105 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
     wv::sync();
 }
 
-// left homology of get_indel_breakend_homology_info (lib/rust-vc-utils/src/indel_breakend_homology.rs:32-47),
-// capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133).
-// The byte probes are random accesses into HBM-resident sequences: they are issued 8 at a time (independent loads,
-// one latency per batch) instead of one dependent load per compared base.
-PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound,
-                          bool &panic, int &probes) {
-    int re = rs + del, qe = qs + ins;
-    int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
-    int maxk = wv::imin(max_left, bound);
+// ---- sequence comparison ------------------------------------------------------------------------------------------
+// The byte probes of the homology / trimming loops are random accesses into HBM-resident sequences.  They are made 16
+// bases at a time: both 16-base windows are fetched as aligned dwords (8 loads, ONE memory round trip), the read side is
+// decoded 4 bases per v_perm_b32 (the 16-entry "=ACMGRSVTWYHKDBN" table, or its complement for a flipped read, split into
+// two 8-byte halves), and the XOR of the two windows gives the match run with one clz / ctz.
+
+PLO_DEV unsigned comp4(unsigned w) {  // comp_base on the four ASCII bytes of w
+    return (unsigned)comp_base((int)(w & 0xffu)) | ((unsigned)comp_base((int)((w >> 8) & 0xffu)) << 8) |
+           ((unsigned)comp_base((int)((w >> 16) & 0xffu)) << 16) | ((unsigned)comp_base((int)(w >> 24)) << 24);
+}
+
+// X byte t (little-endian over X[0..3]) = ref[r0 + t] ^ read_base(rd, q0 + t), t = 0..15.
+// Returns false when a window does not lie inside its buffer: the caller then compares byte-wise.
+PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, long long r0, const ReadSeq &rd, long long q0, unsigned X[4]) {
+    if (r0 < 0 || q0 < 0 || q0 + 16 > (long long)rd.len) return false;
+    const unsigned rsh = (unsigned)(((unsigned long long)(uintptr_t)ref + (unsigned long long)r0) & 3ull);
+    if (r0 - (long long)rsh < 0 || r0 - (long long)rsh + 20 > (long long)ref_len) return false;
+    // read bases q0 .. q0+15 are the stored positions jmin .. jmin+15 (in reverse order when flipped)
+    const long long jmin = rd.flip ? (long long)rd.len - q0 - 16 : q0;
+    const bool bam4 = rd.fmt == PLO_SEQ_BAM4;
+    const long long b0 = bam4 ? (jmin >> 1) : jmin;  // first byte of the read window
+    const unsigned qsh = (unsigned)(((unsigned long long)(uintptr_t)rd.p + (unsigned long long)b0) & 3ull);
+    const int qwords = bam4 ? 3 : 5;
+    if (b0 - (long long)qsh < rd.lo || b0 - (long long)qsh + 4 * qwords > rd.hi) return false;
+    const uint32_t *pr = (const uint32_t *)(ref + (r0 - (long long)rsh));
+    const uint32_t *pq = (const uint32_t *)(rd.p + (b0 - (long long)qsh));
+    unsigned wr[5], wq[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) wr[u] = pr[u];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) wq[u] = u < qwords ? pq[u] : 0u;
+    unsigned D[4];  // stored bases jmin .. jmin+15 as ASCII (complemented when flipped), base jmin+t at byte t
+    if (bam4) {
+        // nibble s = par + t of the byte stream: byte s>>1, high nibble when s is even
+        unsigned S[5];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            unsigned Q = wv::align_bytes(wq[q + 1], wq[q], qsh);
+            unsigned H = (Q >> 4) & 0x0f0f0f0fu, L = Q & 0x0f0f0f0fu;
+            S[2 * q] = wv::perm_bytes(L, H, 0x05010400u);  // nibbles 8q .. 8q+3, one per byte
+            if (2 * q + 1 < 5) S[2 * q + 1] = wv::perm_bytes(L, H, 0x07030602u);
+        }
+        const unsigned par = (unsigned)(jmin & 1);
+        // "=ACMGRSVTWYHKDBN" and its comp_base image "NTGNCNNNANNNNNNN", 8 entries per 64-bit half
+        const unsigned long long lo = rd.flip ? 0x4e4e4e434e47544eull : 0x565352474d43413dull;
+        const unsigned long long hi = rd.flip ? 0x4e4e4e4e4e4e4e41ull : 0x4e42444b48595754ull;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            unsigned T = wv::align_bytes(S[v + 1], S[v], par);
+            unsigned idx = T & 0x07070707u;
+            unsigned dl = wv::perm_bytes((unsigned)(lo >> 32), (unsigned)lo, idx);
+            unsigned dh = wv::perm_bytes((unsigned)(hi >> 32), (unsigned)hi, idx);
+            unsigned mk = ((T >> 3) & 0x01010101u) * 0xffu;
+            D[v] = (dh & mk) | (dl & ~mk);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            D[v] = wv::align_bytes(wq[v + 1], wq[v], qsh);
+            if (rd.flip) D[v] = comp4(D[v]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned R = wv::align_bytes(wr[u + 1], wr[u], rsh);
+        unsigned B = rd.flip ? wv::perm_bytes(0u, D[3 - u], 0x00010203u) : D[u];
+        X[u] = R ^ B;
+    }
+    return true;
+}
+PLO_DEV int zero_bytes_from_top(const unsigned X[4]) {  // t = 15, 14, ...
+    if (X[3]) return wv::clz32(X[3]) >> 3;
+    if (X[2]) return 4 + (wv::clz32(X[2]) >> 3);
+    if (X[1]) return 8 + (wv::clz32(X[1]) >> 3);
+    if (X[0]) return 12 + (wv::clz32(X[0]) >> 3);
+    return 16;
+}
+PLO_DEV int zero_bytes_from_bottom(const unsigned X[4]) {  // t = 0, 1, ...
+    if (X[0]) return wv::ctz32(X[0]) >> 3;
+    if (X[1]) return 4 + (wv::ctz32(X[1]) >> 3);
+    if (X[2]) return 8 + (wv::ctz32(X[2]) >> 3);
+    if (X[3]) return 12 + (wv::ctz32(X[3]) >> 3);
+    return 16;
+}
+
+// number of k in [0, maxk) with ref[re-1-k] == read[qe-1-k], stopping at the first mismatch.  All indices are valid
+// (checked by the callers); `probes` counts the compared base pairs like the reference's loop would.
+PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, const ReadSeq &rd, int qe, int maxk, int &probes) {
     int k = 0;
-    if (max_left > 0) {
-        // the first probe has the largest indices; out of bounds = slice-index panic in the reference (:38-39)
-        if (re - 1 >= ref_len || qe - 1 >= rd.len) {
-            panic = true;
-            return 0;
-        }
-    }
-    // First round: 16 reference bytes and 16 read bases fetched as aligned dwords (8 loads, ONE memory round trip) and
-    // compared in registers; homologies longer than 16 fall through to the byte loop below.
-    {
-        const int n16 = wv::imin(16, maxk);
-        const long long r0 = (long long)re - 16;  // window = ref[re-16 .. re)
-        const unsigned rsh = (unsigned)(((unsigned long long)(uintptr_t)ref + (unsigned long long)r0) & 3ull);
-        // read bases qe-1-k, k = 0..15, are the packed/ASCII positions j(k) = flip ? len-qe+k : qe-1-k
-        const long long jmin = rd.flip ? (long long)rd.len - qe : (long long)qe - 16;
-        const long long b0 = rd.fmt == PLO_SEQ_BAM4 ? (jmin >> 1) : jmin;  // first byte of the read window
-        const unsigned qsh = (unsigned)(((unsigned long long)(uintptr_t)rd.p + (unsigned long long)b0) & 3ull);
-        const int qwords = rd.fmt == PLO_SEQ_BAM4 ? 3 : 5;
-        if (n16 > 0 && qe >= 16 && r0 - (long long)rsh >= 0 && r0 - (long long)rsh + 20 <= (long long)ref_len &&
-            b0 - (long long)qsh >= rd.lo && b0 - (long long)qsh + 4 * qwords <= rd.hi) {
-            const uint32_t *pr = (const uint32_t *)(ref + (r0 - (long long)rsh));
-            const uint32_t *pq = (const uint32_t *)(rd.p + (b0 - (long long)qsh));
-            unsigned wr[5], wq[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) wr[u] = pr[u];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) wq[u] = u < qwords ? pq[u] : 0u;
-            // realign once (funnel shifts) so that every later index is a compile-time constant
-            unsigned R[4], Q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                R[u] = (unsigned)((((unsigned long long)wr[u + 1] << 32) | wr[u]) >> (8 * rsh));  // ref[re-16+4u ..]
-                Q[u] = (unsigned)((((unsigned long long)wq[u + 1] << 32) | wq[u]) >> (8 * qsh));  // read window bytes
-            }
-            unsigned N0 = 0, N1 = 0;  // 4-bit: bases jmin .. jmin+15 as a linear nibble stream (base t at nibble t)
-            if (rd.fmt == PLO_SEQ_BAM4) {
-                unsigned s0 = ((Q[0] & 0x0f0f0f0fu) << 4) | ((Q[0] >> 4) & 0x0f0f0f0fu);
-                unsigned s1 = ((Q[1] & 0x0f0f0f0fu) << 4) | ((Q[1] >> 4) & 0x0f0f0f0fu);
-                unsigned s2 = ((Q[2] & 0x0f0f0f0fu) << 4) | ((Q[2] >> 4) & 0x0f0f0f0fu);
-                unsigned par = (unsigned)(jmin & 1);
-                N0 = (unsigned)((((unsigned long long)s1 << 32) | s0) >> (4 * par));
-                N1 = (unsigned)((((unsigned long long)s2 << 32) | s1) >> (4 * par));
-            }
-            int m = n16;
-#pragma unroll
-            for (int kk = 15; kk >= 0; --kk) {
-                unsigned a = (R[(15 - kk) >> 2] >> (8 * ((15 - kk) & 3))) & 0xffu;  // ref[re-1-kk]
-                unsigned bch;
-                if (rd.fmt == PLO_SEQ_BAM4) {
-                    unsigned nf = ((kk < 8 ? N0 : N1) >> (4 * (kk & 7))) & 15u;                  // base jmin+kk      (flip)
-                    unsigned nr = (((15 - kk) < 8 ? N0 : N1) >> (4 * ((15 - kk) & 7))) & 15u;    // base jmin+15-kk
-                    unsigned nib = rd.flip ? nf : nr;
-                    const unsigned long long lo = 0x565352474d43413dull, hi = 0x4e42444b48595754ull;
-                    bch = (unsigned)(((nib & 8) ? hi : lo) >> ((nib & 7) * 8)) & 0xffu;
-                } else {
-                    unsigned bf = (Q[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
-                    unsigned br = (Q[(15 - kk) >> 2] >> (8 * ((15 - kk) & 3))) & 0xffu;
-                    bch = rd.flip ? bf : br;
-                }
-                if (rd.flip) bch = (unsigned)comp_base((int)bch);
-                if (kk < n16 && a != bch) m = kk;
-            }
-            probes += wv::imin(m + 1, n16);
-            k = m;
-            if (m < n16) return k;
-        }
-    }
     while (k < maxk) {
+        unsigned X[4];
+        if (!xor_window16(ref, ref_len, (long long)re - k - 16, rd, (long long)qe - k - 16, X)) break;
+        int n = wv::imin(16, maxk - k);
+        int m = wv::imin(zero_bytes_from_top(X), n);
+        probes += wv::imin(m + 1, n);
+        k += m;
+        if (m < n) return k;
+    }
+    while (k < maxk) {  // window outside a buffer (first / last bases of a sequence): 8 independent byte probes a round
         int n = wv::imin(8, maxk - k);
         int a[8], b[8];
 #pragma unroll
@@ -376,6 +397,54 @@ PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, cons
         if (adv < n) break;
     }
     return k;
+}
+// number of k in [0, maxk) with ref[rs+k] == read[qs+k], stopping at the first mismatch
+PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, const ReadSeq &rd, int qs, int maxk, int &probes) {
+    int k = 0;
+    while (k < maxk) {
+        unsigned X[4];
+        if (!xor_window16(ref, ref_len, (long long)rs + k, rd, (long long)qs + k, X)) break;
+        int n = wv::imin(16, maxk - k);
+        int m = wv::imin(zero_bytes_from_bottom(X), n);
+        probes += wv::imin(m + 1, n);
+        k += m;
+        if (m < n) return k;
+    }
+    while (k < maxk) {
+        int n = wv::imin(8, maxk - k);
+        int a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int jj = j < n ? j : 0;
+            a[j] = ref[rs + k + jj];
+            b[j] = read_base(rd, qs + k + jj);
+        }
+        int adv = n;
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+            if (j < n && a[j] != b[j]) adv = j;
+        probes += wv::imin(adv + 1, n);
+        k += adv;
+        if (adv < n) break;
+    }
+    return k;
+}
+
+// left homology of get_indel_breakend_homology_info (lib/rust-vc-utils/src/indel_breakend_homology.rs:32-47),
+// capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133).
+PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound,
+                          bool &panic, int &probes) {
+    int re = rs + del, qe = qs + ins;
+    int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
+    int maxk = wv::imin(max_left, bound);
+    if (max_left > 0) {
+        // the first probe has the largest indices; out of bounds = slice-index panic in the reference (:38-39)
+        if (re - 1 >= ref_len || qe - 1 >= rd.len) {
+            panic = true;
+            return 0;
+        }
+    }
+    return match_run_back(ref, ref_len, re, rd, qe, maxk, probes);
 }
 
 // State a (persistent) wave carries from tile to tile.  All fields except the per-lane statistics are wave-uniform.
@@ -1006,46 +1075,13 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         wv::atomic_or(&m.itp[id], 1);  // slice index out of bounds: the reference panics (:58-60)
                     } else {
                         int pre = 0, post = 0, cmp = 0;
-                        for (;;) {  // :55-68, probes issued 8 at a time
-                            int n = wv::imin(8, wv::imin(del, ins));
-                            if (n <= 0) break;
-                            int a[8], b[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                int jj = j < n ? j : 0;
-                                a[j] = ref[rs0 + del - 1 - jj];
-                                b[j] = read_base(rd, qs0 + ins - 1 - jj);
-                            }
-                            int adv = n;
-#pragma unroll
-                            for (int j = 7; j >= 0; --j)
-                                if (j < n && a[j] != b[j]) adv = j;
-                            cmp += wv::imin(adv + 1, n);
-                            del -= adv;
-                            ins -= adv;
-                            post += adv;
-                            if (adv < n) break;
-                        }
-                        for (;;) {  // :71-85
-                            int n = wv::imin(8, wv::imin(del, ins));
-                            if (n <= 0) break;
-                            int a[8], b[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                int jj = j < n ? j : 0;
-                                a[j] = ref[rs0 + pre + jj];
-                                b[j] = read_base(rd, qs0 + pre + jj);
-                            }
-                            int adv = n;
-#pragma unroll
-                            for (int j = 7; j >= 0; --j)
-                                if (j < n && a[j] != b[j]) adv = j;
-                            cmp += wv::imin(adv + 1, n);
-                            del -= adv;
-                            ins -= adv;
-                            pre += adv;
-                            if (adv < n) break;
-                        }
+                        // :55-68 trailing bases shared by the inserted and the deleted sequence, then :71-85 leading ones
+                        post = match_run_back(ref, i_rlen, rs0 + del, rd, qs0 + ins, wv::imin(del, ins), cmp);
+                        del -= post;
+                        ins -= post;
+                        pre = match_run_fwd(ref, i_rlen, rs0, rd, qs0, wv::imin(del, ins), cmp);
+                        del -= pre;
+                        ins -= pre;
                         if (del == 1 && ins == 1) {  // :88-92
                             del = 0;
                             ins = 0;

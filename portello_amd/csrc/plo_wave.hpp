@@ -66,6 +66,13 @@ PLO_DEV int scan_max(int x) {  // inclusive, identity INT_MIN
     return x;
 }
 
+// byte primitives (per lane): v_perm_b32 as a 4-wide byte gather over the 8 bytes {hi:lo} (selector bytes 0..7), v_alignbyte
+// as a funnel shift by whole bytes
+PLO_DEV unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+PLO_DEV unsigned align_bytes(unsigned hi, unsigned lo, unsigned shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
+PLO_DEV int clz32(unsigned x) { return __builtin_clz(x); }  // x != 0
+PLO_DEV int ctz32(unsigned x) { return __builtin_ctz(x); }  // x != 0
+
 PLO_DEV int reduce_add(int x) { return bcast_last(scan_add(x)); }
 PLO_DEV int reduce_max(int x) { return bcast_last(scan_max(x)); }
 

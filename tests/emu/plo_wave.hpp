@@ -161,6 +161,22 @@ inline int bcast_first(int v) {
 }
 inline int imax(int a, int b) { return a > b ? a : b; }
 inline int imin(int a, int b) { return a < b ? a : b; }
+// byte primitives: plain C restatements of v_perm_b32 (selector bytes 0..7 only) and v_alignbyte
+inline unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) {
+    unsigned long long src = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        unsigned sb = (sel >> (8 * i)) & 0xffu;
+        unsigned b = sb < 8 ? (unsigned)((src >> (8 * sb)) & 0xffu) : (sb == 12 ? 0u : 0xffu);
+        r |= b << (8 * i);
+    }
+    return r;
+}
+inline unsigned align_bytes(unsigned hi, unsigned lo, unsigned shift) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3u)));
+}
+inline int clz32(unsigned x) { return __builtin_clz(x); }
+inline int ctz32(unsigned x) { return __builtin_ctz(x); }
 
 inline int scan_add(int x) {
     int64_t p = x;
