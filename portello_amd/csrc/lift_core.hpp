@@ -1018,6 +1018,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     if (!overflow && (stages & PLO_STAGE_SIMPLIFY)) {
         // pass A: clusters = maximal runs of I/D ops; sums at the cluster head; compact list of cluster heads
         int nH = 0;
+        bool changes = false;  // some cluster is not a single I/D op of non-zero length
         {
             SegSum sr, sq;
             MaxScan heads(-1);
@@ -1038,6 +1039,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 int prevC = wv::shfl_up1((int)isC, carry_c);
                 carry_c = wv::bcast_last((int)isC);
                 bool chead = isC && !(prevC && !ihead);
+                changes |= isC && (!chead || L == 0);
                 int hidx = heads.incl(chead ? e : -1);
                 int hrank = hcount.excl(chead ? 1 : 0);
                 if (chead) {
@@ -1055,6 +1057,10 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         overflow = wv::ballot(overflow) != 0ull;
         wv::sync();
+        // Every cluster of the tile is one I or D op: end_indel re-emits it unchanged (:41-44) and, on a CIGAR that the
+        // liftover stage has just cleaned and compressed (both idempotent), :153-155 change nothing either.
+        const bool identity = (stages & PLO_STAGE_LIFTOVER) && wv::ballot(changes) == 0ull;
+        if (!identity) {
         // pass H: one lane per cluster; only complex clusters (both I and D, not 1/1) look at the sequences
         // (CigarBlockInfo::end_indel :49-105).  Results overwrite the head's slots: T0 pre, T1 post, T3 del, T4 ins.
         for (int base = 0; base < nH && !overflow; base += 64) {
@@ -1169,6 +1175,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 alive = false;
             }
         }
+        }  // !identity
     }
 
     PLO_T(8)
