@@ -179,10 +179,11 @@ PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
 // -------------------------------------------------------------------------------------------------------------------
 // clean_up_cigar_edge_indels + compress_cigar  (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:265-291, 204-228)
 // X (n elements, items [s,s+c) per lane) -> Y.  Items with active == false are copied verbatim.
-// Returns the leading-deletion shift of the lane's item in `shift`.
+// Returns the leading-deletion shift of the lane's item in `shift`, and in `indel_pairs` (wave-uniform) whether some
+// active item's output has two neighbouring I/D ops, i.e. an indel cluster of more than one op.
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
-                              bool active, int &shift, int &n_out) {
+                              bool active, int &shift, int &n_out, bool &indel_pairs) {
     const int lane = wv::lane();
     m.itf[lane] = IMAX;
     m.itl[lane] = -1;
@@ -230,8 +231,6 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
                 }
             }
             Y[e] = 0;
-            m.T3[e] = 0;  // left clean for the indel-cluster sums of the next stage
-            m.T4[e] = 0;
         }
     }
     wv::sync();
@@ -239,6 +238,7 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
     {
         MaxScan lasta(-1);
         AddScan heads;
+        bool pairs = false;
         for (int base = 0; base < n; base += 64) {
             int e = base + lane;
             bool valid = e < n;
@@ -252,10 +252,13 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             int pa = lasta.excl_of(ai);
             bool head = false;
             if (alive) {
-                if (!i_act)
+                if (!i_act) {
                     head = true;
-                else
-                    head = (pa < i_s) || (op_type(X[pa]) != t);
+                } else {
+                    int pt = pa < i_s ? -1 : op_type(X[pa]);
+                    head = pt != t;
+                    pairs |= head && is_indel(t) && pt >= 0 && is_indel(pt);
+                }
             }
             int hi = heads.incl(head ? 1 : 0);
             if (alive) {
@@ -271,6 +274,7 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             if (valid) m.T0[e] = hi;
         }
         n_out = heads.carry;
+        indel_pairs = wv::ballot(pairs) != 0ull;
     }
     wv::sync();
     int ns, nc;
@@ -767,7 +771,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             finish_counts(m.T0, sA, cA, sB, cB);
             wv::sync();
             int shift = 0, nOut = 0;
-            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, has && do_shift, shift, nOut);
+            bool pairs_;
+            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, has && do_shift, shift, nOut, pairs_);
             sA = sB;
             cA = cB;
             nA = nOut;
@@ -780,6 +785,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
 
     PLO_T(2)
+    // the lifted CIGARs of the tile have an indel cluster of more than one op (known after the liftover's clean-up)
+    bool lifted_pairs = true;
     // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ------------------------------------------------------------------
     if (!overflow && (stages & PLO_STAGE_LIFTOVER)) {
         // per item: the window [W0, W1) of the block map that can intersect the item was located by build_item_desc;
@@ -980,7 +987,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     alive = false;
                 }
                 int shift = 0, nOut = 0;
-                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut);  // :219-220
+                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs);  // :219-220
                 sA = sB;
                 cA = cB;
                 nA = nOut;
@@ -1015,7 +1022,18 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 
     PLO_T(6)
     // ---- SIMPLIFY (src/simplify_alignment_indels.rs:5-156) ------------------------------------------------------------------
-    if (!overflow && (stages & PLO_STAGE_SIMPLIFY)) {
+    // On a CIGAR that the liftover stage has just cleaned and compressed (no zero-length ops, both steps idempotent),
+    // simplify_alignment_indels is the identity unless some cluster has more than one op: end_indel re-emits a single
+    // I or D unchanged (:41-44) and :153-155 change nothing.  Such tiles skip the stage.
+    if (!overflow && (stages & PLO_STAGE_SIMPLIFY) && !((stages & PLO_STAGE_LIFTOVER) && !lifted_pairs)) {
+        for (int base = 0; base < nA; base += 64) {  // cluster sums start from zero
+            int e = base + lane;
+            if (e < nA) {
+                m.T3[e] = 0;
+                m.T4[e] = 0;
+            }
+        }
+        wv::sync();
         // pass A: clusters = maximal runs of I/D ops; sums at the cluster head; compact list of cluster heads
         int nH = 0;
         bool changes = false;  // some cluster is not a single I/D op of non-zero length
@@ -1057,8 +1075,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         overflow = wv::ballot(overflow) != 0ull;
         wv::sync();
-        // Every cluster of the tile is one I or D op: end_indel re-emits it unchanged (:41-44) and, on a CIGAR that the
-        // liftover stage has just cleaned and compressed (both idempotent), :153-155 change nothing either.
+        // (same test on the clusters themselves: complex clusters of items that take no part do not count)
         const bool identity = (stages & PLO_STAGE_LIFTOVER) && wv::ballot(changes) == 0ull;
         if (!identity) {
         // pass H: one lane per cluster; only complex clusters (both I and D, not 1/1) look at the sequences
@@ -1165,7 +1182,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             finish_counts(m.T2, sA, cA, sB, cB);
             wv::sync();
             int shift = 0, nOut = 0;
-            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, simp, shift, nOut);  // :153-154
+            bool pairs_;
+            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, simp, shift, nOut, pairs_);  // :153-154
             sA = sB;
             cA = cB;
             nA = nOut;
