@@ -197,11 +197,12 @@ constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its o
 
 // Persistent: the grid is sized to the resident capacity of the chip and every wave strides over the tiles, keeping its
 // output slab and statistics in registers (WaveCtx).
-#ifdef PLO_TILE_WPE
-#define PLO_TILE_OCC __attribute__((amdgpu_waves_per_eu(PLO_TILE_WPE, PLO_TILE_WPE)))
-#else
-#define PLO_TILE_OCC
+// Register budget: 3 waves per SIMD (<= 168 VGPRs) is what the LDS slices allow as well (12 waves per CU); without the
+// attribute the allocator may drift past 168 and the resident waves drop to 2 per SIMD.
+#ifndef PLO_TILE_WPE
+#define PLO_TILE_WPE 3
 #endif
+#define PLO_TILE_OCC __attribute__((amdgpu_waves_per_eu(PLO_TILE_WPE, PLO_TILE_WPE)))
 __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
                                                                uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                uint32_t lds_per_wave) {

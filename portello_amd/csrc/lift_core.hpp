@@ -77,19 +77,16 @@ PLO_DEV bool is_indel(int t) { return t == OP_I || t == OP_D; }
 // ---- sequence access --------------------------------------------------------------------------------------------
 // comp_base, lib/rust-vc-utils/src/seq_util.rs:1-15
 PLO_DEV int comp_base(int b) {
-    switch (b) {
-        case 'A': return 'T';
-        case 'T': return 'A';
-        case 'C': return 'G';
-        case 'G': return 'C';
-        case 'N': return 'N';
-        case 'a': return 't';
-        case 't': return 'a';
-        case 'c': return 'g';
-        case 'g': return 'c';
-        case 'n': return 'n';
-        default: return 'N';
-    }
+    // branch-free (a switch is lowered to exec-mask branches, ~140 instructions per inlined call): fold the case bit
+    // away, map A<->T and C<->G, keep N/n, everything else is 'N'
+    const int u = b & ~0x20, lower = b & 0x20;
+    int r = 'N';
+    r = (u == 'A') ? 'T' : r;
+    r = (u == 'T') ? 'A' : r;
+    r = (u == 'C') ? 'G' : r;
+    r = (u == 'G') ? 'C' : r;
+    const bool known = (r != 'N') || (u == 'N');
+    return known ? (r | lower) : 'N';
 }
 // The read as the reference sees it after `record.seq().as_bytes()` (+ rev_comp_in_place when need_flipped),
 // src/read_alignment_scanner.rs:170-173,238-241 -- never materialised: decoded / complemented per probe.

@@ -348,3 +348,6 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
     out->rev_seq_bytes = (uint64_t)o->soff[ne] * 16u; out->rev_qual_bytes = (uint64_t)o->qoff[ne] * 16u;
     return 0;
 }
+
+// the device comp_base (lift_core.hpp), for an exhaustive comparison with the oracle
+extern "C" int emu_comp_base(int b) { return plo::comp_base(b); }

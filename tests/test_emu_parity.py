@@ -103,3 +103,14 @@ def test_lane_order_independence(oracle):
     rc, res, _ = emu_lib.liftover_batch(ix, b, order_seed=12345)
     assert rc == 0
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1), res)
+
+
+def test_comp_base_all_bytes(oracle):
+    """the device's branch-free comp_base against the oracle's restatement of seq_util.rs:1-15, all 256 byte values"""
+    import ctypes as C
+    L = emu_lib.lib()
+    L.emu_comp_base.restype = C.c_int
+    L.emu_comp_base.argtypes = [C.c_int]
+    O = oracle.lib()
+    for b in range(256):
+        assert L.emu_comp_base(b) == O.orc_comp_base(b), b
