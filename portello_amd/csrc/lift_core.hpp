@@ -595,11 +595,24 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 m.T4[e] = 0;
             }
         }
-        // the gather itself carries no cross-lane dependency: all chunks' loads are in flight together
-#pragma unroll 4
-        for (int base = 0; base < nA; base += 64) {
-            int e = base + lane;
-            if (e < nA) m.A[e] = bt.cigar[m.T0[e]];
+        // the gather carries no cross-lane dependency: the loads of four chunks are in flight together (indices first,
+        // then all loads, then all stores -- written out because the compiler must assume that m.A aliases m.T0 and
+        // would otherwise finish every chunk's store before the next chunk's index read)
+        for (int base = 0; base < nA; base += 256) {
+            int src[4];
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = base + 64 * u + lane;
+                src[u] = e < nA ? m.T0[e] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[u] >= 0 ? bt.cigar[src[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = base + 64 * u + lane;
+                if (e < nA) m.A[e] = v[u];
+            }
         }
         wv::sync();
     }
