@@ -160,6 +160,15 @@ struct SegSum {
     }
 };
 
+// appends one op of item `id` at Y[p] when `on` (p advances): the emission passes write up to four ops per element this way
+PLO_DEV void put_op(uint32_t *Y, uint8_t *idY, int &p, bool on, uint32_t v, int id) {
+    if (on) {
+        Y[p] = v;
+        idY[p] = (uint8_t)id;
+    }
+    p += on ? 1 : 0;
+}
+
 // Per-item counts/starts of an output array from the inclusive emission prefix E[] stored per *input* element
 // (input items are contiguous: item t = [s, s+c)).
 PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
@@ -739,35 +748,36 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 carry_r = wv::bcast_last(r_after);
                 int r_before = have_prev ? r_excl : 0;
                 int x = r_before + m_e;
-                uint32_t o[4];
-                int ne = 0;
-                if (valid && !i_do) {
-                    o[ne++] = c;  // item not shifted: copy
-                } else if (on && chead) {
-                    int cs = wv::imin(x, h);  // actual_shift_len (:132)
-                    if (x - cs > 0) o[ne++] = mk_op(OP_M, x - cs);
-                    if (ins > 0) o[ne++] = mk_op(OP_I, ins);  // "nImD" order for the left shift (:141-147)
-                    if (del > 0) o[ne++] = mk_op(OP_D, del);
-                } else if (on && event) {
-                    if (x > 0) o[ne++] = mk_op(OP_M, x);
-                    o[ne++] = c;
-                }
-                if (on && e == i_s + i_c - 1) {  // get_cigar(): final add_other(None) (:54-60)
+                // Up to four ops per element, as flags + values (no indexed local array: that would live in scratch):
+                //   copy (item not shifted) | cluster head: M(x-cs) I(ins) D(del), "nImD" order of the left shift
+                //   (:132-147) | other event: M(x) op | last element: final add_other(None) M(x_end) (:54-60)
+                const bool cp = valid && !i_do, ch = on && chead, ev = on && !chead && event;
+                const int cs = wv::imin(x, h);  // actual_shift_len (:132)
+                const bool e0 = cp || (ch && x - cs > 0) || (ev && x > 0);
+                const uint32_t v0 = cp ? c : mk_op(OP_M, ch ? x - cs : x);
+                const bool e1 = (ch && ins > 0) || ev;
+                const uint32_t v1 = ch ? mk_op(OP_I, ins) : c;
+                const bool e2 = ch && del > 0;
+                const uint32_t v2 = mk_op(OP_D, del);
+                int x_end = 0;
+                if (on && e == i_s + i_c - 1) {
                     bool have_le = li >= i_s;
                     int pm_incl = pm + (is_match(t) ? L : 0);
                     int m_end = pm_incl - (have_le ? m.T2[li] : 0);
-                    int x_end = (have_le ? r_after : 0) + m_end;
-                    if (x_end > 0) o[ne++] = mk_op(OP_M, x_end);
+                    x_end = (have_le ? r_after : 0) + m_end;
                 }
+                const bool e3 = x_end > 0;
+                const uint32_t v3 = mk_op(OP_M, x_end);
+                const int ne = (int)e0 + (int)e1 + (int)e2 + (int)e3;
                 int ei = emit.incl(ne);
                 int p = ei - ne;
                 if (p + ne > m.cap) {
                     overflow = true;
                 } else {
-                    for (int k = 0; k < ne; ++k) {
-                        m.B[p + k] = o[k];
-                        m.idB[p + k] = (uint8_t)id;
-                    }
+                    put_op(m.B, m.idB, p, e0, v0, id);
+                    put_op(m.B, m.idB, p, e1, v1, id);
+                    put_op(m.B, m.idB, p, e2, v2, id);
+                    put_op(m.B, m.idB, p, e3, v3, id);
                 }
                 if (valid) m.T0[e] = ei;
             }
@@ -948,36 +958,33 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     int pmap = lastmap.excl_of(mi);
                     int fi = lastfm.incl(fm ? j : -1);
                     int fe = lastfm.excl_of(fi);
-                    uint32_t o[2];
-                    int ne = 0;
-                    if (valid && !piece) {
-                        o[ne++] = c;
-                    } else if (piece) {
-                        if (mapped) {
-                            bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
-                            bool started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
-                            bool started_before = fe >= 0 && (m.T3[fe] & 63) == id;
-                            if (fm && !started_before) m.its[id] = startval;
-                            if (prev_ok) {  // :91-96
-                                int d = val - m.T4[pmap];
-                                if (d > 0 && started) o[ne++] = mk_op(OP_D, d);
-                            }
-                            if (ism || started) o[ne++] = mk_op(t == OP_D ? OP_D : (t == OP_N ? OP_N : OP_M), plen);  // :102-109
-                        } else if (!before) {
-                            if (ism) o[ne++] = mk_op(OP_I, plen);  // :111-115
-                        } else {
-                            if (ism) o[ne++] = mk_op(OP_S, plen);  // :117-123
+                    // at most two ops per piece, as flags + values (no indexed local array: that would live in scratch)
+                    bool e0 = false, started = false;  // e0: the jump deletion of :91-96
+                    uint32_t v0 = 0;
+                    if (mapped) {
+                        bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
+                        started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
+                        bool started_before = fe >= 0 && (m.T3[fe] & 63) == id;
+                        if (fm && !started_before) m.its[id] = startval;
+                        if (prev_ok) {  // :91-96
+                            int d = val - m.T4[pmap];
+                            e0 = d > 0 && started;
+                            v0 = mk_op(OP_D, d);
                         }
                     }
+                    // copied op | mapped piece (:102-109) | insertion over an unmapped block (:111-115) | soft clip before the
+                    // first block (:117-123)
+                    const bool e1 = (valid && !piece) || (piece && (mapped ? (ism || started) : ism));
+                    const uint32_t v1 = !piece ? c
+                                        : mk_op(mapped ? (t == OP_D ? OP_D : (t == OP_N ? OP_N : OP_M)) : (before ? OP_S : OP_I), plen);
+                    const int ne = (int)e0 + (int)e1;
                     int ei = emit.incl(ne);
                     int p = ei - ne;
                     if (p + ne > m.cap) {
                         overflow = true;
                     } else {
-                        for (int k = 0; k < ne; ++k) {
-                            m.B[p + k] = o[k];
-                            m.idB[p + k] = (uint8_t)id;
-                        }
+                        put_op(m.B, m.idB, p, e0, v0, id);
+                        put_op(m.B, m.idB, p, e1, v1, id);
                     }
                     if (ne > 0) wv::atomic_add(&m.itc[id], ne);
                 }
@@ -1147,38 +1154,41 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 int t = op_type(c);
                 bool on = valid && i_on;
                 int hrank = hcount.excl((on && chead) ? 1 : 0);
-                uint32_t o[4];
-                int ne = 0;
-                if (valid && !(on && is_indel(t))) {
-                    o[ne++] = c;  // :144-147 (everything that is not part of a cluster is copied)
-                } else if (on && chead) {
-                    int del = m.T3[e], ins = m.T4[e];
-                    int was_complex = hrank < m.capk ? m.V[hrank] : 0;
+                // up to four ops per element, as flags + values (no indexed local array: that would live in scratch)
+                const bool cp = valid && !(on && is_indel(t));  // :144-147 everything outside a cluster is copied
+                const bool ch = on && is_indel(t) && chead;
+                int del = 0, ins = 0, pre = 0, post = 0, was_complex = 0;
+                if (ch) {
+                    del = m.T3[e];
+                    ins = m.T4[e];
+                    was_complex = hrank < m.capk ? m.V[hrank] : 0;
                     if (was_complex) {
-                        int pre = m.T0[e], post = m.T1[e];
-                        if (pre > 0) o[ne++] = mk_op(OP_M, pre);  // :101-104
-                        if (ins > 0) o[ne++] = mk_op(OP_I, ins);
-                        if (del > 0) o[ne++] = mk_op(OP_D, del);
-                        if (post > 0) o[ne++] = mk_op(OP_M, post);
-                    } else if (del == 0 && ins == 0) {
-                    } else if (del == 0) {
-                        o[ne++] = mk_op(OP_I, ins);
-                    } else if (ins == 0) {
-                        o[ne++] = mk_op(OP_D, del);
-                    } else if (del == 1 && ins == 1) {
-                        o[ne++] = mk_op(OP_M, 1);  // :45-48
+                        pre = m.T0[e];
+                        post = m.T1[e];
                     }
-                    // (a complex cluster that would have panicked emits nothing; the item is reported PANIC)
                 }
+                // complex cluster: M(pre) I(ins) D(del) M(post) (:101-104); simple: I | D | 1I1D -> M(1) (:41-48); a complex
+                // cluster that would have panicked has both sizes > 0 and emits nothing (the item is reported PANIC)
+                const bool one_one = ch && !was_complex && del == 1 && ins == 1;
+                const bool both = del > 0 && ins > 0;
+                const bool e0 = cp || (ch && (was_complex ? pre > 0 : one_one));
+                const uint32_t v0 = cp ? c : mk_op(OP_M, was_complex ? pre : 1);
+                const bool e1 = ch && ins > 0 && (was_complex || !both);
+                const uint32_t v1 = mk_op(OP_I, ins);
+                const bool e2 = ch && del > 0 && (was_complex || !both);
+                const uint32_t v2 = mk_op(OP_D, del);
+                const bool e3 = ch && was_complex && post > 0;
+                const uint32_t v3 = mk_op(OP_M, post);
+                const int ne = (int)e0 + (int)e1 + (int)e2 + (int)e3;
                 int ei = emit.incl(ne);
                 int p = ei - ne;
                 if (p + ne > m.cap) {
                     overflow = true;
                 } else {
-                    for (int k = 0; k < ne; ++k) {
-                        m.B[p + k] = o[k];
-                        m.idB[p + k] = (uint8_t)id;
-                    }
+                    put_op(m.B, m.idB, p, e0, v0, id);
+                    put_op(m.B, m.idB, p, e1, v1, id);
+                    put_op(m.B, m.idB, p, e2, v2, id);
+                    put_op(m.B, m.idB, p, e3, v3, id);
                 }
                 if (valid) m.T2[e] = ei;
             }
