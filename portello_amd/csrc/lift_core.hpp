@@ -15,6 +15,7 @@
 //
 // All citations are relative to /root/reference.
 #pragma once
+#include <type_traits>
 #include <plo_wave.hpp>
 #include <stdint.h>
 
@@ -837,9 +838,12 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             wv::sync();
         }
-        // pass A: per op, first block f and number of (op x block) pieces
+        // pass A: per op, first block f and number of (op x block) pieces.  Passes A and B are instantiated once for block
+        // maps staged in LDS and once for maps read from global memory (a run-time select between the two pointers would
+        // turn every probe into a flat load behind a branch).
         int P = 0;
-        {
+        auto pass_a = [&](auto staged_c) {
+            constexpr bool STAGED = decltype(staged_c)::value;
             SegSum sr;
             AddScan pieces;
             for (int base = 0; base < nA; base += 64) {
@@ -862,14 +866,14 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                             int nw = i_w1 - i_w0, lo = 0, hi = nw;
                             while (lo < hi) {  // upper bound of s
                                 int mid = (lo + hi) >> 1;
-                                int key = staged ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
+                                int key = STAGED ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
                                 if (key <= s) lo = mid + 1; else hi = mid;
                             }
                             f = lo - 1;
                             hi = nw;  // lower bound of s+L (>= the upper bound of s)
                             while (lo < hi) {
                                 int mid = (lo + hi) >> 1;
-                                int key = staged ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
+                                int key = STAGED ? m.K[i_kb + mid] : ix.kv[i_w0 + mid].key;
                                 if (key < s + L) lo = mid + 1; else hi = mid;
                             }
                             cnt = (lo - 1) - f + 1;
@@ -886,7 +890,9 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
             }
             P = pieces.carry;
-        }
+        };
+        if (staged) pass_a(std::true_type{});
+        else pass_a(std::false_type{});
         PLO_T(3)
         if (P > m.cap) overflow = true;
         if (!overflow) {
@@ -904,7 +910,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             wv::sync();
             // pass B: one lane per piece (update_ref2_cigar_segment, :35-133)
             int nB = 0;
-            {
+            auto pass_b = [&](auto staged_c) {
+                constexpr bool STAGED = decltype(staged_c)::value;
                 MaxScan owner(0), lastmap(-1), lastfm(-1);
                 AddScan emit;
                 for (int base = 0; base < P; base += 64) {
@@ -926,7 +933,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         before = b < 0;
                         int bkey = 0;
                         if (!before) {
-                            if (staged) {
+                            if (STAGED) {
                                 bkey = m.K[i_kb + b];
                                 val = m.V[i_kb + b];
                             } else {
@@ -938,7 +945,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         int pstart = (tt == 0) ? s : bkey;
                         int pend = s + L;
                         if (i_w0 + b + 1 < i_kv1) {
-                            int kn = staged ? m.K[i_kb + b + 1] : ix.kv[i_w0 + b + 1].key;
+                            int kn = STAGED ? m.K[i_kb + b + 1] : ix.kv[i_w0 + b + 1].key;
                             if (kn < pend) pend = kn;
                         }
                         plen = pend - pstart;
@@ -989,7 +996,9 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (ne > 0) wv::atomic_add(&m.itc[id], ne);
                 }
                 nB = emit.carry;
-            }
+            };
+            if (staged) pass_b(std::true_type{});
+            else pass_b(std::false_type{});
             overflow = wv::ballot(overflow) != 0ull;
             wv::sync();
             PLO_T(4)
