@@ -316,8 +316,8 @@ PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, long long r0, const R
     const unsigned qsh = (unsigned)(((unsigned long long)(uintptr_t)rd.p + (unsigned long long)b0) & 3ull);
     const int qwords = bam4 ? 3 : 5;
     if (b0 - (long long)qsh < rd.lo || b0 - (long long)qsh + 4 * qwords > rd.hi) return false;
-    const uint32_t *pr = (const uint32_t *)(ref + (r0 - (long long)rsh));
-    const uint32_t *pq = (const uint32_t *)(rd.p + (b0 - (long long)qsh));
+    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ref + (r0 - (long long)rsh));
+    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(rd.p + (b0 - (long long)qsh));
     unsigned wr[5], wq[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) wr[u] = pr[u];
@@ -396,7 +396,7 @@ PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, const ReadSe
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int jj = j < n ? j : 0;
-            a[j] = ref[re - 1 - k - jj];
+            a[j] = ((const PLO_GLOBAL uint8_t *)ref)[re - 1 - k - jj];
             b[j] = read_base(rd, qe - 1 - k - jj);
         }
         int adv = n;
@@ -427,7 +427,7 @@ PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, const ReadSeq
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int jj = j < n ? j : 0;
-            a[j] = ref[rs + k + jj];
+            a[j] = ((const PLO_GLOBAL uint8_t *)ref)[rs + k + jj];
             b[j] = read_base(rd, qs + k + jj);
         }
         int adv = n;

@@ -11,6 +11,8 @@
 #define PLO_DEV __device__ __forceinline__
 #define PLO_HD __host__ __device__ __forceinline__
 #define PLO_WAVE 64
+// pointers rebuilt from integer addresses (item descriptors) are generic; this marks what they point to as global memory
+#define PLO_GLOBAL __attribute__((address_space(1)))
 
 namespace wv {
 

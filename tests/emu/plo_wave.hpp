@@ -18,6 +18,7 @@
 #define PLO_DEV inline
 #define PLO_HD inline
 #define PLO_WAVE 64
+#define PLO_GLOBAL
 #define PLO_EMULATOR 1
 
 namespace wv {
