@@ -43,9 +43,13 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     long long part = 0;
     if (s < bt.n_segs) {
         uint32_t c0 = bt.seg_cigar_off[s], c1 = bt.seg_cigar_off[s + 1];
-        for (uint32_t i = c0 + sub; i < c1; i += 8) {
-            uint32_t c = bt.cigar[i];
-            if ((0x18D >> (c & 15u)) & 1) part += (long long)(c >> 4);
+        for (uint32_t i = c0 + sub; i < c1; i += 32) {  // four independent loads in flight
+            uint32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = (i + 8u * u < c1) ? bt.cigar[i + 8u * u] : 0u;  // 0 = M of length 0
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
         }
     }
     part += __shfl_xor(part, 1, 64);
