@@ -41,6 +41,24 @@ PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first inde
     return lo;
 }
 
+// same result as kv_lower_bound when the answer is expected a few entries after `lo` (the end of an item's window):
+// probes lo, lo+1, lo+3, lo+7, ... before bisecting the bracket
+PLO_DEV int kv_lower_bound_near(const KV *kv, int lo, int hi, int x) {
+    int step = 1;
+    while (lo < hi) {
+        int probe = lo + step - 1;
+        if (probe >= hi) break;
+        if (kv[probe].key < x) {
+            lo = probe + 1;
+            step <<= 1;
+        } else {
+            hi = probe;
+            break;
+        }
+    }
+    return kv_lower_bound(kv, lo, hi, x);
+}
+
 // Block map of one contig split segment: get_read_segment_to_ref_pos_tree_map
 // (lib/rust-vc-utils/src/bam_utils/read_to_ref_map.rs:101-137, ignore_hard_clip = false as at
 // src/contig_alignment_scanner/mod.rs:98-102).  Every flush of a match run inserts {start -> Some(ref), end -> None};
@@ -115,7 +133,7 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     long long hi = pos1 + ref_len > 0x7fffffffLL ? 0x7fffffffLL : pos1 + ref_len;
     int ub = kv_upper_bound(ix.kv, kv0, kv1, (int)lo);
     int w0 = ub - 1 > kv0 ? ub - 1 : kv0;
-    int w1 = kv_lower_bound(ix.kv, w0, kv1, (int)hi);
+    int w1 = kv_lower_bound_near(ix.kv, w0, kv1, (int)hi);
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
     wk.item_nin[i] = n_in;
