@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Copies the summaries written by tools/profile_round.sh (gpurun_out/<ver>/) into profiles/ under round-prefixed names
+and refreshes profiles/hbm_traffic.json.  usage: tools/save_profiles.py v5 [round]"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ver = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = f"gpurun_out/{ver}"
+pre = f"profiles/{rnd}_{ver}_wgs30x"
+rows = list(csv.reader(open(f"{src}/kernel_stats.csv")))
+hdr, body = rows[0], rows[1:]
+tot = sum(int(r[2]) for r in body)
+eng = [r for r in body if r[0].startswith("k_")]
+with open(f"{pre}_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (default workload wgs30x, 10 steps + 2 warm-up)\n")
+    f.write(f"# rows of the engine kernels only (the other {len(body) - len(eng)} rows are torch kernels of the synthetic generator); total traced kernel time {tot} ns\n")
+    w = csv.writer(f)
+    w.writerow(hdr)
+    for r in eng:
+        w.writerow(r)
+shutil.copy(f"{src}/bench.json", f"{pre}_bench.json")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"{pre}_bench_under_rocprof.json")
+
+
+def rd(p):
+    return {l.split(",")[0]: float(l.split(",")[1]) for l in open(p) if "," in l}
+
+
+fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
+with open(f"{pre}_pmc_summary.csv", "w") as f:
+    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_tiles --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+    f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of k_lift_tiles; FETCH_SIZE / WRITE_SIZE in KiB\n")
+    f.write("counter,mean_per_launch,launches\n")
+    for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
+        for l in open(f"{src}/{p}.csv"):
+            if "," in l:
+                f.write(l)
+h = json.load(open("profiles/hbm_traffic.json"))
+b = json.load(open(f"{src}/bench.json"))
+h["wgs30x"] = {"k_lift_tiles": int((2 * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr,
+               "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"]}
+json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
+print(h["wgs30x"])
+print(json.dumps(b["roofline"]))
+print(b["value"], b["ms_per_step"], b["cpu_baseline"]["value"])
+for r in eng[:4]:
+    print(r[0][:40], r[1], r[3])
