@@ -117,15 +117,24 @@ __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint3
     tile_lo[t] = lo > n_small ? lo : n_small;
 }
 
-// maximum (out[0]) and 64-bit sum (out[2..3]) of a uint32 array, one atomic pair per wave; out must be zeroed
-__global__ void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out) {
+// maximum (out[0]) and 64-bit sum (out[2..3]) of a uint32 array, one atomic pair per wave, plus a histogram of the values
+// in bins of WHIST_STEP (out[WHIST_AT + b], last bin = everything above); out must be zeroed
+constexpr int WHIST_STEP = 32, WHIST_BINS = 40, WHIST_AT = 8;
+__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out) {
+    __shared__ uint32_t hist[WHIST_BINS];
+    if (threadIdx.x < WHIST_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t m = 0;
     unsigned long long sum = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t v = in[i];
         m = v > m ? v : m;
         sum += v;
+        uint32_t b = v / WHIST_STEP;
+        atomicAdd(&hist[b < WHIST_BINS - 1 ? b : WHIST_BINS - 1], 1u);
     }
+    __syncthreads();
+    if (threadIdx.x < WHIST_BINS && hist[threadIdx.x]) atomicAdd(out + WHIST_AT + threadIdx.x, hist[threadIdx.x]);
     int r = wv::reduce_max((int)(m & 0x7fffffffu));
     unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(sum & 0xffffffull));
     unsigned hi = (unsigned)wv::reduce_add((int)(unsigned)(sum >> 24));
@@ -247,8 +256,9 @@ __global__ __launch_bounds__(LANE_WAVES * 64) void k_lift_lanes(DevIndex ix, Dev
     wave_ctx_flush(wk, ctx);
 }
 
-// Items of the lane kernel whose intermediates overflowed its per-lane capacity: the tile code, RETRY_PER items per wave
-constexpr uint32_t RETRY_PER = 6;
+// Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
+// items per wave with a larger LDS slice (retry_cap)
+constexpr uint32_t RETRY_PER = 1;
 __global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_retry,
                                                    int big_thresh, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, Dev
     WaveCtx ctx;
     for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
         uint32_t left = n_retry - r;
-        lift_tile(ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, false, big_thresh, ctx);
+        lift_tile(ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx);
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWo
     TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
     WaveCtx ctx;
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, true, 0, ctx);
+        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx);
@@ -435,7 +445,8 @@ struct plo_ctx {
     // cap sets the LDS slice of a wave (34 B per element + 1.25 KB): 320 -> 12,160 B -> 3 four-wave blocks = 12 waves per CU,
     // which is also what the kernel's VGPR budget allows; measured on MI355X (wgs30x, 2M reads): cap 512 (8 waves/CU) 8.34 ms,
     // cap 384 (still 2 blocks) 8.33 ms, cap 320 6.26 ms, cap 256 6.27 ms + overflow items.
-    int window = 160, big_thresh = 176, cap = 320;
+    int window = 256, big_thresh = 176, cap = 320;
+    bool adaptive = true;  // geometry chosen per batch (off when any of PLO_WINDOW / PLO_BIG_THRESH / PLO_CAP is set)
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
     // routing threshold of the lane-per-item kernel (k_lift_lanes).  Measured on MI355X (wgs30x): forward items run 1.6x
@@ -658,9 +669,9 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_retry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
-    if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e));
-    if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e));
-    if (const char *e = getenv("PLO_CAP")) c->cap = std::max(64, atoi(e));
+    if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e)), c->adaptive = false;
+    if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e)), c->adaptive = false;
+    if (const char *e = getenv("PLO_CAP")) c->cap = std::max(64, atoi(e)), c->adaptive = false;
     *out = c;
     return PLO_OK;
 }
@@ -880,8 +891,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     uint32_t total_ops = 0, max_nin = 0, n_small = 0;
     unsigned long long all_ops = 0;
     {
-        HIP_TRY(c, c->misc.ensure(64));
-        HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 64, st));
+        HIP_TRY(c, c->misc.ensure(256));
+        HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
         if (n_items)
             hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 64u)), dim3(256), 0, st,
                                (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>());
@@ -891,11 +902,36 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipMemcpyAsync(h + 4, c->misc.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(h + 2, c->rank0.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(h + 3, c->rank1.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 8, c->misc.as<uint32_t>() + WHIST_AT, WHIST_BINS * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        total_ops = h[0];  // ops of the large (tiled) items
+        total_ops = h[0];  // weight of the tiled items
         max_nin = h[1];
         n_small = n_items ? h[2] + h[3] : 0;
         all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
+        if (c->adaptive && n_items) {
+            // Tile geometry from the batch's weight distribution: the routing threshold covers all but 0.2 % of the items
+            // (those take the large-item kernel), the LDS slice holds one window plus the overhang of its last item.  Dense
+            // contig block maps (many blocks per read) thus get larger slices and fewer resident waves instead of a
+            // large-item kernel that runs every read alone from global scratch.
+            const uint32_t *hist = h + 8;
+            unsigned long long above = 0, allow = n_items / 500;
+            int b = WHIST_BINS - 1;
+            for (; b > 0; --b) {  // lowest threshold (b * WHIST_STEP) with at most `allow` items above it
+                if (above + hist[b] > allow) break;
+                above += hist[b];
+            }
+            int thresh = std::min(std::max(176, (b + 1) * WHIST_STEP), (WHIST_BINS - 1) * WHIST_STEP);
+            c->big_thresh = thresh;
+            // up to a threshold of 256 the 320-element slice (12 waves per CU) stays: the few tiles it cannot hold are re-run
+            // item by item (k_lift_retry); measured on MI355X, 1 M reads, contig indel rate 1e-3: 4.3 ms against 5.3-7.2 ms
+            // with 384-element slices.  Workgroup width per slice size as measured (tools/tune.py --contig-indel).
+            c->cap = thresh <= 256 ? 320 : (thresh + 144 + 63) & ~63;
+            c->window = c->cap - 64;
+            c->tile_waves = c->cap <= 320 ? TILE_WAVES : (c->cap <= 448 ? 2 : 1);
+            if (getenv("PLO_DEBUG_GEOMETRY"))
+                fprintf(stderr, "[plo] batch geometry: thresh %d cap %d window %d tile_waves %d (max weight %u, %llu items beyond the 0.2 %% cut)\n", thresh, c->cap,
+                        c->window, c->tile_waves, max_nin, above);
+        }
     }
     const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
     HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
@@ -951,9 +987,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipStreamSynchronize(st));
         n_retry = (uint32_t)hc[CNT_NRETRY];
         if (n_retry) {
-            uint32_t lds = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
-            uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 8u);
-            hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, c->cap);
+            // one item of at most big_thresh weight: the shift / simplify stages at most double its ops
+            const int retry_cap = std::min(4096, std::max(c->cap, (2 * c->big_thresh + 64 + 63) & ~63));
+            uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15);
+            uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 6u);
+            hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));

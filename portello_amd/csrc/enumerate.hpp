@@ -108,6 +108,15 @@ PLO_HD int build_segment_map(const uint32_t *cigar, uint32_t n, long long ref_po
     return bad ? -1 : cnt;
 }
 
+// Upper bound of the elements an item needs in any stage: pieces <= ops + blocks, raw lifted ops <= pieces + one jump
+// deletion per block.  Tiles are cut and large items are routed by this weight, so that a tile of `window` weight fits the
+// LDS slice whatever the density of the contig's block map.
+PLO_DEV int item_weight(int n_in, int w0, int w1, int kv1) {
+    int nblk = (w1 + 1 < kv1 ? w1 + 1 : kv1) - w0;
+    return n_in + 2 * (nblk > 0 ? nblk : 0);
+}
+enum { LEVEL_TILE = 0, LEVEL_RETRY = 1, LEVEL_LAST = 2 };
+
 // Resolves everything the tile kernel needs to know about item i = (read segment seg, contig segment cseg):
 // the caller glue of get_liftover_alignment_for_read_and_contig_segment (src/read_alignment_scanner.rs:146-176) --
 // need_flipped (:153-157), rev_pos (:164-166) -- plus the window of the block map the item can touch.
@@ -136,7 +145,7 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     int w1 = kv_lower_bound_near(ix.kv, w0, kv1, (int)hi);
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
-    wk.item_nin[i] = n_in;
+    wk.item_nin[i] = (uint32_t)item_weight((int)n_in, w0, w1, kv1);  // tiling weight
     wk.item_cls[i] = (((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u) |
                      ((wk.lane_max_in < 0 || n_in > (uint32_t)wk.lane_max_in) ? 2u : 0u);
     wk.d.in_off[i] = in_off;

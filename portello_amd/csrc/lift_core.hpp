@@ -492,7 +492,10 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx) {
 // The tile pipeline
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
-                       int nit, TileMem m, const uint32_t *list, bool last_resort, int big_thresh, WaveCtx &ctx) {
+                       int nit, TileMem m, const uint32_t *list, int level, int big_thresh, WaveCtx &ctx) {
+    // level: LEVEL_TILE (shared tile; a tile that overflows its capacity re-queues its items on the retry list),
+    // LEVEL_RETRY (few items, larger capacity; overflow -> large-item list), LEVEL_LAST (one item, global scratch)
+    const bool last_resort = level == LEVEL_LAST;
     const int lane = wv::lane();
 #ifdef PLO_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -537,7 +540,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
     // items too long for a shared tile go to the large-item kernel (one item per wave, global scratch)
     {
-        bool defer = has && !last_resort && n_in > big_thresh;
+        bool defer = has && !last_resort && item_weight(n_in, W0, W1, kv1) > big_thresh;
         unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int nd = __builtin_popcountll(dm);
@@ -1238,14 +1241,17 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             if (lane == 0) wv::atomic_add_global(&wk.counters[CNT_ERROR], 1ull);
         } else {
-            // tile capacity exceeded: re-queue every item of the tile for the large-item kernel
+            // capacity exceeded: re-queue every item -- of a shared tile on the retry list (few items per wave, larger
+            // capacity), of a retry group on the large-item list (one item per wave, global scratch)
+            const bool to_big = level != LEVEL_TILE;
             unsigned long long hm = wv::ballot(has);
             int slot = 0;
-            if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NBIG], (unsigned long long)__builtin_popcountll(hm));
+            if (lane == 0)
+                slot = (int)wv::atomic_add_global(&wk.counters[to_big ? CNT_NBIG : CNT_NRETRY], (unsigned long long)__builtin_popcountll(hm));
             slot = wv::bcast_first(slot);
             if (has) {
                 int rank = __builtin_popcountll(hm & ((1ull << lane) - 1ull));
-                wk.big_list[slot + rank] = g;
+                (to_big ? wk.big_list : wk.retry_list)[slot + rank] = g;
                 wk.status[g] = (uint8_t)ITEM_NEED_BIG;
             }
         }
@@ -1307,7 +1313,7 @@ PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &
     uint32_t lo = wk.tile_lo[tile], hi = wk.tile_lo[tile + 1];  // written by k_tile_bounds
     for (uint32_t b = lo; b < hi; b += 64) {
         int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-        lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, false, big_thresh, ctx);
+        lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx);
         wv::sync();
     }
 }

@@ -189,19 +189,6 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                     wave_ctx_flush(wk, ctx);
                 });
             }
-            // retry list -> tile code, a few items per wave
-            uint32_t n_retry = (uint32_t)counters[CNT_NRETRY];
-            const uint32_t per = 6;
-            for (uint32_t r = 0; r < n_retry; r += per) {
-                wv::EmuWave w;
-                w.order_seed = order_seed ? order_seed + 555 + r : 0;
-                TileMem m = carve_tile_mem(lds.data(), cap);
-                w.run([&]() {
-                    WaveCtx ctx;
-                    lift_tile(ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, false, big_thresh, ctx);
-                    wave_ctx_flush(wk, ctx);
-                });
-            }
         }
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
         for (uint32_t wv_id = 0; wv_id < n_waves && n_large; ++wv_id) {
@@ -214,6 +201,23 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 wave_ctx_flush(wk, ctx);
             });
         }
+        {
+            const int retry_cap = std::max(cap, (2 * big_thresh + 64 + 63) & ~63);
+            std::vector<unsigned char> rlds(tile_mem_bytes(retry_cap) + 64);
+            // retry list -> tile code, a few items per wave
+            uint32_t n_retry = (uint32_t)counters[CNT_NRETRY];
+            const uint32_t per = 1;
+            for (uint32_t r = 0; r < n_retry; r += per) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 555 + r : 0;
+                TileMem m = carve_tile_mem(rlds.data(), retry_cap);
+                w.run([&]() {
+                    WaveCtx ctx;
+                    lift_tile(ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+                    wave_ctx_flush(wk, ctx);
+                });
+            }
+        }
         uint32_t n_big = (uint32_t)counters[CNT_NBIG];
         if (n_big) {
             std::vector<unsigned char> scratch(tile_mem_bytes(big_cap) + 64);
@@ -225,7 +229,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.run([&]() {
                     WaveCtx ctx;
                     for (uint32_t i = wv_id; i < n_big; i += n_bw) {
-                        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, true, 0, ctx);
+                        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
                         wv::sync();
                     }
                     wave_ctx_flush(wk, ctx);

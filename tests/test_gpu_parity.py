@@ -100,17 +100,47 @@ def test_synthetic_plumbing_config(oracle):
     eng_ix.close()
 
 
-def test_synthetic_indel_dense_large_item_kernel(oracle):
+def _indel_dense_workload():
     cfg = synth.config("tiny", n_reads=200, seed=203, read_len_mean=6000, read_len_sd=1500,
                        read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
                        contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
-    w = synth.generate(cfg)
+    return synth.generate(cfg)
+
+
+def test_synthetic_indel_dense_large_item_kernel(oracle, monkeypatch):
+    """fixed geometry: items heavier than the routing threshold run alone from global scratch (k_lift_big), tiles that
+    overflow their LDS slice are re-run one item per wave (k_lift_retry)"""
+    monkeypatch.setenv("PLO_WINDOW", "256")
+    monkeypatch.setenv("PLO_BIG_THRESH", "176")
+    monkeypatch.setenv("PLO_CAP", "320")
+    w = _indel_dense_workload()
     ix, b = w.index_data(), w.batch_data()
     eng_ix = api.Index(ix)
     eng = api.Engine(eng_ix)
     got = eng.liftover_batch(b)
     assert eng.timing().n_big_items > 0
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "indel_dense")
+    eng.close()
+    eng_ix.close()
+
+
+def test_synthetic_indel_dense_adaptive_geometry(oracle):
+    """default: the routing threshold / LDS slice follow the batch's weight distribution, the same items stay in tiles"""
+    w = _indel_dense_workload()
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    got = eng.liftover_batch(b)
+    t = eng.timing()
+    assert t.n_big_items < t.n_items // 4
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "indel_dense_adaptive")
+    # a sparse batch after a dense one on the same context goes back to the small geometry
+    w2 = synth.generate(synth.config("tiny", n_reads=100, seed=209))
+    eng_ix2 = api.Index(w2.index_data())
+    eng2 = api.Engine(eng_ix2)
+    _assert_same(oracle.liftover_batch(w2.index_data(), w2.batch_data(), abi.STAGES_ALL, 2), eng2.liftover_batch(w2.batch_data()), "sparse")
+    eng2.close()
+    eng_ix2.close()
     eng.close()
     eng_ix.close()
 

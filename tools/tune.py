@@ -19,6 +19,7 @@ ap.add_argument("--settings", default="160:176:512,128:144:384,96:112:320,256:25
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--stages", default="31")
 ap.add_argument("--rev-frac", type=float, default=0.5)
+ap.add_argument("--contig-indel", type=float, default=-1.0, help="contig-vs-reference insertion and deletion rate (default: the workload's 1e-4 each)")
 ap.add_argument("--lib", default="", help="alternative library file name under portello_amd/")
 ap.add_argument("--timing", action="store_true", help="use the instrumented build and print per-phase cycles")
 args = ap.parse_args()
@@ -31,16 +32,25 @@ if args.timing:
     L = api.load_library(os.path.join(ROOT, "portello_amd", "libportello_liftover_timing.so"))
     L.plo_ctx_phase_cycles.restype = None
     L.plo_ctx_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-w = synth.generate(synth.config(args.workload, n_reads=args.reads, rev_contig_frac=args.rev_frac), device=dev)
+over = dict(n_reads=args.reads, rev_contig_frac=args.rev_frac)
+if args.contig_indel >= 0:
+    over["contig_rates"] = synth.EditRates(mismatch=1e-3, ins=args.contig_indel, dele=args.contig_indel, hpol_frac=0.3, big_indel_prob=0.02)
+w = synth.generate(synth.config(args.workload, **over), device=dev)
 index = api.Index(w.index_data_device(), 0)
 db = devbatch.DeviceBatch.from_workload(w)
 desc = db.desc()
 for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",")]:
     stages = int(s[1])
-    parts = s[0].split(":")
-    win, thr, cap = parts[:3]
-    os.environ["PLO_TILE_WAVES"] = parts[3] if len(parts) > 3 else "4"
-    os.environ["PLO_WINDOW"], os.environ["PLO_BIG_THRESH"], os.environ["PLO_CAP"] = win, thr, cap
+    if s[0] == "auto":  # the engine's own per-batch geometry
+        for k in ("PLO_TILE_WAVES", "PLO_WINDOW", "PLO_BIG_THRESH", "PLO_CAP"):
+            os.environ.pop(k, None)
+        win = thr = cap = "auto"
+        os.environ["PLO_DEBUG_GEOMETRY"] = "1"
+    else:
+        parts = s[0].split(":")
+        win, thr, cap = parts[:3]
+        os.environ["PLO_TILE_WAVES"] = parts[3] if len(parts) > 3 else "4"
+        os.environ["PLO_WINDOW"], os.environ["PLO_BIG_THRESH"], os.environ["PLO_CAP"] = win, thr, cap
     eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
     ms, big, en, ln = [], [], [], []
     for i in range(args.steps + 1):
@@ -48,12 +58,12 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         t = eng.timing()
         if i:
             ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.lanes_ms)
-    print(f"tw={os.environ['PLO_TILE_WAVES']} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(ln):.3f} ms ({t.n_lane_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
+    print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(ln):.3f} ms ({t.n_lane_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
           f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big))/1e3:.1f} M items/s", flush=True)
     if args.timing:
         ph = (C.c_ulonglong * 12)()
         L.plo_ctx_phase_cycles(eng.handle, ph)
         tot = sum(ph) or 1
         names = ["desc", "load+lshiftA", "lshift cc", "lift:stage+passA", "lift:scatter+passB", "lift:cc", "lencheck", "simplify A+H+B", "simplify cc", "output", "lshift H", "lshift B"]
-        print("   phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/tile-wave {tot/ max(1,(t.n_in_ops//int(win)+1)):.0f}", flush=True)
+        print("   phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/tile-wave {tot/ max(1,(t.n_in_ops//(int(win) if win != 'auto' else 256)+1)):.0f}", flush=True)
     eng.close()
