@@ -566,15 +566,33 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     bool overflow = false;
     unsigned long long algo_bytes = 0;
 
-    // block-map entries of the item's window: issued now, consumed at the liftover stage (hidden behind LOAD / LSHIFT)
-    constexpr int KV_PF = 6;
-    KV kv_pre[KV_PF];
+    // Block-map windows of the tile's items -> LDS (m.K / m.V), flattened: entry j of the tile belongs to the item whose
+    // [kb, kb + nk) contains j.  Only the source indices are computed here (into the idle ping-pong array); the loads go out
+    // together with the CIGAR gather below, so that both cost one memory round trip per tile.
     const int nk_all = (has && (stages & PLO_STAGE_LIFTOVER)) ? (wv::imin(W1 + 1, kv1) - W0) : 0;
-#pragma unroll
-    for (int k = 0; k < KV_PF; ++k) {
-        kv_pre[k].key = 0;
-        kv_pre[k].val = 0;
-        if (k < nk_all) kv_pre[k] = ix.kv[W0 + k];
+    const int inck = wv::scan_add(nk_all);
+    const int kb = inck - nk_all;
+    const int nkT = wv::bcast_last(inck);
+    const bool staged = nkT <= m.capk;
+    int *const srcK = (int *)m.B;
+    if (staged && nkT > 0) {
+        for (int base = 0; base < nkT; base += 64) {
+            int j = base + lane;
+            if (j < nkT) m.T3[j] = 0;
+        }
+        wv::sync();
+        if (nk_all > 0) m.T3[kb] = lane + 1;
+        wv::sync();
+        MaxScan owner(0);
+        for (int base = 0; base < nkT; base += 64) {
+            int j = base + lane;
+            bool valid = j < nkT;
+            int id = owner.incl(valid ? m.T3[j] : 0) - 1;
+            if (id < 0) id = 0;
+            int i_w0 = wv::shfl(W0, id), i_kb = wv::shfl(kb, id);
+            if (valid) srcK[j] = i_w0 + (j - i_kb);
+        }
+        wv::sync();
     }
     PLO_T(0)
     // ---- LOAD: flattened op stream of the tile (reversed for reverse-mapped contig segments, :167) --------------
@@ -611,20 +629,32 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // the gather carries no cross-lane dependency: the loads of four chunks are in flight together (indices first,
         // then all loads, then all stores -- written out because the compiler must assume that m.A aliases m.T0 and
         // would otherwise finish every chunk's store before the next chunk's index read)
-        for (int base = 0; base < nA; base += 256) {
-            int src[4];
+        const int nkS = staged ? nkT : 0;  // block-map entries to stage
+        for (int base = 0; base < nA || base < nkS; base += 256) {
+            int src[4], ksrc[4];
             uint32_t v[4];
+            KV kvv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int e = base + 64 * u + lane;
                 src[u] = e < nA ? m.T0[e] : -1;
+                ksrc[u] = e < nkS ? srcK[e] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = src[u] >= 0 ? bt.cigar[src[u]] : 0u;
+            for (int u = 0; u < 4; ++u) {
+                v[u] = src[u] >= 0 ? bt.cigar[src[u]] : 0u;
+                kvv[u].key = 0;
+                kvv[u].val = 0;
+                if (ksrc[u] >= 0) kvv[u] = ix.kv[ksrc[u]];
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int e = base + 64 * u + lane;
                 if (e < nA) m.A[e] = v[u];
+                if (e < nkS) {
+                    m.K[e] = kvv[u].key;
+                    m.V[e] = kvv[u].val;
+                }
             }
         }
         wv::sync();
@@ -633,8 +663,10 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     PLO_T(1)
     // ---- LEFT SHIFT (left_shift_indels.rs:17-39 + cigar_indel_shifter.rs:10-165), items with do_shift ---------------
     if (!overflow && wv::ballot(has && do_shift) != 0ull) {
-        // pass A: classes, heads, cluster sums, positions
+        // pass A: classes, heads, cluster sums, positions.  The list of cluster heads lives in the idle ping-pong array
+        // (m.K / m.V hold the staged block maps).
         int nH = 0;
+        int *const heads_list = (int *)m.B;
         {
             SegSum sr, sq, sm;
             MaxScan pnz(-1), heads(-1);
@@ -666,10 +698,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 bool event = chead || isO;
                 int hidx = heads.incl(chead ? e : -1);
                 int hrank = hcount.excl(chead ? 1 : 0);
-                if (chead) {
-                    if (hrank < m.capk) m.K[hrank] = e;  // compact list of cluster heads
-                    else overflow = true;
-                }
+                if (chead) heads_list[hrank] = e;  // compact list of cluster heads (hrank < nA <= cap)
                 if (valid) {
                     m.T0[e] = i_pos + R;  // indel_block_ref_start
                     m.T1[e] = Q;          // indel_block_read_start
@@ -688,7 +717,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         for (int base = 0; base < nH && !overflow; base += 64) {
             int hl = base + lane;
             bool valid = hl < nH;
-            int e = valid ? m.K[hl] : 0;
+            int e = valid ? heads_list[hl] : 0;
             int id = m.idA[e] & 63;
             int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(shift_ref_len, id);
             unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(shift_ref, id);
@@ -700,7 +729,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                                       panic, probes);
                 algo_bytes += 2ull * (unsigned)probes;
                 if (panic) wv::atomic_or(&m.itp[id], 1);
-                m.V[hl] = h;
+                m.T1[e] = h;  // the read start is not needed any more: the head's slot carries the homology to pass B
             }
         }
         wv::sync();
@@ -709,7 +738,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         int nB = 0;
         {
             MaxScan ev(-1);
-            AddScan emit, hcount;
+            AddScan emit;
             wv::MinPlus carryF = {0, IMAX, 0};
             int carry_r = 0;
             for (int base = 0; base < nA; base += 64) {
@@ -733,9 +762,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     del = m.T3[e];
                     ins = m.T4[e];
                 }
-                int hrank = hcount.excl((on && chead) ? 1 : 0);
                 if (on && chead) {
-                    h = hrank < m.capk ? m.V[hrank] : 0;  // left homology from pass H
+                    h = m.T1[e];  // left homology from pass H
                     f.a = m_e;
                     f.b = h;
                     f.s = have_prev ? 0 : 1;
@@ -821,25 +849,6 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
         } else {
             W1 = W0;
-        }
-        int nk = alive ? nk_all : 0;
-        int inck = wv::scan_add(nk);
-        int kb = inck - nk;
-        const bool staged = wv::bcast_last(inck) <= m.capk;
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < KV_PF; ++k) {
-                if (k < nk) {
-                    m.K[kb + k] = kv_pre[k].key;
-                    m.V[kb + k] = kv_pre[k].val;
-                }
-            }
-            for (int k = KV_PF; k < nk; ++k) {
-                KV e = ix.kv[W0 + k];
-                m.K[kb + k] = e.key;
-                m.V[kb + k] = e.val;
-            }
-            wv::sync();
         }
         // pass A: per op, first block f and number of (op x block) pieces.  Passes A and B are instantiated once for block
         // maps staged in LDS and once for maps read from global memory (a run-time select between the two pointers would
@@ -1065,6 +1074,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         wv::sync();
         // pass A: clusters = maximal runs of I/D ops; sums at the cluster head; compact list of cluster heads
         int nH = 0;
+        int *const heads_list = (int *)m.B;
         bool changes = false;  // some cluster is not a single I/D op of non-zero length
         {
             SegSum sr, sq;
@@ -1089,10 +1099,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 changes |= isC && (!chead || L == 0);
                 int hidx = heads.incl(chead ? e : -1);
                 int hrank = hcount.excl(chead ? 1 : 0);
-                if (chead) {
-                    if (hrank < m.capk) m.K[hrank] = e;
-                    else overflow = true;
-                }
+                if (chead) heads_list[hrank] = e;
                 if (valid) {
                     m.T0[e] = i_pos + R;  // block_ref_start
                     m.T1[e] = Q;          // block_read_start
@@ -1112,7 +1119,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         for (int base = 0; base < nH && !overflow; base += 64) {
             int hl = base + lane;
             bool valid = hl < nH;
-            int e = valid ? m.K[hl] : 0;
+            int e = valid ? heads_list[hl] : 0;
             int id = m.idA[e] & 63;
             int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(chrom_ref_len, id);
             unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(chrom_ref, id);
@@ -1147,14 +1154,14 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         complex_done = 1;
                     }
                 }
-                m.V[hl] = complex_done;
+                m.T2[e] = complex_done;
             }
         }
         wv::sync();
         // pass B: emission
         int nB = 0;
         {
-            AddScan emit, hcount;
+            AddScan emit;
             for (int base = 0; base < nA; base += 64) {
                 int e = base + lane;
                 bool valid = e < nA;
@@ -1165,7 +1172,6 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 int i_on = wv::shfl((int)simp, id);
                 int t = op_type(c);
                 bool on = valid && i_on;
-                int hrank = hcount.excl((on && chead) ? 1 : 0);
                 // up to four ops per element, as flags + values (no indexed local array: that would live in scratch)
                 const bool cp = valid && !(on && is_indel(t));  // :144-147 everything outside a cluster is copied
                 const bool ch = on && is_indel(t) && chead;
@@ -1173,7 +1179,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 if (ch) {
                     del = m.T3[e];
                     ins = m.T4[e];
-                    was_complex = hrank < m.capk ? m.V[hrank] : 0;
+                    was_complex = m.T2[e];
                     if (was_complex) {
                         pre = m.T0[e];
                         post = m.T1[e];
