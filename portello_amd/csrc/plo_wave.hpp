@@ -83,16 +83,15 @@ PLO_DEV int reduce_max(int x) { return bcast_last(scan_max(x)); }
 struct MinPlus {
     int a, b, s;
 };
-PLO_DEV int sat_add(int x, int y) {
-    long long t = (long long)x + (long long)y;
-    return t > 0x7fffffffLL ? 0x7fffffff : (int)t;
+PLO_DEV int sat_add(int x, int y) {  // x, y >= 0 (match lengths, homologies, IMAX): the unsigned sum cannot wrap
+    unsigned t = (unsigned)x + (unsigned)y;
+    return (int)(t < 0x7fffffffu ? t : 0x7fffffffu);
 }
-PLO_DEV MinPlus mp_compose(MinPlus p, MinPlus c) {  // apply p first, then c
+PLO_DEV MinPlus mp_compose(MinPlus p, MinPlus c) {  // apply p first, then c (branch-free)
     MinPlus r;
-    if (c.s) return c;
-    r.a = sat_add(p.a, c.a);
-    r.b = imin(sat_add(p.b, c.a), c.b);
-    r.s = p.s;
+    r.a = c.s ? c.a : sat_add(p.a, c.a);
+    r.b = c.s ? c.b : imin(sat_add(p.b, c.a), c.b);
+    r.s = c.s ? c.s : p.s;
     return r;
 }
 PLO_DEV MinPlus scan_minplus(MinPlus x) {
