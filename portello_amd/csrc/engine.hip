@@ -875,10 +875,17 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         if (n_items) hipLaunchKernelGGL(k_class_flags, dim3((n_items + 255) / 256), dim3(256), 0, st,
                                         (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>(),
                                         c->cls1.as<uint32_t>(), c->cls2.as<uint32_t>());
-        plo_status s = scan_u32(c, c->cls0.as<uint32_t>(), n_items, c->rank0.as<uint32_t>());
-        if (s != PLO_OK) return s;
-        s = scan_u32(c, c->cls1.as<uint32_t>(), n_items, c->rank1.as<uint32_t>());
-        if (s != PLO_OK) return s;
+        plo_status s = PLO_OK;
+        if (c->lane_max_in < 0) {
+            // lane kernel off: every item is "large" (classes 2 and 3 only), the ranks of classes 0 and 1 are all zero
+            HIP_TRY(c, hipMemsetAsync(c->rank0.p, 0, ((size_t)n_items + 1) * 4, st));
+            HIP_TRY(c, hipMemsetAsync(c->rank1.p, 0, ((size_t)n_items + 1) * 4, st));
+        } else {
+            s = scan_u32(c, c->cls0.as<uint32_t>(), n_items, c->rank0.as<uint32_t>());
+            if (s != PLO_OK) return s;
+            s = scan_u32(c, c->cls1.as<uint32_t>(), n_items, c->rank1.as<uint32_t>());
+            if (s != PLO_OK) return s;
+        }
         s = scan_u32(c, c->cls2.as<uint32_t>(), n_items, c->rank2.as<uint32_t>());
         if (s != PLO_OK) return s;
         if (n_items) hipLaunchKernelGGL(k_permute, dim3((n_items + 255) / 256), dim3(256), 0, st,
