@@ -258,6 +258,29 @@ typedef struct plo_finish_out {
 
 plo_status plo_finish_batch_dev(plo_ctx *ctx, const plo_batch_in *in, const plo_finish_in *fin, plo_finish_out *out);
 
+/* ---- SA tag text (device-resident) ----------------------------------------------------------------------------
+ * Consumes the results of the preceding plo_liftover_batch_dev + plo_finish_batch_dev on the same context and writes,
+ * for every LIFTED item of a read that has at least two lifted records, the text of get_sa_tag_segment
+ * (src/read_alignment_scanner.rs:292-301): "{chrom},{pos+1},{strand},{cigar},{mapq},0;".  The SA:Z value of record j is
+ * the concatenation of the segments of the read's other lifted items in item order (:352-364, done by the caller:
+ * items of a read are consecutive).  Chromosome labels are ChromList labels (the reference BAM header's @SQ names).
+ * All pointers are device pointers; outputs are owned by the context and valid until its next call. */
+typedef struct plo_sa_in {
+    uint32_t n_chroms;
+    const uint32_t *chrom_name_off; /* [n_chroms + 1] byte offsets into chrom_names                    */
+    const uint8_t *chrom_names;     /* concatenated labels, no terminators                             */
+} plo_sa_in;
+
+typedef struct plo_sa_out {
+    uint32_t n_items;
+    const uint32_t *item_sa_off;    /* [n_items + 1] byte offsets into sa_text; empty range = no segment */
+    const uint8_t *sa_text;
+    uint64_t sa_bytes;
+    float sa_ms;
+} plo_sa_out;
+
+plo_status plo_sa_segments_dev(plo_ctx *ctx, const plo_sa_in *in, plo_sa_out *out);
+
 plo_status plo_ctx_sync(plo_ctx *ctx);
 /* Copies `bytes` from device memory (e.g. a plo_liftover_batch_dev output array) to host memory on the context's
    stream and waits for it. */

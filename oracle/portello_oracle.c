@@ -7,6 +7,8 @@
 #include "portello_oracle.h"
 
 #include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1150,4 +1152,58 @@ void orc_finish_free(plo_finish_out *out) {
     free((void *)out->rev_seq);
     free((void *)out->rev_qual);
     memset(out, 0, sizeof(*out));
+}
+
+/* ---- SA tag text: src/read_alignment_scanner.rs:292-301, :348-364 ---------------------------------------------- */
+
+typedef struct {
+    char *p;
+    size_t n, cap;
+} sbuf;
+static void sb_putf(sbuf *b, const char *fmt, ...) {
+    va_list ap;
+    for (;;) {
+        va_start(ap, fmt);
+        int w = vsnprintf(b->p + b->n, b->cap - b->n, fmt, ap);
+        va_end(ap);
+        if (w >= 0 && (size_t)w < b->cap - b->n) {
+            b->n += (size_t)w;
+            return;
+        }
+        b->cap = b->cap ? b->cap * 2 : 256;
+        b->p = (char *)realloc(b->p, b->cap);
+    }
+}
+/* :292-301 get_sa_tag_segment: "{chrom},{pos+1},{schar},{cigar},{mapq},0;" */
+static void sa_tag_segment(sbuf *b, const char *chrom, int64_t pos, int is_reverse, const uint32_t *cig, uint32_t n, unsigned mapq) {
+    static const char opc[] = "MIDNSHP=X";
+    sb_putf(b, "%s,%lld,%c,", chrom, (long long)(pos + 1), is_reverse ? '-' : '+');
+    for (uint32_t k = 0; k < n; ++k) sb_putf(b, "%u%c", (unsigned)CIG_LEN(cig[k]), CIG_OP(cig[k]) < 9 ? opc[CIG_OP(cig[k])] : '?');
+    sb_putf(b, ",%u,0;", mapq);
+}
+int orc_sa_values(const plo_batch_in *in, const plo_batch_out *lift, const uint16_t *item_flag, const char *const *chrom_names,
+                  char **values) {
+    uint32_t ni = lift->n_items;
+    for (uint32_t i = 0; i < ni; ++i) values[i] = NULL;
+    uint32_t i0 = 0;
+    while (i0 < ni) { /* the records of one read: consecutive items */
+        uint32_t r = in->seg_read[lift->item_seg[i0]], i1 = i0;
+        while (i1 < ni && in->seg_read[lift->item_seg[i1]] == r) ++i1;
+        for (uint32_t i = i0; i < i1; ++i) { /* :352-364 */
+            if (lift->item_status[i] != PLO_ITEM_LIFTED) continue;
+            sbuf b = {NULL, 0, 0};
+            for (uint32_t j = i0; j < i1; ++j) {
+                if (j == i || lift->item_status[j] != PLO_ITEM_LIFTED) continue;
+                sa_tag_segment(&b, chrom_names[lift->item_chrom_index[j]], lift->item_ref_pos[j], (item_flag[j] & 0x10) != 0,
+                               lift->cigar + lift->item_cigar_off[j], lift->item_cigar_len[j], lift->item_mapq[j]);
+            }
+            if (b.n) values[i] = b.p; /* :360 !aux_str.is_empty() */
+            else free(b.p);
+        }
+        i0 = i1;
+    }
+    return 0;
+}
+void orc_sa_free(char **values, uint32_t n_items) {
+    for (uint32_t i = 0; i < n_items; ++i) free(values[i]);
 }

@@ -86,6 +86,15 @@ uint16_t orc_bam_reg2bin(uint64_t begin, uint64_t end);
 int orc_finish_batch(const plo_batch_in *in, const plo_finish_in *fin, const plo_batch_out *lift, plo_finish_out *out);
 void orc_finish_free(plo_finish_out *out);
 
+/* SA:Z values restated from src/read_alignment_scanner.rs:292-301 (get_sa_tag_segment) and :348-364 (every lifted record
+ * of a read gets the segments of the read's other lifted records, in record order; nothing when there are none).
+ * `item_flag` = flags of the lifted records (orc_finish_batch), `chrom_names` = ChromList labels.  values[i] is a malloc'ed
+ * NUL-terminated string, or NULL when record i gets no SA tag (orc_sa_free).  The CIGAR text follows rust-htslib 0.50.0's
+ * Display for CigarStringView ("{len}{char}" per op; third-party, not under /root/reference: parity unpinned for it). */
+int orc_sa_values(const plo_batch_in *in, const plo_batch_out *lift, const uint16_t *item_flag, const char *const *chrom_names,
+                  char **values);
+void orc_sa_free(char **values, uint32_t n_items);
+
 #ifdef __cplusplus
 }
 #endif

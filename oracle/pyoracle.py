@@ -258,3 +258,31 @@ def finish_batch(batch: abi.BatchData, read_flags, qual, read_qual_off, lift: ab
     res["rev_qual"] = cp(out.rev_qual, np.uint8, int(out.rev_qual_bytes))
     lib().orc_finish_free(C.byref(out))
     return res
+
+
+def sa_values(batch: abi.BatchData, lift: abi.BatchResult, item_flag, chrom_names) -> list:
+    """SA:Z values (orc_sa_values): bytes per item, None where the record gets no SA tag."""
+    b = batch.to_desc()
+    arrs = {n: np.ascontiguousarray(getattr(lift, n)) for n in ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq",
+                                                                 "item_chrom_index", "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")}
+    lo = abi.PloBatchOut()
+    lo.n_items = lift.n_items
+    for n, t in (("item_seg", C.c_uint32), ("item_cseg", C.c_uint32), ("item_status", C.c_uint8), ("item_need_flipped", C.c_uint8),
+                 ("item_mapq", C.c_uint8), ("item_chrom_index", C.c_uint32), ("item_ref_pos", C.c_int64), ("item_cigar_off", C.c_uint64),
+                 ("item_cigar_len", C.c_uint32), ("cigar", C.c_uint32)):
+        setattr(lo, n, _p(arrs[n], t))
+    lo.n_cigar = len(arrs["cigar"])
+    fl = np.ascontiguousarray(item_flag, dtype=np.uint16)
+    names = (C.c_char_p * max(1, len(chrom_names)))(*[n.encode() if isinstance(n, str) else n for n in chrom_names])
+    n = lift.n_items
+    vals = (C.c_void_p * max(1, n))()
+    L = lib()
+    L.orc_sa_values.restype = C.c_int
+    L.orc_sa_values.argtypes = [C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloBatchOut), C.POINTER(C.c_uint16), C.POINTER(C.c_char_p),
+                                C.POINTER(C.c_void_p)]
+    L.orc_sa_free.restype = None
+    L.orc_sa_free.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]
+    assert L.orc_sa_values(C.byref(b), C.byref(lo), _p(fl, C.c_uint16), names, vals) == 0
+    out = [C.string_at(vals[i]) if vals[i] else None for i in range(n)]
+    L.orc_sa_free(vals, n)
+    return out

@@ -143,6 +143,14 @@ class PloFinishOut(C.Structure):
     ]
 
 
+class PloSaIn(C.Structure):
+    _fields_ = [("n_chroms", C.c_uint32), ("chrom_name_off", _u32p), ("chrom_names", _u8p)]
+
+
+class PloSaOut(C.Structure):
+    _fields_ = [("n_items", C.c_uint32), ("item_sa_off", _u32p), ("sa_text", _u8p), ("sa_bytes", C.c_uint64), ("sa_ms", C.c_float)]
+
+
 FINISH_ITEM_FIELDS = [("item_flag", np.uint16), ("item_bin", np.uint16), ("item_ref_end", np.int64), ("item_is_primary", np.uint8),
                       ("item_seq_off", np.uint64), ("item_qual_off", np.uint64)]
 FINISH_READ_FIELDS = [("read_n_lifted", np.uint32), ("read_primary_item", np.uint32), ("read_unmapped_flag", np.uint16),

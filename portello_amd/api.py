@@ -58,6 +58,8 @@ def load_library(path: Optional[str] = None):
     L.plo_liftover_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
     L.plo_liftover_batch_dev.restype = C.c_int
     L.plo_liftover_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
+    L.plo_sa_segments_dev.restype = C.c_int
+    L.plo_sa_segments_dev.argtypes = [vp, C.POINTER(abi.PloSaIn), C.POINTER(abi.PloSaOut)]
     L.plo_finish_batch_dev.restype = C.c_int
     L.plo_finish_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloFinishOut)]
     L.plo_ctx_sync.restype = C.c_int
@@ -146,6 +148,12 @@ class Engine:
         """Record finishing for the last liftover_batch_dev result (plo_finish_batch_dev); device pointers."""
         out = abi.PloFinishOut()
         self._check(self.lib.plo_finish_batch_dev(self.handle, C.byref(desc), C.byref(fin), C.byref(out)), "plo_finish_batch_dev")
+        return out
+
+    def sa_segments_dev(self, sa_in: abi.PloSaIn) -> abi.PloSaOut:
+        """SA-tag segments of the last liftover + finish result (plo_sa_segments_dev); device pointers."""
+        out = abi.PloSaOut()
+        self._check(self.lib.plo_sa_segments_dev(self.handle, C.byref(sa_in), C.byref(out)), "plo_sa_segments_dev")
         return out
 
     def download(self, dev_ptr, dtype, count: int) -> np.ndarray:
@@ -305,3 +313,23 @@ def left_shift_indels(ref_pos: int, cigar: Sequence[int], ref_seq: bytes, read_s
     cs = CaseSet()
     cs.add_left_shift(ref_pos, cigar, ref_seq, read_seq)
     return cs.run(abi.STAGE_LSHIFT, backend)[0]
+
+
+def assemble_sa_values(seg_off: np.ndarray, text: np.ndarray, item_read: np.ndarray) -> list:
+    """SA:Z value of every item from the per-item segments (src/read_alignment_scanner.rs:352-364): the segments of the
+    read's other items, in item order; None where the record gets no SA tag.  Items of a read are consecutive."""
+    n = len(item_read)
+    t = text.tobytes()
+    segs = [t[int(seg_off[i]):int(seg_off[i + 1])] for i in range(n)]
+    out = [None] * n
+    i0 = 0
+    while i0 < n:
+        i1 = i0
+        while i1 < n and item_read[i1] == item_read[i0]:
+            i1 += 1
+        for i in range(i0, i1):
+            if segs[i]:
+                v = b"".join(segs[j] for j in range(i0, i1) if j != i)
+                out[i] = v if v else None
+        i0 = i1
+    return out

@@ -307,6 +307,15 @@ __global__ void k_finish_offsets(DevBatch bt, DevWork wk, DevFinish f) {
         f.read_qual_off_out[e - n] = qo;
     }
 }
+// SA tag text: thread per item (only the few items of reads with several lifted records produce text)
+__global__ void k_sa_len(DevWork wk, DevSa sa) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wk.n_items) sa.len[i] = sa_item_len(wk, sa, i);
+}
+__global__ void k_sa_emit(DevWork wk, DevSa sa) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wk.n_items) sa_item_emit(wk, sa, i);
+}
 // reverse_alignment_seq_and_qual: one workgroup per record that needs it, streaming 16-byte-aligned outputs.
 // HBM-bound: per flipped read L/2 + L bytes in, the same out.
 __global__ __launch_bounds__(256) void k_revcomp(DevBatch bt, DevWork wk, DevFinish f) {
@@ -423,11 +432,11 @@ struct plo_ctx {
     std::string err;
     // workspace
     DevBuf f_flag, f_bin, f_end, f_prim, f_isoff, f_iqoff, f_iread, f_nl, f_pitem, f_uflag, f_rsoff, f_rqoff, f_su, f_qu, f_soff,
-        f_qoff, f_rseq, f_rqual, f_fflag, f_frank, f_flist;
+        f_qoff, f_rseq, f_rqual, f_fflag, f_frank, f_flist, sa_len, sa_off, sa_text;
     DevWork last_wk{};
     DevBatch last_bt{};
-    bool have_last = false;
-    hipEvent_t fev[3] = {nullptr, nullptr, nullptr};
+    bool have_last = false, have_finish = false;
+    hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
@@ -681,7 +690,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipSetDevice(c->ix->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
-                      &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist,
+                      &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
                       &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
@@ -695,7 +704,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     for (HostBuf *b : hb) b->release();
     for (int i = 0; i < 6; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 5; ++i)
         if (c->fev[i]) (void)hipEventDestroy(c->fev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1059,6 +1068,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->last_wk = wk;
     c->last_bt = bt;
     c->have_last = true;
+    c->have_finish = false;
     return PLO_OK;
 }
 
@@ -1168,6 +1178,59 @@ plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_fi
     out->rev_qual = f.rev_qual;
     out->rev_seq_bytes = sb;
     out->rev_qual_bytes = qb;
+    c->have_finish = true;
+    return PLO_OK;
+}
+
+plo_status plo_sa_segments_dev(plo_ctx *c, const plo_sa_in *in, plo_sa_out *out) {
+    if (!c || !in || !out) return PLO_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    c->err.clear();
+    if (!c->have_last || !c->have_finish) {
+        c->err = "plo_sa_segments_dev: call plo_liftover_batch_dev and plo_finish_batch_dev on the batch first";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (in->n_chroms < c->ix->d.n_chroms || !in->chrom_name_off || (!in->chrom_names && in->n_chroms)) {
+        c->err = "plo_sa_in: one label per chromosome of the index is required";
+        return PLO_ERR_INVALID_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    hipStream_t st = c->stream;
+    for (int i = 3; i < 5; ++i)
+        if (!c->fev[i]) HIP_TRY(c, hipEventCreate(&c->fev[i]));
+    const DevWork &wk = c->last_wk;
+    uint32_t n = wk.n_items;
+    HIP_TRY(c, c->sa_len.ensure(((size_t)n + 1) * 4));
+    HIP_TRY(c, c->sa_off.ensure(((size_t)n + 1) * 4));
+    DevSa sa;
+    sa.chrom_name_off = in->chrom_name_off;
+    sa.chrom_names = in->chrom_names;
+    sa.item_flag = c->f_flag.as<uint16_t>();
+    sa.item_read = c->f_iread.as<uint32_t>();
+    sa.read_n_lifted = c->f_nl.as<uint32_t>();
+    sa.len = c->sa_len.as<uint32_t>();
+    sa.off = c->sa_off.as<uint32_t>();
+    sa.text = nullptr;
+    HIP_TRY(c, hipEventRecord(c->fev[3], st));
+    if (n) hipLaunchKernelGGL(k_sa_len, dim3((n + 255) / 256), dim3(256), 0, st, wk, sa);
+    HIP_TRY(c, hipGetLastError());
+    plo_status s = scan_u32(c, sa.len, n, c->sa_off.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    uint32_t *h = c->h_counters.as<uint32_t>();
+    HIP_TRY(c, hipMemcpyAsync(h, c->sa_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    uint64_t bytes = n ? h[0] : 0;
+    HIP_TRY(c, c->sa_text.ensure(std::max<uint64_t>(bytes, 16)));
+    sa.text = c->sa_text.as<uint8_t>();
+    if (bytes) hipLaunchKernelGGL(k_sa_emit, dim3((n + 255) / 256), dim3(256), 0, st, wk, sa);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->fev[4], st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&out->sa_ms, c->fev[3], c->fev[4]);
+    out->n_items = n;
+    out->item_sa_off = c->sa_off.as<uint32_t>();
+    out->sa_text = sa.text;
+    out->sa_bytes = bytes;
     return PLO_OK;
 }
 

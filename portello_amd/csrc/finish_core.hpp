@@ -96,6 +96,70 @@ PLO_DEV uint32_t u32_lower_bound(const uint32_t *a, uint32_t n, uint32_t x) {
     return lo;
 }
 
+// ---- SA tag text (get_sa_tag_segment, src/read_alignment_scanner.rs:292-301) ------------------------------------------
+// One segment "{chrom},{pos+1},{strand},{cigar},{mapq},0;" per lifted record of a read with at least two lifted records
+// (:352-364 give every record the segments of the read's *other* records, in record order; a read with one record gets
+// no SA tag).  The CIGAR is written as rust-htslib's Display does: "{len}{op}" per op, nothing for an empty CIGAR.
+struct DevSa {
+    const uint32_t *chrom_name_off;  // [n_chroms + 1]
+    const uint8_t *chrom_names;      // concatenated chromosome labels
+    const uint16_t *item_flag;
+    const uint32_t *item_read;
+    const uint32_t *read_n_lifted;
+    uint32_t *len;        // [n_items] bytes of the item's segment (0 = none)
+    const uint32_t *off;  // exclusive scan of len
+    uint8_t *text;
+};
+PLO_DEV uint32_t dec_digits(unsigned long long v) {
+    uint32_t n = 1;
+    while (v >= 10) {
+        v /= 10;
+        ++n;
+    }
+    return n;
+}
+PLO_DEV uint8_t *put_dec(uint8_t *p, unsigned long long v) {
+    uint32_t n = dec_digits(v);
+    for (uint32_t k = n; k > 0; --k) {
+        p[k - 1] = (uint8_t)('0' + (v % 10));
+        v /= 10;
+    }
+    return p + n;
+}
+PLO_DEV bool sa_wanted(const DevWork &wk, const DevSa &sa, uint32_t i) {
+    return wk.status[i] == PLO_ITEM_LIFTED && sa.read_n_lifted[sa.item_read[i]] >= 2;
+}
+PLO_DEV uint32_t sa_item_len(const DevWork &wk, const DevSa &sa, uint32_t i) {
+    if (!sa_wanted(wk, sa, i)) return 0;
+    uint32_t chrom = wk.chrom[i];
+    uint32_t n = sa.chrom_name_off[chrom + 1] - sa.chrom_name_off[chrom];
+    n += dec_digits((unsigned long long)(wk.pos[i] + 1)) + dec_digits(wk.mapq[i]) + 8;  // five commas, strand, "0;"
+    const uint32_t *cg = wk.out_cigar + wk.cig_off[i];
+    for (uint32_t k = 0; k < wk.cig_len[i]; ++k) n += dec_digits(cg[k] >> 4) + 1;
+    return n;
+}
+PLO_DEV void sa_item_emit(const DevWork &wk, const DevSa &sa, uint32_t i) {
+    if (!sa_wanted(wk, sa, i)) return;
+    uint8_t *p = sa.text + sa.off[i];
+    uint32_t chrom = wk.chrom[i];
+    for (uint32_t k = sa.chrom_name_off[chrom]; k < sa.chrom_name_off[chrom + 1]; ++k) *p++ = sa.chrom_names[k];
+    *p++ = ',';
+    p = put_dec(p, (unsigned long long)(wk.pos[i] + 1));
+    *p++ = ',';
+    *p++ = (sa.item_flag[i] & 0x10) ? '-' : '+';
+    *p++ = ',';
+    const uint32_t *cg = wk.out_cigar + wk.cig_off[i];
+    for (uint32_t k = 0; k < wk.cig_len[i]; ++k) {
+        p = put_dec(p, cg[k] >> 4);
+        *p++ = (uint8_t)"MIDNSHP=XB??????"[cg[k] & 15u];
+    }
+    *p++ = ',';
+    p = put_dec(p, wk.mapq[i]);
+    *p++ = ',';
+    *p++ = '0';
+    *p++ = ';';
+}
+
 // finish_remapped_alignment_set (:310-366): primary = highest MAPQ, first wins (:338-346); no record -> unmapped copy (:317-335)
 PLO_DEV void finish_read(const DevBatch &bt, const DevWork &wk, const DevFinish &f, uint32_t r) {
     uint32_t n = wk.n_items;

@@ -125,3 +125,20 @@ def download_finish(eng, fo: abi.PloFinishOut, n_items: int, n_reads: int) -> di
     res["rev_seq"] = eng.download(fo.rev_seq, np.uint8, int(fo.rev_seq_bytes))
     res["rev_qual"] = eng.download(fo.rev_qual, np.uint8, int(fo.rev_qual_bytes))
     return res
+
+
+def sa_inputs(names, dev):
+    """chromosome labels as device arrays + the plo_sa_in"""
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    off = np.zeros(len(enc) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy()
+    t_off = torch.from_numpy(off).to(dev)
+    t_blob = torch.from_numpy(blob).to(dev)
+    return abi.PloSaIn(len(enc), _p(t_off, C.c_uint32), _p(t_blob, C.c_uint8)), dict(off=t_off, blob=t_blob)
+
+
+def download_sa(eng, so: abi.PloSaOut):
+    off = eng.download(so.item_sa_off, np.uint32, int(so.n_items) + 1)
+    text = eng.download(so.sa_text, np.uint8, int(so.sa_bytes))
+    return off, text

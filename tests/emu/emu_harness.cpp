@@ -355,3 +355,45 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
 
 // the device comp_base (lift_core.hpp), for an exhaustive comparison with the oracle
 extern "C" int emu_comp_base(int b) { return plo::comp_base(b); }
+
+
+// SA tag segments: finish_core.hpp's sa_item_len / sa_item_emit executed on the host.  `lift` and the finish arrays are host
+// copies; text/off are malloc'ed and released by emu_sa_free.
+extern "C" int emu_sa_segments(const plo_batch_out *lift, const uint16_t *item_flag, const uint32_t *item_read, const uint32_t *read_n_lifted,
+                               const uint32_t *chrom_name_off, const uint8_t *chrom_names, uint32_t **off_out, uint8_t **text_out) {
+    DevWork wk;
+    memset(&wk, 0, sizeof(wk));
+    wk.n_items = lift->n_items;
+    wk.status = (uint8_t *)lift->item_status;
+    wk.chrom = (uint32_t *)lift->item_chrom_index;
+    wk.pos = (int64_t *)lift->item_ref_pos;
+    wk.mapq = (uint8_t *)lift->item_mapq;
+    wk.cig_off = (uint64_t *)lift->item_cigar_off;
+    wk.cig_len = (uint32_t *)lift->item_cigar_len;
+    wk.out_cigar = (uint32_t *)lift->cigar;
+    uint32_t n = lift->n_items;
+    std::vector<uint32_t> len(n + 1, 0);
+    uint32_t *off = (uint32_t *)malloc(((size_t)n + 1) * 4);
+    DevSa sa;
+    sa.chrom_name_off = chrom_name_off;
+    sa.chrom_names = chrom_names;
+    sa.item_flag = item_flag;
+    sa.item_read = item_read;
+    sa.read_n_lifted = read_n_lifted;
+    sa.len = len.data();
+    sa.off = off;
+    sa.text = nullptr;
+    for (uint32_t i = 0; i < n; ++i) len[i] = sa_item_len(wk, sa, i);
+    off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) off[i + 1] = off[i] + len[i];
+    uint8_t *text = (uint8_t *)malloc(off[n] ? off[n] : 1);
+    sa.text = text;
+    for (uint32_t i = 0; i < n; ++i) sa_item_emit(wk, sa, i);
+    *off_out = off;
+    *text_out = text;
+    return 0;
+}
+extern "C" void emu_sa_free(uint32_t *off, uint8_t *text) {
+    free(off);
+    free(text);
+}

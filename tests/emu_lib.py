@@ -81,3 +81,38 @@ def finish_batch(batch: abi.BatchData, read_flags, qual, read_qual_off, lift: ab
     res["rev_seq"] = cp(out.rev_seq, np.uint8, int(out.rev_seq_bytes))
     res["rev_qual"] = cp(out.rev_qual, np.uint8, int(out.rev_qual_bytes))
     return res
+
+
+def sa_segments(batch: abi.BatchData, lift: abi.BatchResult, item_flag, read_n_lifted, chrom_names):
+    """finish_core.hpp's SA-segment code executed on the host: (offsets [n_items+1], text bytes)"""
+    p = lambda arr, t: arr.ctypes.data_as(C.POINTER(t))
+    arrs = {n: np.ascontiguousarray(getattr(lift, n)) for n in ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq",
+                                                                 "item_chrom_index", "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")}
+    lo = abi.PloBatchOut()
+    lo.n_items = lift.n_items
+    for n, t in (("item_seg", C.c_uint32), ("item_cseg", C.c_uint32), ("item_status", C.c_uint8), ("item_need_flipped", C.c_uint8),
+                 ("item_mapq", C.c_uint8), ("item_chrom_index", C.c_uint32), ("item_ref_pos", C.c_int64), ("item_cigar_off", C.c_uint64),
+                 ("item_cigar_len", C.c_uint32), ("cigar", C.c_uint32)):
+        setattr(lo, n, p(arrs[n], t))
+    lo.n_cigar = len(arrs["cigar"])
+    fl = np.ascontiguousarray(item_flag, dtype=np.uint16)
+    item_read = np.ascontiguousarray(np.asarray(batch.seg_read, dtype=np.uint32)[arrs["item_seg"]], dtype=np.uint32)
+    nl = np.ascontiguousarray(read_n_lifted, dtype=np.uint32)
+    enc = [n.encode() if isinstance(n, str) else n for n in chrom_names]
+    noff = np.zeros(len(enc) + 1, dtype=np.uint32)
+    noff[1:] = np.cumsum([len(e) for e in enc])
+    blob = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy()
+    L = lib()
+    L.emu_sa_segments.restype = C.c_int
+    L.emu_sa_segments.argtypes = [C.POINTER(abi.PloBatchOut), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint8))]
+    L.emu_sa_free.restype = None
+    L.emu_sa_free.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+    off_p, text_p = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint8)()
+    assert L.emu_sa_segments(C.byref(lo), p(fl, C.c_uint16), p(item_read, C.c_uint32), p(nl, C.c_uint32), p(noff, C.c_uint32),
+                             p(blob, C.c_uint8), C.byref(off_p), C.byref(text_p)) == 0
+    n = lift.n_items
+    off = np.ctypeslib.as_array(off_p, shape=(n + 1,)).copy()
+    text = np.ctypeslib.as_array(text_p, shape=(max(1, int(off[n])),)).copy()[: int(off[n])]
+    L.emu_sa_free(off_p, text_p)
+    return off, text, item_read

@@ -128,3 +128,81 @@ def test_finish_hip_vs_oracle(oracle, seq_fmt):
     assert n_checked > 50
     eng.close()
     index.close()
+
+
+# ---- SA tag text (get_sa_tag_segment, src/read_alignment_scanner.rs:292-301, :348-364) --------------------------------------
+
+def _chrom_names(n):
+    return [f"chr{k + 1}" if k % 3 else f"chrUn_scaffold{k:04d}v1" for k in range(n)]
+
+
+def test_oracle_sa_format(oracle):
+    """hand-checked SA values on a two-record read (1-based position, strand from the record's reverse bit, CIGAR text)"""
+    C_ = abi
+    batch = C_.BatchData(read_is_reverse=[0], read_seq_len=[10], read_seq_off=[0], seq=np.zeros(5, np.uint8), seq_fmt=C_.SEQ_BAM4,
+                         seg_read=[0, 0], seg_contig=[0, 0], seg_pos=[0, 0], seg_is_fwd_strand=[1, 1], seg_cigar_off=[0, 1, 2],
+                         cigar=[(10 << 4) | 0, (10 << 4) | 0])
+    lift = C_.BatchResult(item_seg=np.array([0, 1], np.uint32), item_cseg=np.array([0, 0], np.uint32), item_status=np.array([0, 0], np.uint8),
+                          item_need_flipped=np.array([0, 1], np.uint8), item_mapq=np.array([60, 7], np.uint8),
+                          item_chrom_index=np.array([1, 0], np.uint32), item_ref_pos=np.array([99, 12344], np.int64),
+                          item_cigar_off=np.array([0, 3], np.uint64), item_cigar_len=np.array([3, 2], np.uint32),
+                          cigar=np.array([(4 << 4) | 4, (5 << 4) | 0, (1 << 4) | 2, (7 << 4) | 0, (3 << 4) | 1], np.uint32))
+    vals = oracle.sa_values(batch, lift, np.array([0x0, 0x810], np.uint16), ["chrA", "chrB"])
+    assert vals == [b"chrA,12345,-,7M3I,7,0;", b"chrB,100,+,4S5M1D,60,0;"]
+    # a read with a single lifted record gets no SA tag
+    lift.item_status = np.array([0, 1], np.uint8)
+    assert oracle.sa_values(batch, lift, np.array([0x0, 0x810], np.uint16), ["chrA", "chrB"]) == [None, None]
+
+
+def test_sa_device_code_on_host_vs_oracle(oracle):
+    import emu_lib
+    from portello_amd import api
+
+    n_with = 0
+    for seed in (421, 422):
+        w, b, flags, qual, qoff = _host_case(seed, abi.SEQ_BAM4)
+        ix = w.index_data()
+        lift = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1)
+        f = oracle.finish_batch(b, flags, qual, qoff, lift)
+        names = _chrom_names(len(ix.chrom_len))
+        ref = oracle.sa_values(b, lift, f["item_flag"], names)
+        off, text, item_read = emu_lib.sa_segments(b, lift, f["item_flag"], f["read_n_lifted"], names)
+        got = api.assemble_sa_values(off, text, item_read)
+        assert got == ref
+        n_with += sum(v is not None for v in ref)
+    assert n_with > 10
+
+
+@pytest.mark.gpu
+def test_sa_hip_vs_oracle(oracle):
+    import torch
+
+    from portello_amd import api, devbatch
+
+    w = synth.generate(synth.config("tiny", n_reads=600, seed=431, split_read_frac=0.3, read_len_mean=3000, read_len_sd=1200), device="cuda")
+    index = api.Index(w.index_data_device())
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    desc = db.desc()
+    fin, keep = devbatch.finish_inputs(w, db, seed=9)
+    ix = w.index_data()
+    names = _chrom_names(len(ix.chrom_len))
+    sa_in, keep_sa = devbatch.sa_inputs(names, db.seq.device)
+    torch.cuda.synchronize()
+    out = eng.liftover_batch_dev(desc)
+    with pytest.raises(api.PortelloError):  # needs the finishing results (record flags, records per read)
+        eng.sa_segments_dev(sa_in)
+    fo = eng.finish_batch_dev(desc, fin)
+    so = eng.sa_segments_dev(sa_in)
+    lift = devbatch.download(eng, out)
+    off, text = devbatch.download_sa(eng, so)
+    b = w.batch_data()
+    item_read = np.asarray(b.seg_read, dtype=np.uint32)[lift.item_seg]
+    got = api.assemble_sa_values(off, text, item_read)
+    olift = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 2)
+    of = oracle.finish_batch(b, keep["flags"].cpu().numpy().view(np.uint16), keep["qual"].cpu().numpy(), keep["qoff"].cpu().numpy(), olift)
+    ref = oracle.sa_values(b, olift, of["item_flag"], names)
+    assert got == ref
+    assert sum(v is not None for v in ref) > 20
+    eng.close()
+    index.close()
