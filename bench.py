@@ -16,6 +16,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -81,6 +82,14 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("PLO_BENCH_WORKLOAD", "wgs30x"))
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("PLO_BENCH_WORKERS", "1")),
+                    help="host worker threads per GPU, each with its own context and HIP stream (INTEGRATION.md: one plo_ctx per "
+                         "rayon worker); batches are dealt to them in turn, so one worker's enumerate pass and host syncs overlap the "
+                         "other's tile kernel.  Default 1: the HIP-event kernel times of the roofline object then measure execution "
+                         "only (with several streams they include the wait behind the other stream's kernel)")
+    ap.add_argument("--overlap-workers", type=int, default=2,
+                    help="after the timed region, repeat the same K steps with this many workers and report the rate as the "
+                         "supplementary object `overlap` (N = 1 only; 0/1 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,39 +123,98 @@ def main():
             f"{len(w.contig_len)} contigs / {len(w.seg_pos)} contig segments, generated on GPU in {t_gen:.1f}s")
 
     index = api.Index(w.index_data_device(), device=local_rank)
-    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    n_workers = max(1, args.workers)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
+    engs = [api.Engine(index, stream=s.cuda_stream) for s in streams]
+    eng = engs[0]
     db = devbatch.DeviceBatch.from_workload(w)
     desc = db.desc()
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def step():
-        out = eng.liftover_batch_dev(desc)
+    gather_lock = threading.Lock()  # one exchange at a time per rank: the n-th exchange of every rank pairs up
+    last_out = [None] * n_workers
+
+    def step(k):
+        out = engs[k].liftover_batch_dev(desc)
         if dist is not None:
-            plo_gather.gather_results(out, dev, dist, rank, world)
+            with gather_lock, torch.cuda.stream(streams[k]):
+                plo_gather.gather_results(out, dev, dist, rank, world)
+        last_out[k] = out
         return out
 
-    for _ in range(args.warmup):
-        out = step()
+    lift_ms, enum_ms, big_ms, lanes_ms, retry_ms = [], [], [], [], []
+
+    def run_steps(n_steps, record):
+        """n_steps batches, dealt to the workers in turn; every worker drives its own context on its own stream"""
+        errors = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(local_rank)
+                for _ in range(k, n_steps, n_workers):
+                    step(k)
+                    if record:
+                        tm = engs[k].timing()  # HIP events on the worker's stream (waits for the step)
+                        lift_ms.append(tm.lift_ms)
+                        enum_ms.append(tm.enumerate_ms)
+                        big_ms.append(tm.big_ms)
+                        lanes_ms.append(tm.lanes_ms)
+                        retry_ms.append(tm.retry_ms)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
+                errors.append(e)
+
+        if n_workers == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(n_workers)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errors:
+            raise errors[0]
+
+    run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    lift_ms, enum_ms, big_ms, lanes_ms, retry_ms = [], [], [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        tm = eng.timing()  # HIP events on the engine's stream (waits for the step)
-        lift_ms.append(tm.lift_ms)
-        enum_ms.append(tm.enumerate_ms)
-        big_ms.append(tm.big_ms)
-        lanes_ms.append(tm.lanes_ms)
-        retry_ms.append(tm.retry_ms)
+    run_steps(args.steps, True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    out = last_out[0]
+
+    overlap = None
+    if dist is None and n_workers == 1 and args.overlap_workers > 1:
+        # supplementary: the same K batches dealt to several workers (not `value`: see --workers)
+        ow = args.overlap_workers
+        o_streams = [torch.cuda.Stream(device=dev) for _ in range(ow)]
+        o_engs = [api.Engine(index, stream=s_.cuda_stream) for s_ in o_streams]
+
+        def o_run(n_steps):
+            th = [threading.Thread(target=lambda k=k: [o_engs[k].liftover_batch_dev(desc) for _ in range(k, n_steps, ow)]) for k in range(ow)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+        o_run(ow)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        o_run(args.steps)
+        torch.cuda.synchronize()
+        odt = time.perf_counter() - t1
+        overlap = {"host_workers_per_gpu": ow, "value": w.n_reads * args.steps / odt, "unit": "reads/s", "ms_per_step": odt / args.steps * 1e3,
+                   "note": "same K batches dealt to several host workers (one context + HIP stream each): enumerate pass and host syncs of one "
+                           "worker overlap the other's tile kernel; supplementary, the headline value is the single-worker rate"}
+        for e in o_engs:
+            e.close()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,7 +258,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
                    "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
-                   "large_items_per_gpu": int(tm.n_big_items), "lane_items_per_gpu": int(tm.n_lane_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}",
+                   "large_items_per_gpu": int(tm.n_big_items), "lane_items_per_gpu": int(tm.n_lane_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}", "host_workers_per_gpu": n_workers,
                    "gather": "rccl send/recv to rank 0" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -199,6 +267,8 @@ def main():
                      "lift_big_ms": float(np.mean(big_ms)), "lift_lanes_ms": float(np.mean(lanes_ms)),
                      "lift_retry_ms": float(np.mean(retry_ms))},
     }
+    if overlap is not None:
+        result["overlap"] = overlap
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cb, ok, n_checked = cpu_baseline(w, eng, db, out)
@@ -212,7 +282,8 @@ def main():
             result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     index.close()
     if dist is not None:
         dist.destroy_process_group()
