@@ -96,7 +96,7 @@ struct ReadSeq {
     int len;
     int fmt;
     int flip;
-    long long lo, hi;  // bytes p[lo .. hi) belong to the batch's seq buffer (bounds for the wide-window loads)
+    int lo, hi;  // bytes p[lo .. hi) belong to the batch's seq buffer (bounds for the wide-window loads), clamped to +-2^30
 };
 PLO_DEV int read_base(const ReadSeq &r, int i) {
     int j = r.flip ? (r.len - 1 - i) : i;
@@ -120,8 +120,9 @@ PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, in
     r.len = seq_len;
     r.fmt = bt.seq_fmt;
     r.flip = flip;
-    r.lo = -(long long)seq_off;
-    r.hi = (long long)bt.seq_bytes - (long long)seq_off;
+    const unsigned long long before = seq_off, after = bt.seq_bytes - seq_off;
+    r.lo = -(int)(before < (1ull << 30) ? before : (1ull << 30));
+    r.hi = (int)(after < (1ull << 30) ? after : (1ull << 30));
     return r;
 }
 
@@ -305,19 +306,20 @@ PLO_DEV unsigned comp4(unsigned w) {  // comp_base on the four ASCII bytes of w
 
 // X byte t (little-endian over X[0..3]) = ref[r0 + t] ^ read_base(rd, q0 + t), t = 0..15.
 // Returns false when a window does not lie inside its buffer: the caller then compares byte-wise.
-PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, long long r0, const ReadSeq &rd, long long q0, unsigned X[4]) {
-    if (r0 < 0 || q0 < 0 || q0 + 16 > (long long)rd.len) return false;
-    const unsigned rsh = (unsigned)(((unsigned long long)(uintptr_t)ref + (unsigned long long)r0) & 3ull);
-    if (r0 - (long long)rsh < 0 || r0 - (long long)rsh + 20 > (long long)ref_len) return false;
+PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, unsigned X[4]) {
+    // all positions are below 2^31 (BAM coordinates): 32-bit index arithmetic throughout
+    if (r0 < 0 || q0 < 0 || q0 > rd.len - 16) return false;
+    const int rsh = (int)(((unsigned)(uintptr_t)ref + (unsigned)r0) & 3u);
+    if (r0 - rsh < 0 || r0 - rsh > ref_len - 20) return false;
     // read bases q0 .. q0+15 are the stored positions jmin .. jmin+15 (in reverse order when flipped)
-    const long long jmin = rd.flip ? (long long)rd.len - q0 - 16 : q0;
+    const int jmin = rd.flip ? rd.len - q0 - 16 : q0;
     const bool bam4 = rd.fmt == PLO_SEQ_BAM4;
-    const long long b0 = bam4 ? (jmin >> 1) : jmin;  // first byte of the read window
-    const unsigned qsh = (unsigned)(((unsigned long long)(uintptr_t)rd.p + (unsigned long long)b0) & 3ull);
+    const int b0 = bam4 ? (jmin >> 1) : jmin;  // first byte of the read window
+    const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
     const int qwords = bam4 ? 3 : 5;
-    if (b0 - (long long)qsh < rd.lo || b0 - (long long)qsh + 4 * qwords > rd.hi) return false;
-    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ref + (r0 - (long long)rsh));
-    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(rd.p + (b0 - (long long)qsh));
+    if (b0 - qsh < rd.lo || b0 - qsh + 4 * qwords > rd.hi) return false;
+    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ref + (r0 - rsh));
+    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(rd.p + (b0 - qsh));
     unsigned wr[5], wq[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) wr[u] = pr[u];
@@ -329,7 +331,7 @@ PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, long long r0, const R
         unsigned S[5];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            unsigned Q = wv::align_bytes(wq[q + 1], wq[q], qsh);
+            unsigned Q = wv::align_bytes(wq[q + 1], wq[q], (unsigned)qsh);
             unsigned H = (Q >> 4) & 0x0f0f0f0fu, L = Q & 0x0f0f0f0fu;
             S[2 * q] = wv::perm_bytes(L, H, 0x05010400u);  // nibbles 8q .. 8q+3, one per byte
             if (2 * q + 1 < 5) S[2 * q + 1] = wv::perm_bytes(L, H, 0x07030602u);
@@ -350,13 +352,13 @@ PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, long long r0, const R
     } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            D[v] = wv::align_bytes(wq[v + 1], wq[v], qsh);
+            D[v] = wv::align_bytes(wq[v + 1], wq[v], (unsigned)qsh);
             if (rd.flip) D[v] = comp4(D[v]);
         }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        unsigned R = wv::align_bytes(wr[u + 1], wr[u], rsh);
+        unsigned R = wv::align_bytes(wr[u + 1], wr[u], (unsigned)rsh);
         unsigned B = rd.flip ? wv::perm_bytes(0u, D[3 - u], 0x00010203u) : D[u];
         X[u] = R ^ B;
     }
@@ -383,7 +385,7 @@ PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, const ReadSe
     int k = 0;
     while (k < maxk) {
         unsigned X[4];
-        if (!xor_window16(ref, ref_len, (long long)re - k - 16, rd, (long long)qe - k - 16, X)) break;
+        if (!xor_window16(ref, ref_len, re - k - 16, rd, qe - k - 16, X)) break;
         int n = wv::imin(16, maxk - k);
         int m = wv::imin(zero_bytes_from_top(X), n);
         probes += wv::imin(m + 1, n);
@@ -414,7 +416,7 @@ PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, const ReadSeq
     int k = 0;
     while (k < maxk) {
         unsigned X[4];
-        if (!xor_window16(ref, ref_len, (long long)rs + k, rd, (long long)qs + k, X)) break;
+        if (!xor_window16(ref, ref_len, rs + k, rd, qs + k, X)) break;
         int n = wv::imin(16, maxk - k);
         int m = wv::imin(zero_bytes_from_bottom(X), n);
         probes += wv::imin(m + 1, n);
