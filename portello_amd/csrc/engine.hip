@@ -34,27 +34,30 @@ using namespace plo;
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
 
-// Eight lanes per read segment: the reference span (get_cigar_ref_offset) is a strided partial sum per lane + a 3-step
-// xor-shuffle reduction, so that one load instruction covers 32 contiguous bytes of every segment's CIGAR; lane 0 of the
-// group then does the overlap test against the contig's segments.
+// SEG_LANES lanes per read segment: the reference span (get_cigar_ref_offset) is a strided partial sum per lane + an
+// xor-shuffle reduction, so that one load instruction covers SEG_LANES * 4 contiguous bytes of every segment's CIGAR;
+// lane 0 of the group then does the overlap test against the contig's segments.
+#ifndef PLO_SEG_LANES
+#define PLO_SEG_LANES 8  // measured on MI355X (wgs30x enumerate pass): 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms
+#endif
+constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 2 : 32 / SEG_LANES;
 __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t s = t >> 3, sub = t & 7u;
+    uint32_t s = t / SEG_LANES, sub = t % SEG_LANES;
     long long part = 0;
     if (s < bt.n_segs) {
         uint32_t c0 = bt.seg_cigar_off[s], c1 = bt.seg_cigar_off[s + 1];
-        for (uint32_t i = c0 + sub; i < c1; i += 32) {  // four independent loads in flight
-            uint32_t c[4];
+        for (uint32_t i = c0 + sub; i < c1; i += SEG_LANES * SEG_UNROLL) {  // independent loads in flight
+            uint32_t c[SEG_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = (i + 8u * u < c1) ? bt.cigar[i + 8u * u] : 0u;  // 0 = M of length 0
+            for (uint32_t u = 0; u < SEG_UNROLL; ++u) c[u] = (i + SEG_LANES * u < c1) ? bt.cigar[i + SEG_LANES * u] : 0u;  // 0 = M of length 0
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < SEG_UNROLL; ++u)
                 if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
         }
     }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
+#pragma unroll
+    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) part += __shfl_xor(part, (int)d, 64);
     if (s >= bt.n_segs || sub != 0) return;
     seg_reflen[s] = (int)part;
     seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0, seg_reflen, /*have_ref_len=*/true);
@@ -788,7 +791,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
         if (ns)
-            hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * 8 + 255) / 256)), dim3(256), 0, st, ix, bt,
+            hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt,
                                c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
