@@ -3,7 +3,8 @@
 Reads shard across GPUs with no data-path collective; after a batch every rank holds compact result records
 (per item: read segment, contig segment, status/flags, chromosome, position, CIGAR).  They are gathered to the writer
 rank with direct peer -> root ``isend``/``irecv`` posted as one group (one xGMI link per peer, all links concurrently;
-a ring all-gather would be per-link bound for no benefit) after a 24-byte-per-rank size exchange.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the
+a ring all-gather would be per-link bound for no benefit) after a 16-byte-per-rank size exchange; every field is sent
+straight from the engine's output array (no packing copy).  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the
 same code runs on CPU tensors over gloo (tests).
 """
 from __future__ import annotations
@@ -87,33 +88,39 @@ def unpack(payload: torch.Tensor, n_items: int, n_cigar: int) -> Dict[str, torch
 
 
 def gather_payloads(t: Dict[str, torch.Tensor], dist, rank: int, world: int, root: int = 0) -> Optional[List[Dict[str, torch.Tensor]]]:
-    """Gather every rank's records on `root`.  Returns the per-rank dicts on root, None elsewhere."""
+    """Gather every rank's records on `root`.  Returns the per-rank dicts on root, None elsewhere.
+
+    Every field travels as its own message straight from the engine's output array (no packing copy); all messages of the
+    step are posted as ONE group so that the peers' links run concurrently into the root, and messages between one pair
+    of ranks match in posting order."""
     dev = t["cigar"].device
-    payload = pack(t)
-    sizes = torch.tensor([t["item_seg"].numel(), t["cigar"].numel(), payload.numel()], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+    fields = ITEM_FIELDS + [("cigar", np.uint32, torch.int32)]
+    sizes = torch.tensor([t["item_seg"].numel(), t["cigar"].numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    # all transfers of the step are posted as ONE group so that the peers' links run concurrently into the root
     if rank != root:
-        if payload.numel():
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, root)]):
+        ops = [dist.P2POp(dist.isend, t[name].contiguous(), root) for name, _, _ in fields if t[name].numel()]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
                 q.wait()
         return None
-    bufs, ops = {}, []
+    res: List[Dict[str, torch.Tensor]] = []
+    ops = []
     for r in range(world):
         if r == root:
+            res.append({name: t[name] for name, _, _ in fields})
             continue
-        nb = int(all_sizes[r][2].item())
-        bufs[r] = torch.empty(nb, dtype=torch.uint8, device=dev)
-        if nb:
-            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+        ni, nc = (int(x) for x in all_sizes[r].tolist())
+        d = {}
+        for name, _, tdt in fields:
+            n = nc if name == "cigar" else ni
+            d[name] = torch.empty(n, dtype=tdt, device=dev)
+            if n:
+                ops.append(dist.P2POp(dist.irecv, d[name], r))
+        res.append(d)
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
-    res: List[Dict[str, torch.Tensor]] = []
-    for r in range(world):
-        ni, nc, _ = (int(x) for x in all_sizes[r].tolist())
-        res.append(unpack(payload if r == root else bufs[r], ni, nc))
     return res
 
 
