@@ -927,6 +927,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         max_nin = h[1];
         n_small = n_items ? h[2] + h[3] : 0;
         all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
+        if (all_ops > 0xf0000000ull) {  // the tiling prefix is 32-bit
+            c->err = "batch too large: the item weights (CIGAR ops + 2 x block-map entries) sum to more than 2^32; split the batch";
+            return PLO_ERR_RANGE;
+        }
         if (c->adaptive && n_items) {
             // Tile geometry from the batch's weight distribution: the routing threshold covers all but 0.2 % of the items
             // (those take the large-item kernel), the LDS slice holds one window plus the overhang of its last item.  Dense
