@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the tile kernel repeatedly on one resident batch (for rocprofv3 PC sampling / counters).  GPU only."""
+"""Runs the tile kernel repeatedly on one resident batch (for rocprofv3 counter passes; PC sampling is not supported on this ROCm 7.2 / gfx950 stack).  GPU only."""
 import argparse
 import os
 import sys
