@@ -212,37 +212,12 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             int le = lastm.excl_of(li);
             if (ism && le < i_s) m.itf[id] = e;                        // first match of the item: single writer
             if (valid && e == i_s + i_c - 1) m.itl[id] = (li >= i_s) ? li : -1;  // last element publishes the last match
+            if (valid) Y[e] = 0;  // run sums of pass 2 start from zero
         }
     }
     wv::sync();
-    // pass 2: edge I -> S(len), edge D -> S(0) (+ leading D lengths summed into the position shift); in place
-    for (int base = 0; base < n; base += 64) {
-        int e = base + lane;
-        bool valid = e < n;
-        int id = valid ? (idX[e] & 63) : 0;
-        int i_act = wv::shfl((int)active, id);
-        if (valid) {
-            uint32_t cc = X[e];
-            if (i_act) {
-                int f = m.itf[id], l = m.itl[id];
-                bool lead = e < f;
-                bool trail = e > l;
-                int t = op_type(cc);
-                if (lead || trail) {
-                    if (t == OP_D) {
-                        if (lead) wv::atomic_add(&m.its[id], op_len(cc));
-                        cc = mk_op(OP_S, 0);
-                    } else if (t == OP_I) {
-                        cc = mk_op(OP_S, op_len(cc));
-                    }
-                    X[e] = cc;
-                }
-            }
-            Y[e] = 0;
-        }
-    }
-    wv::sync();
-    // pass 3: drop zero-length ops, merge equal neighbours (head flags + run sums)
+    // pass 2: edge I -> S(len), edge D -> S(0) (+ leading D lengths summed into the position shift), applied on the fly;
+    // then drop zero-length ops and merge equal neighbours (head flags + run sums)
     {
         MaxScan lasta(-1);
         AddScan heads;
@@ -255,6 +230,20 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             int i_act = wv::shfl((int)active, id);
             uint32_t cc = valid ? X[e] : 0;
             int t = op_type(cc), L = op_len(cc);
+            int f = IMAX, l = -1;
+            if (valid && i_act) {
+                f = m.itf[id];
+                l = m.itl[id];
+                if (e < f || e > l) {  // clean_up_cigar_edge_indels (:265-291)
+                    if (t == OP_D) {
+                        if (e < f) wv::atomic_add(&m.its[id], L);
+                        t = OP_S;
+                        L = 0;
+                    } else if (t == OP_I) {
+                        t = OP_S;
+                    }
+                }
+            }
             bool alive = valid && (!i_act || L > 0);
             int ai = lasta.incl(alive ? e : -1);
             int pa = lasta.excl_of(ai);
@@ -263,7 +252,12 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
                 if (!i_act) {
                     head = true;
                 } else {
-                    int pt = pa < i_s ? -1 : op_type(X[pa]);
+                    int pt = -1;
+                    if (pa >= i_s) {  // the previous surviving op of the item, after its own edge clean-up (a surviving edge op
+                                      // is an insertion turned soft clip; edge deletions have length 0 and do not survive)
+                        pt = op_type(X[pa]);
+                        if ((pa < f || pa > l) && pt == OP_I) pt = OP_S;
+                    }
                     head = pt != t;
                     pairs |= head && is_indel(t) && pt >= 0 && is_indel(pt);
                 }
