@@ -234,7 +234,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(Dev
     const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
     TileMem m = carve_tile_mem(smem + (size_t)w * lds_per_wave, cap);
     WaveCtx ctx;
-    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) lift_window(ix, bt, wk, stages, tile, window, big_thresh, m, ctx);
+    (void)window;
+    lift_tiles_persistent(ix, bt, wk, stages, wave, n_waves, n_tiles, big_thresh, m, ctx);
     wave_ctx_flush(wk, ctx);
 }
 

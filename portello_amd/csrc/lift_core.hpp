@@ -487,8 +487,14 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx) {
 // -------------------------------------------------------------------------------------------------------------------
 // The tile pipeline
 // -------------------------------------------------------------------------------------------------------------------
+// What a persistent wave fetches about a tile one iteration ahead (lift_tiles_persistent): lane t <-> item t of the tile's
+// first 64 items -- the item index and the descriptor fields needed to issue the CIGAR / block-map gathers.
+struct TilePre {
+    uint32_t g = 0, in_off = 0, n_in = 0, w0 = 0, w1 = 0, kv1 = 0, fl = 0;
+};
+
 PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
-                       int nit, TileMem m, const uint32_t *list, int level, int big_thresh, WaveCtx &ctx) {
+                       int nit, TileMem m, const uint32_t *list, int level, int big_thresh, WaveCtx &ctx, const TilePre *pre = nullptr) {
     // level: LEVEL_TILE (shared tile; a tile that overflows its capacity re-queues its items on the retry list),
     // LEVEL_RETRY (few items, larger capacity; overflow -> large-item list), LEVEL_LAST (one item, global scratch)
     const bool last_resort = level == LEVEL_LAST;
@@ -507,7 +513,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 #endif
     bool has = lane < nit;
     // `list` maps positions to item indices: the class-order permutation (tiles), the retry list, or the large-item list
-    const uint32_t g = has ? list[item_begin + (uint32_t)lane] : 0u;
+    const uint32_t g = pre ? pre->g : (has ? list[item_begin + (uint32_t)lane] : 0u);
 
     // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
     int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;
@@ -515,14 +521,24 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     unsigned long long seq_off = 0, shift_ref = 0, chrom_ref = 0;
     bool rev = false, do_shift = false, flip = false;
     if (has) {
-        in_off = (int)wk.d.in_off[g];
-        n_in = (int)wk.d.n_in[g];
+        uint32_t fl;
+        if (pre) {  // fetched while the previous tile was being processed
+            in_off = (int)pre->in_off;
+            n_in = (int)pre->n_in;
+            W0 = (int)pre->w0;
+            W1 = (int)pre->w1;
+            kv1 = (int)pre->kv1;
+            fl = pre->fl;
+        } else {
+            in_off = (int)wk.d.in_off[g];
+            n_in = (int)wk.d.n_in[g];
+            W0 = (int)wk.d.w0[g];
+            W1 = (int)wk.d.w1[g];
+            kv1 = (int)wk.d.kv1[g];
+            fl = wk.d.flags[g];
+        }
         pos1 = wk.d.pos1[g];
-        W0 = (int)wk.d.w0[g];
-        W1 = (int)wk.d.w1[g];
         kv0 = (int)wk.d.kv0[g];
-        kv1 = (int)wk.d.kv1[g];
-        uint32_t fl = wk.d.flags[g];
         seq_len = (int)wk.d.seq_len[g];
         seq_off = wk.d.seq_off[g];
         shift_ref = wk.d.shift_ref[g];
@@ -1305,18 +1321,66 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Tile assignment (k_tile_bounds): the tiled items, in class order, form one flattened input-op stream that is cut into
-// windows of `window` ops; every item goes to the window its first op falls in.  A window with more than 64 items is
+// Tile assignment (k_tile_bounds): the tiled items, in class order, form one flattened stream of item weights that is cut
+// into windows of `window`; every item goes to the window its first unit falls in.  A window with more than 64 items is
 // processed in several passes.
+//
+// Persistent wave: tiles first, first + stride, ...  The dependent chain tile bounds -> item list -> descriptors -> gather
+// would cost four memory round trips per tile; the first three are software-pipelined across tiles (bounds three tiles
+// ahead, item indices two, descriptor fields one), so that only the gather itself is waited for.
 // -------------------------------------------------------------------------------------------------------------------
-PLO_DEV void lift_window(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t tile, int window,
-                         int big_thresh, TileMem m, WaveCtx &ctx) {
-    (void)window;
-    uint32_t lo = wk.tile_lo[tile], hi = wk.tile_lo[tile + 1];  // written by k_tile_bounds
-    for (uint32_t b = lo; b < hi; b += 64) {
-        int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-        lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx);
-        wv::sync();
+PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first,
+                                   uint32_t stride, uint32_t n_tiles, int big_thresh, TileMem m, WaveCtx &ctx) {
+    const uint32_t lane = (uint32_t)wv::lane();
+    auto bounds = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {  // per lane, same value in every lane
+        lo = 0;
+        hi = 0;
+        if (t < n_tiles) {
+            lo = wk.tile_lo[t];  // written by k_tile_bounds
+            hi = wk.tile_lo[t + 1];
+        }
+    };
+    auto load_g = [&](uint32_t lo, uint32_t hi) -> uint32_t { return (lo + lane < hi) ? wk.perm[lo + lane] : 0u; };
+    auto load_desc = [&](uint32_t lo, uint32_t hi, uint32_t g, TilePre &p) {
+        p.g = g;
+        if (lo + lane < hi) {
+            p.in_off = wk.d.in_off[g];
+            p.n_in = wk.d.n_in[g];
+            p.w0 = wk.d.w0[g];
+            p.w1 = wk.d.w1[g];
+            p.kv1 = wk.d.kv1[g];
+            p.fl = wk.d.flags[g];
+        }
+    };
+    uint32_t t = first;
+    uint32_t lo0, hi0, lo1, hi1, lo2, hi2;
+    bounds(t, lo0, hi0);
+    bounds(t + stride, lo1, hi1);
+    bounds(t + 2 * stride, lo2, hi2);
+    uint32_t g1 = load_g(lo1, hi1);
+    TilePre d0;
+    load_desc(lo0, hi0, load_g(lo0, hi0), d0);
+    for (; t < n_tiles; t += stride) {
+        // next stages of the pipeline: issued now, consumed one iteration later
+        TilePre d1;
+        load_desc(lo1, hi1, g1, d1);
+        uint32_t g2 = load_g(lo2, hi2);
+        uint32_t lo3, hi3;
+        bounds(t + 3 * stride, lo3, hi3);
+        const uint32_t lo = (uint32_t)wv::bcast_first((int)lo0), hi = (uint32_t)wv::bcast_first((int)hi0);
+        for (uint32_t b = lo; b < hi; b += 64) {
+            int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
+            lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx, b == lo ? &d0 : nullptr);
+            wv::sync();
+        }
+        lo0 = lo1;
+        hi0 = hi1;
+        lo1 = lo2;
+        hi1 = hi2;
+        lo2 = lo3;
+        hi2 = hi3;
+        g1 = g2;
+        d0 = d1;
     }
 }
 

@@ -197,7 +197,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             TileMem m = carve_tile_mem(lds.data(), cap);
             w.run([&]() {
                 WaveCtx ctx;
-                for (uint32_t t = wv_id; t < n_tiles; t += n_waves) lift_window(ix, bt, wk, stages, t, window, big_thresh, m, ctx);
+                lift_tiles_persistent(ix, bt, wk, stages, wv_id, n_waves, n_tiles, big_thresh, m, ctx);
                 wave_ctx_flush(wk, ctx);
             });
         }
