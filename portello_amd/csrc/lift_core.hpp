@@ -191,14 +191,22 @@ PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
 // active item's output has two neighbouring I/D ops, i.e. an indel cluster of more than one op.
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
-                              bool active, int &shift, int &n_out, bool &indel_pairs) {
+                              bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false) {
     const int lane = wv::lane();
-    m.itf[lane] = IMAX;
-    m.itl[lane] = -1;
+    if (!edges_known) {
+        m.itf[lane] = IMAX;
+        m.itl[lane] = -1;
+    }
     m.its[lane] = 0;
     wv::sync();
-    // pass 1: first / last alignment-match element of every item (the edges are everything outside them)
-    {
+    // pass 1: first / last alignment-match element of every item (the edges are everything outside them); a producer that
+    // knows where it puts its match ops publishes m.itf / m.itl itself (edges_known) and only the run sums are zeroed
+    if (edges_known) {
+        for (int base = 0; base < n; base += 64) {
+            int e = base + lane;
+            if (e < n) Y[e] = 0;
+        }
+    } else {
         MaxScan lastm(-1);
         for (int base = 0; base < n; base += 64) {
             int e = base + lane;
@@ -926,6 +934,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             m.its[lane] = NONE32;  // ref2_start_pos = None
             m.itc[lane] = 0;
+            m.itf[lane] = IMAX;    // first / last match op of the item's lifted CIGAR, published by pass B for the clean-up
+            m.itl[lane] = -1;
             wv::sync();
             for (int base = 0; base < nA; base += 64) {
                 int e = base + lane;
@@ -990,12 +1000,12 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     int fi = lastfm.incl(fm ? j : -1);
                     int fe = lastfm.excl_of(fi);
                     // at most two ops per piece, as flags + values (no indexed local array: that would live in scratch)
-                    bool e0 = false, started = false;  // e0: the jump deletion of :91-96
+                    bool e0 = false, started = false, started_before = false;  // e0: the jump deletion of :91-96
                     uint32_t v0 = 0;
                     if (mapped) {
                         bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
                         started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
-                        bool started_before = fe >= 0 && (m.T3[fe] & 63) == id;
+                        started_before = fe >= 0 && (m.T3[fe] & 63) == id;
                         if (fm && !started_before) m.its[id] = startval;
                         if (prev_ok) {  // :91-96
                             int d = val - m.T4[pmap];
@@ -1014,6 +1024,11 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (p + ne > m.cap) {
                         overflow = true;
                     } else {
+                        if (fm) {  // the only match ops of the output are the mapped match pieces: position p (+1 after a jump D)
+                            int pm = p + (e0 ? 1 : 0);
+                            if (!started_before) m.itf[id] = pm;  // single writer, like m.its
+                            wv::atomic_max(&m.itl[id], pm);
+                        }
                         put_op(m.B, m.idB, p, e0, v0, id);
                         put_op(m.B, m.idB, p, e1, v1, id);
                     }
@@ -1037,7 +1052,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     alive = false;
                 }
                 int shift = 0, nOut = 0;
-                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs);  // :219-220
+                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true);  // :219-220
                 sA = sB;
                 cA = cB;
                 nA = nOut;
