@@ -143,6 +143,7 @@ def main():
     def step(k):
         out = engs[k].liftover_batch_dev(desc)
         if dist is not None:
+            engs[k].compact_output_dev(out)  # no slab gaps over xGMI
             with gather_lock, torch.cuda.stream(streams[k]):
                 plo_gather.gather_results(out, dev, dist, rank, world)
         last_out[k] = out

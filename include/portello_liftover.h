@@ -281,6 +281,18 @@ typedef struct plo_sa_out {
 
 plo_status plo_sa_segments_dev(plo_ctx *ctx, const plo_sa_in *in, plo_sa_out *out);
 
+/* Packs the output CIGARs of the last plo_liftover_batch_dev result densely (items in order, no gaps): the kernels
+   allocate them in per-wave slabs, so plo_batch_out.cigar spans up to 16 Ki unused ops per resident wave.  Rewrites
+   item_cigar_off, cigar and n_cigar of `out` (and what plo_finish_batch_dev / plo_sa_segments_dev will read).  Worth it
+   before the arrays leave the device (plo_liftover_batch does it itself before its device-to-host copy). */
+plo_status plo_compact_output_dev(plo_ctx *ctx, plo_batch_out *out);
+
+/* Page-locked host memory for the arrays handed to plo_liftover_batch: copies from such buffers are direct DMA transfers
+   (measured on MI355X, chr20 batch of 50 k reads / 385 MB: pageable 14 GB/s, page-locked see DESIGN.md).  The caller fills
+   them in place (e.g. one set per worker thread, reused from batch to batch) and releases them with plo_host_free. */
+plo_status plo_host_alloc(size_t bytes, void **out);
+void plo_host_free(void *p);
+
 plo_status plo_ctx_sync(plo_ctx *ctx);
 /* Copies `bytes` from device memory (e.g. a plo_liftover_batch_dev output array) to host memory on the context's
    stream and waits for it. */

@@ -58,6 +58,12 @@ def load_library(path: Optional[str] = None):
     L.plo_liftover_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
     L.plo_liftover_batch_dev.restype = C.c_int
     L.plo_liftover_batch_dev.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.c_uint32, C.POINTER(abi.PloBatchOut)]
+    L.plo_compact_output_dev.restype = C.c_int
+    L.plo_compact_output_dev.argtypes = [vp, C.POINTER(abi.PloBatchOut)]
+    L.plo_host_alloc.restype = C.c_int
+    L.plo_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.plo_host_free.restype = None
+    L.plo_host_free.argtypes = [C.c_void_p]
     L.plo_sa_segments_dev.restype = C.c_int
     L.plo_sa_segments_dev.argtypes = [vp, C.POINTER(abi.PloSaIn), C.POINTER(abi.PloSaOut)]
     L.plo_finish_batch_dev.restype = C.c_int
@@ -148,6 +154,11 @@ class Engine:
         """Record finishing for the last liftover_batch_dev result (plo_finish_batch_dev); device pointers."""
         out = abi.PloFinishOut()
         self._check(self.lib.plo_finish_batch_dev(self.handle, C.byref(desc), C.byref(fin), C.byref(out)), "plo_finish_batch_dev")
+        return out
+
+    def compact_output_dev(self, out: abi.PloBatchOut) -> abi.PloBatchOut:
+        """Pack the output CIGARs of the last liftover_batch_dev result densely (plo_compact_output_dev); updates `out`."""
+        self._check(self.lib.plo_compact_output_dev(self.handle, C.byref(out)), "plo_compact_output_dev")
         return out
 
     def sa_segments_dev(self, sa_in: abi.PloSaIn) -> abi.PloSaOut:
@@ -333,3 +344,30 @@ def assemble_sa_values(seg_off: np.ndarray, text: np.ndarray, item_read: np.ndar
                 out[i] = v if v else None
         i0 = i1
     return out
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from plo_host_alloc (released on close / garbage collection)"""
+
+    def __init__(self, like: np.ndarray):
+        like = np.ascontiguousarray(like)
+        self.lib = load_library()
+        self.ptr = C.c_void_p()
+        rc = self.lib.plo_host_alloc(max(16, like.nbytes), C.byref(self.ptr))
+        if rc != abi.PLO_OK:
+            raise PortelloError(rc, "plo_host_alloc failed")
+        buf = (C.c_uint8 * max(16, like.nbytes)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=like.dtype, count=like.size).reshape(like.shape)
+        self.array[...] = like
+
+    def close(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self.array = None
+            self.lib.plo_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

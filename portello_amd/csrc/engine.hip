@@ -311,6 +311,18 @@ __global__ void k_finish_offsets(DevBatch bt, DevWork wk, DevFinish f) {
         f.read_qual_off_out[e - n] = qo;
     }
 }
+// dense re-packing of the slab-allocated output CIGARs: eight lanes per item copy 32 contiguous bytes per step
+__global__ __launch_bounds__(256) void k_compact_cigar(const uint32_t *src, uint64_t *cig_off, const uint32_t *cig_len,
+                                                       const uint32_t *dense_off, uint32_t n, uint32_t *dst) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = t >> 3, sub = t & 7u;
+    if (i >= n) return;
+    const uint64_t from = cig_off[i];  // read by all eight lanes before lane 0 overwrites it below
+    const uint32_t len = cig_len[i], to = dense_off[i];
+    for (uint32_t k = sub; k < len; k += 8) dst[to + k] = src[from + k];
+    if (sub == 0) cig_off[i] = to;
+}
+
 // SA tag text: thread per item (only the few items of reads with several lifted records produce text)
 __global__ void k_sa_len(DevWork wk, DevSa sa) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,7 +457,7 @@ struct plo_ctx {
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
-    DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar;
+    DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense;
     // host staging for plo_liftover_batch
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
@@ -699,7 +711,7 @@ void plo_ctx_destroy(plo_ctx *c) {
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
-                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
+                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
                       &c->i_item_seg, &c->i_item_cseg};
     for (DevBuf *b : bufs) b->release();
@@ -1242,6 +1254,51 @@ plo_status plo_sa_segments_dev(plo_ctx *c, const plo_sa_in *in, plo_sa_out *out)
     return PLO_OK;
 }
 
+plo_status plo_compact_output_dev(plo_ctx *c, plo_batch_out *out) {
+    if (!c || !out) return PLO_ERR_INVALID_ARG;
+    c->err.clear();
+    if (!c->have_last || out->n_items != c->last_wk.n_items) {
+        c->err = "plo_compact_output_dev: `out` is not the result of the context's last plo_liftover_batch_dev";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (c->last_wk.out_cigar == c->o_cigar_dense.as<uint32_t>()) return PLO_OK;  // already dense
+    HIP_TRY(c, hipSetDevice(c->ix->device));
+    hipStream_t st = c->stream;
+    const uint32_t n = out->n_items;
+    HIP_TRY(c, c->o_dense_off.ensure(((size_t)n + 1) * 4));
+    plo_status s = scan_u32(c, c->o_clen.as<uint32_t>(), n, c->o_dense_off.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    uint32_t *h = c->h_counters.as<uint32_t>();
+    h[0] = 0;
+    if (n) HIP_TRY(c, hipMemcpyAsync(h, c->o_dense_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint64_t total = h[0];
+    HIP_TRY(c, c->o_cigar_dense.ensure(std::max<uint64_t>(total, 4) * 4));
+    if (n)
+        hipLaunchKernelGGL(k_compact_cigar, dim3((unsigned)(((unsigned long long)n * 8 + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t *)c->o_cigar.as<uint32_t>(), c->o_coff.as<uint64_t>(), (const uint32_t *)c->o_clen.as<uint32_t>(),
+                           (const uint32_t *)c->o_dense_off.as<uint32_t>(), n, c->o_cigar_dense.as<uint32_t>());
+    HIP_TRY(c, hipGetLastError());
+    c->last_wk.out_cigar = c->o_cigar_dense.as<uint32_t>();
+    out->cigar = c->o_cigar_dense.as<uint32_t>();
+    out->n_cigar = total;
+    return PLO_OK;
+}
+
+plo_status plo_host_alloc(size_t bytes, void **out) {
+    if (!out) return PLO_ERR_INVALID_ARG;
+    *out = nullptr;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable);
+    if (e == hipErrorNoDevice || e == hipErrorInsufficientDriver) return PLO_ERR_NO_DEVICE;
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? PLO_ERR_OUT_OF_MEMORY : PLO_ERR_HIP;
+    *out = p;
+    return PLO_OK;
+}
+void plo_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     if (!c || !t) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1353,6 +1410,8 @@ plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stage
 #undef UP
     plo_batch_out dout;
     plo_status s = plo_liftover_batch_dev(c, &din, stages, &dout);
+    if (s != PLO_OK) return s;
+    s = plo_compact_output_dev(c, &dout);  // no slab gaps over the bus
     if (s != PLO_OK) return s;
     size_t ni = dout.n_items, nc = (size_t)dout.n_cigar;
 #define DOWN(hbuf, src, bytes)                                                                        \

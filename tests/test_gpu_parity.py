@@ -325,3 +325,38 @@ def test_boundary_validation_errors():
     with pytest.raises(api.PortelloError) as e:
         api.Index(ixb)
     assert e.value.status == abi.PLO_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_compact_output(oracle):
+    """plo_compact_output_dev: dense CIGAR array (no slab gaps), same records; finishing / SA text read the dense layout"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("tiny", n_reads=500, seed=210, split_read_frac=0.2), device="cuda")
+    index = api.Index(w.index_data_device())
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    desc = db.desc()
+    out = eng.liftover_batch_dev(desc)
+    slab = devbatch.download(eng, out)
+    extent = int(out.n_cigar)
+    eng.compact_output_dev(out)
+    dense = devbatch.download(eng, out)
+    assert int(out.n_cigar) == int(dense.item_cigar_len.sum()) <= extent
+    assert np.array_equal(dense.item_cigar_off, np.cumsum(dense.item_cigar_len, dtype=np.uint64) - dense.item_cigar_len)
+    assert dense.canonical() == slab.canonical()
+    eng.compact_output_dev(out)  # idempotent
+    assert devbatch.download(eng, out).canonical() == slab.canonical()
+    fin, keep = devbatch.finish_inputs(w, db, seed=3)
+    fo = eng.finish_batch_dev(desc, fin)
+    got = devbatch.download_finish(eng, fo, dense.n_items, db.n_reads)
+    b = w.batch_data()
+    ref = oracle.finish_batch(b, keep["flags"].cpu().numpy().view(np.uint16), keep["qual"].cpu().numpy(), keep["qoff"].cpu().numpy(),
+                              oracle.liftover_batch(w.index_data(), b, abi.STAGES_ALL, 2))
+    lifted = dense.item_status == 0
+    assert np.array_equal(got["item_ref_end"][lifted], ref["item_ref_end"][lifted])
+    assert np.array_equal(got["item_bin"][lifted], ref["item_bin"][lifted])
+    eng.close()
+    index.close()
