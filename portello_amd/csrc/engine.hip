@@ -44,23 +44,51 @@ constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 
 __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = t / SEG_LANES, sub = t % SEG_LANES;
+    const bool live = s < bt.n_segs;
+    // Two dependent chains, issued side by side so that the kernel is three memory round trips deep instead of five:
+    //   CIGAR offsets -> ops (reference span)   and   contig -> its segment range -> segment intervals (overlap test,
+    //   one contig segment per lane of the group)
+    uint32_t c0 = 0, c1 = 0, contig = 0;
+    long long r_start = 0;
+    if (live) {
+        c0 = bt.seg_cigar_off[s];
+        c1 = bt.seg_cigar_off[s + 1];
+        contig = bt.seg_contig[s];
+        r_start = (long long)bt.seg_pos[s];
+    }
+    uint32_t g0 = 0, g1 = 0;
+    if (live && contig < ix.n_contigs) {
+        g0 = ix.contig_seg_off[contig];
+        g1 = ix.contig_seg_off[contig + 1];  // g0 == g1: contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
+    }
     long long part = 0;
-    if (s < bt.n_segs) {
-        uint32_t c0 = bt.seg_cigar_off[s], c1 = bt.seg_cigar_off[s + 1];
-        for (uint32_t i = c0 + sub; i < c1; i += SEG_LANES * SEG_UNROLL) {  // independent loads in flight
-            uint32_t c[SEG_UNROLL];
+    for (uint32_t i = c0 + sub; i < c1; i += SEG_LANES * SEG_UNROLL) {  // independent loads in flight
+        uint32_t c[SEG_UNROLL];
 #pragma unroll
-            for (uint32_t u = 0; u < SEG_UNROLL; ++u) c[u] = (i + SEG_LANES * u < c1) ? bt.cigar[i + SEG_LANES * u] : 0u;  // 0 = M of length 0
+        for (uint32_t u = 0; u < SEG_UNROLL; ++u) c[u] = (i + SEG_LANES * u < c1) ? bt.cigar[i + SEG_LANES * u] : 0u;  // 0 = M of length 0
 #pragma unroll
-            for (uint32_t u = 0; u < SEG_UNROLL; ++u)
-                if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
-        }
+        for (uint32_t u = 0; u < SEG_UNROLL; ++u)
+            if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
+    }
+    // the first interval of every lane is fetched before the reduction needs the ops
+    const uint32_t gl = g0 + sub;
+    long long cs = 0, ce = 0;
+    if (gl < g1) {
+        cs = (long long)ix.cs_start[gl];
+        ce = (long long)ix.cs_end[gl];
     }
 #pragma unroll
     for (uint32_t d = 1; d < SEG_LANES; d <<= 1) part += __shfl_xor(part, (int)d, 64);
-    if (s >= bt.n_segs || sub != 0) return;
+    const long long r_end = r_start + part;
+    // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end (int_range.rs:56-58)
+    uint32_t n = (gl < g1 && r_end >= cs && r_start < ce) ? 1u : 0u;
+    for (uint32_t g = gl + SEG_LANES; g < g1; g += SEG_LANES)  // contigs with more segments than lanes
+        if (r_end >= (long long)ix.cs_start[g] && r_start < (long long)ix.cs_end[g]) ++n;
+#pragma unroll
+    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) n += (uint32_t)__shfl_xor((int)n, (int)d, 64);
+    if (!live || sub != 0) return;
     seg_reflen[s] = (int)part;
-    seg_cnt[s] = enumerate_segment(ix, bt, s, nullptr, 0, 0, seg_reflen, /*have_ref_len=*/true);
+    seg_cnt[s] = n;
 }
 
 // thread per read segment: resolve the descriptors of its items (build_item_desc) at their scanned offsets
