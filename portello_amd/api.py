@@ -42,6 +42,12 @@ def load_library(path: Optional[str] = None):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise PortelloError(abi.PLO_ERR_NO_DEVICE, f"{path} not built: run `python -m portello_amd.build` (hipcc, gfx950)")
+    try:
+        # In a process that also uses torch, torch's own HIP runtime must be the one the library binds to: loaded the other
+        # way round, two runtimes share the process and the engine's one does not see the device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp = C.c_void_p
     L.plo_index_create.restype = C.c_int
