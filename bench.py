@@ -19,8 +19,11 @@ import sys
 import threading
 import time
 
-import numpy as np
-import torch
+# the host driver of this pool only supports dmabuf IPC (RCCL / cross-process tensor sharing fail without it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
