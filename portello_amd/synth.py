@@ -64,6 +64,7 @@ class WorkloadConfig:
                                                                        big_indel_prob=0.02))
     read_rates: EditRates = field(default_factory=EditRates)
     seq_fmt: int = abi.SEQ_BAM4
+    sorted_reads: bool = False  # reads of a contig in coordinate order, as a coordinate-sorted read->contig BAM delivers them
 
 
 def config(name: str, **over) -> WorkloadConfig:
@@ -76,17 +77,17 @@ def config(name: str, **over) -> WorkloadConfig:
                            split_read_frac=0.0,
                            contig_rates=EditRates(mismatch=1e-3, ins=1e-4, dele=1e-4, hpol_frac=0.3, big_indel_prob=0.01))
     elif name == "chr20":  # configs[1]: 64 Mb slice, 2 haplotypes x ~10 contigs, ~50 k reads x 15 kb
-        c = WorkloadConfig(name="chr20", seed=SEED_BASE + 1, chrom_lens=(64_000_000,), n_contigs_per_hap=10, n_haps=2,
+        c = WorkloadConfig(name="chr20", sorted_reads=True, seed=SEED_BASE + 1, chrom_lens=(64_000_000,), n_contigs_per_hap=10, n_haps=2,
                            max_segments=5, n_reads=50_000)
     elif name == "wgs30x":  # configs[2]: 3.1 Gb, 2 x 300 contigs, 2 M reads x 15 kb
         lens = tuple(int(x) for x in np.linspace(248e6, 46e6, 24))
         scale = 3.1e9 / sum(lens)
         lens = tuple(int(x * scale) for x in lens)
-        c = WorkloadConfig(name="wgs30x", seed=SEED_BASE + 2, chrom_lens=lens, n_contigs_per_hap=300, n_haps=2,
+        c = WorkloadConfig(name="wgs30x", sorted_reads=True, seed=SEED_BASE + 2, chrom_lens=lens, n_contigs_per_hap=300, n_haps=2,
                            max_segments=5, n_reads=2_000_000)
     elif name == "stress":  # configs[4]: 20 kb reads, 5 % indel-dense CIGARs
         lens = (64_000_000,)
-        c = WorkloadConfig(name="stress", seed=SEED_BASE + 4, chrom_lens=lens, n_contigs_per_hap=10, n_haps=2,
+        c = WorkloadConfig(name="stress", sorted_reads=True, seed=SEED_BASE + 4, chrom_lens=lens, n_contigs_per_hap=10, n_haps=2,
                            max_segments=5, n_reads=100_000, read_len_mean=20_000, read_len_sd=2_000,
                            read_rates=EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1))
     else:
@@ -535,6 +536,9 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
         rl = rl.long().clamp_(min=cfg.read_len_min, max=max(cfg.read_len_min, Lc - 2))
         rl = rl.clamp_(max=Lc - 2)
         start = (torch.rand(R, generator=gen, device=device) * (Lc - rl).float()).long().clamp_(min=0)
+        if cfg.sorted_reads:
+            start, order_ = torch.sort(start)
+            rl = rl[order_]
         m = mutate(contig_fwd[c], start, rl, cfg.read_rates, gen)
         is_rev = torch.rand(R, generator=gen, device=device) < 0.5
         # soft clips (random bases) on a fraction of reads, supplementary part on a fraction

@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--stages", default="31")
 ap.add_argument("--rev-frac", type=float, default=0.5)
 ap.add_argument("--contig-indel", type=float, default=-1.0, help="contig-vs-reference insertion and deletion rate (default: the workload's 1e-4 each)")
+ap.add_argument("--sorted", action="store_true", help="reads of every contig in coordinate order")
 ap.add_argument("--lib", default="", help="alternative library file name under portello_amd/")
 ap.add_argument("--timing", action="store_true", help="use the instrumented build and print per-phase cycles")
 args = ap.parse_args()
@@ -33,6 +34,8 @@ if args.timing:
     L.plo_ctx_phase_cycles.restype = None
     L.plo_ctx_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 over = dict(n_reads=args.reads, rev_contig_frac=args.rev_frac)
+if args.sorted:
+    over["sorted_reads"] = True
 if args.contig_indel >= 0:
     over["contig_rates"] = synth.EditRates(mismatch=1e-3, ins=args.contig_indel, dele=args.contig_indel, hpol_frac=0.3, big_indel_prob=0.02)
 w = synth.generate(synth.config(args.workload, **over), device=dev)
