@@ -237,6 +237,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in,
 }
 
 // ---- the dominant kernel: one wave per tile ---------------------------------------------------------------------
+constexpr uint32_t STAT_SLOTS = 1u << 16;  // >= waves of any lift launch (CUs x 16 blocks x 4 waves at most)
 constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its own tile with its own LDS slice
 
 // Persistent: the grid is sized to the resident capacity of the chip and every wave strides over the tiles, keeping its
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(Dev
     WaveCtx ctx;
     (void)window;
     lift_tiles_persistent(ix, bt, wk, stages, wave, n_waves, n_tiles, big_thresh, m, ctx);
-    wave_ctx_flush(wk, ctx);
+    wave_ctx_flush(wk, ctx, wave);
 }
 
 // Short-CIGAR fast path: one lane per item, 64 items per wave (lane_core.hpp); persistent waves over groups of 64.
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(LANE_WAVES * 64) void k_lift_lanes(DevIndex ix, Dev
         lift_lanes(ix, bt, wk, stages, b0, (int)(left < 64u ? left : 64u), m, ctx);
         wv::sync();
     }
-    wave_ctx_flush(wk, ctx);
+    wave_ctx_flush(wk, ctx, wave);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, Dev
         lift_tile(ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
         wv::sync();
     }
-    wave_ctx_flush(wk, ctx);
+    wave_ctx_flush(wk, ctx, blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
@@ -312,7 +313,31 @@ __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWo
         lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
         wv::sync();
     }
-    wave_ctx_flush(wk, ctx);
+    wave_ctx_flush(wk, ctx, blockIdx.x);
+}
+
+// sums (and clears) the per-wave statistic slots of the lift kernel that has just run into the batch counters; one block
+__global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint32_t n_slots, unsigned long long *counters) {
+    __shared__ unsigned long long acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long a = 0, b = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        unsigned long long *w = ws + (size_t)i * 4;
+        a += w[0];
+        b += w[1];
+        c += w[2];
+        w[0] = w[1] = w[2] = 0;
+    }
+    atomicAdd(&acc[0], a);
+    atomicAdd(&acc[1], b);
+    atomicAdd(&acc[2], c);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[CNT_ALGO_BYTES] += acc[0];
+        counters[CNT_IN_OPS] += acc[1];
+        counters[CNT_OUT_OPS] += acc[2];
+    }
 }
 
 // ---- record finishing (finish_core.hpp) ----------------------------------------------------------------------------------
@@ -485,7 +510,7 @@ struct plo_ctx {
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
-    DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense;
+    DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense, wave_stats;
     // host staging for plo_liftover_batch
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
@@ -739,7 +764,7 @@ void plo_ctx_destroy(plo_ctx *c) {
                       &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
-                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
+                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
                       &c->i_item_seg, &c->i_item_cseg};
     for (DevBuf *b : bufs) b->release();
@@ -914,6 +939,17 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.cig_off = c->o_coff.as<uint64_t>();
     wk.cig_len = c->o_clen.as<uint32_t>();
     wk.counters = c->counters.as<unsigned long long>();
+    {   // statistic slots of the lift kernels' waves: zeroed once, cleared again by every k_sum_stats
+        const size_t want = (size_t)STAT_SLOTS * 4 * 8;
+        if (c->wave_stats.cap < want) {
+            HIP_TRY(c, c->wave_stats.ensure(want));
+            HIP_TRY(c, hipMemsetAsync(c->wave_stats.p, 0, want, st));
+        }
+    }
+    wk.wave_stats = c->wave_stats.as<unsigned long long>();
+#define PLO_SUM_STATS(n_waves_)                                                                                                 \
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), (uint32_t)(n_waves_), \
+                       c->counters.as<unsigned long long>())
     wk.big_list = c->big_list.as<uint32_t>();
     if (n_items) {
         if (in->item_seg)
@@ -1027,6 +1063,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
             nblk = (nblk + 7u) & ~7u;
             hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lpw * LANE_WAVES, st, ix, bt, wk, stages, lpw);
+            PLO_SUM_STATS(nblk * LANE_WAVES);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
@@ -1045,8 +1082,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages,
                                n_tiles, c->window, c->big_thresh, c->cap, lds_per_wave);
             HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->ev[2], st));
+            PLO_SUM_STATS(nblk * tw);
+        } else {
+            HIP_TRY(c, hipEventRecord(c->ev[2], st));
         }
-        HIP_TRY(c, hipEventRecord(c->ev[2], st));
         HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         n_retry = (uint32_t)hc[CNT_NRETRY];
@@ -1056,6 +1096,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15);
             uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 6u);
             hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
+            PLO_SUM_STATS(nw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
@@ -1077,6 +1118,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                big_cap, bpw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[3], st));
+            PLO_SUM_STATS(nw);
             c->ev_big = true;
             HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));

@@ -99,6 +99,7 @@ struct DevWork {
     uint32_t *out_cigar;
     uint64_t out_cap;
     unsigned long long *counters;  // [CNT_N]
+    unsigned long long *wave_stats;  // [waves of the launch][4]: algorithmic bytes, input ops, output ops of every wave (summed by k_sum_stats)
     uint32_t *big_list;            // items re-queued for the large-item kernel
 };
 

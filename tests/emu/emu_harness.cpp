@@ -125,6 +125,14 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.cig_off = o->cig_off.data();
     wk.cig_len = o->cig_len.data();
     wk.counters = counters;
+    unsigned long long wave_stats[4] = {0, 0, 0, 0};  // the emulated waves run one after another: one slot, summed after each
+    wk.wave_stats = wave_stats;
+    auto sum_stats = [&]() {  // k_sum_stats
+        counters[CNT_ALGO_BYTES] += wave_stats[0];
+        counters[CNT_IN_OPS] += wave_stats[1];
+        counters[CNT_OUT_OPS] += wave_stats[2];
+        wave_stats[0] = wave_stats[1] = wave_stats[2] = 0;
+    };
     wk.big_list = big_list.data();
     if (in->item_seg) {
         for (uint32_t i = 0; i < n_items; ++i)
@@ -186,8 +194,9 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                         lift_lanes(ix, bt, wk, stages, b0, (int)std::min<uint32_t>(64u, n_small - b0), lm, ctx);
                         wv::sync();
                     }
-                    wave_ctx_flush(wk, ctx);
+                    wave_ctx_flush(wk, ctx, 0);
                 });
+                sum_stats();
             }
         }
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
@@ -198,8 +207,9 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             w.run([&]() {
                 WaveCtx ctx;
                 lift_tiles_persistent(ix, bt, wk, stages, wv_id, n_waves, n_tiles, big_thresh, m, ctx);
-                wave_ctx_flush(wk, ctx);
+                wave_ctx_flush(wk, ctx, 0);
             });
+            sum_stats();
         }
         {
             const int retry_cap = std::max(cap, (2 * big_thresh + 64 + 63) & ~63);
@@ -214,8 +224,9 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.run([&]() {
                     WaveCtx ctx;
                     lift_tile(ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
-                    wave_ctx_flush(wk, ctx);
+                    wave_ctx_flush(wk, ctx, 0);
                 });
+                sum_stats();
             }
         }
         uint32_t n_big = (uint32_t)counters[CNT_NBIG];
@@ -232,8 +243,9 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                         lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
                         wv::sync();
                     }
-                    wave_ctx_flush(wk, ctx);
+                    wave_ctx_flush(wk, ctx, 0);
                 });
+                sum_stats();
             }
         }
         if (counters[CNT_OVERFLOW] == 0) break;
