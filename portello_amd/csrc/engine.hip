@@ -151,8 +151,15 @@ __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint3
 // maximum (out[0]) and 64-bit sum (out[2..3]) of a uint32 array, one atomic pair per wave, plus a histogram of the values
 // in bins of WHIST_STEP (out[WHIST_AT + b], last bin = everything above); out must be zeroed
 constexpr int WHIST_STEP = 32, WHIST_BINS = 40, WHIST_AT = 8;
-__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out) {
+// out[4..6] = *t0, *t1, *t2 (scan totals the host wants in the same copy)
+__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n, uint32_t *out, const uint32_t *t0, const uint32_t *t1,
+                                                 const uint32_t *t2) {
     __shared__ uint32_t hist[WHIST_BINS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[4] = *t0;
+        out[5] = *t1;
+        out[6] = *t2;
+    }
     if (threadIdx.x < WHIST_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t m = 0;
@@ -991,15 +998,21 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
         if (n_items)
             hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 64u)), dim3(256), 0, st,
-                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>());
-        uint32_t *h = c->h_counters.as<uint32_t>();
-        HIP_TRY(c, hipMemcpyAsync(h, c->op_prefix.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(h + 1, c->misc.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(h + 4, c->misc.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(h + 2, c->rank0.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(h + 3, c->rank1.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(h + 8, c->misc.as<uint32_t>() + WHIST_AT, WHIST_BINS * 4, hipMemcpyDeviceToHost, st));
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>(),
+                               (const uint32_t *)c->op_prefix.as<uint32_t>() + n_items, (const uint32_t *)c->rank0.as<uint32_t>() + n_items,
+                               (const uint32_t *)c->rank1.as<uint32_t>() + n_items);
+        // one copy: [0] max weight, [2..3] weight sum, [4] tiled weight, [5..6] class-0/1 counts, [8..] weight histogram
+        uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;  // clear of h[0..47] below
+        HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, (WHIST_AT + WHIST_BINS) * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        uint32_t *h = c->h_counters.as<uint32_t>();
+        h[0] = n_items ? m_[4] : 0;
+        h[1] = m_[0];
+        h[2] = n_items ? m_[5] : 0;
+        h[3] = n_items ? m_[6] : 0;
+        h[4] = m_[2];
+        h[5] = m_[3];
+        for (int k = 0; k < WHIST_BINS; ++k) h[8 + k] = m_[WHIST_AT + k];
         total_ops = h[0];  // weight of the tiled items
         max_nin = h[1];
         n_small = n_items ? h[2] + h[3] : 0;
