@@ -271,6 +271,10 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(Dev
     TileMem m = carve_tile_mem(smem + (size_t)w * lds_per_wave, cap);
     WaveCtx ctx;
     (void)window;
+    if (wk.slab_pre) {  // first slab by wave id: 3 072 waves reserving theirs at the same moment would serialise on one counter
+        ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
+        ctx.slab_left = SLAB_OPS;
+    }
     lift_tiles_persistent(ix, bt, wk, stages, wave, n_waves, n_tiles, big_thresh, m, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
@@ -1092,6 +1096,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 occ = 1;
             nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
             nblk = (nblk + 7u) & ~7u;
+            wk.slab_pre = n_small == 0 ? 1u : 0u;  // nothing has been reserved yet (the lane kernel did not run)
+            wk.slab_offset = wk.slab_pre ? (unsigned long long)nblk * tw * SLAB_OPS : 0ull;
             hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages,
                                n_tiles, c->window, c->big_thresh, c->cap, lds_per_wave);
             HIP_TRY(c, hipGetLastError());
@@ -1141,7 +1147,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             c->err = "output CIGAR buffer kept overflowing";
             return PLO_ERR_INTERNAL;
         }
-        HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS) * 4));
+        HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + wk.slab_offset + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS) * 4));
     }
     if (hc[CNT_ERROR]) {
         c->err = "an item exceeded the large-item scratch capacity (raise PLO_BIG_CAP)";
@@ -1167,7 +1173,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     out->item_cigar_off = c->o_coff.as<uint64_t>();
     out->item_cigar_len = c->o_clen.as<uint32_t>();
     out->cigar = c->o_cigar.as<uint32_t>();
-    out->n_cigar = hc[CNT_CIGAR];
+    out->n_cigar = hc[CNT_CIGAR] + wk.slab_offset;
     c->last_wk = wk;
     c->last_bt = bt;
     c->have_last = true;

@@ -385,7 +385,7 @@ PLO_DEV void lift_lanes(const DevIndex &ix, const DevBatch &bt, const DevWork &w
     if ((unsigned long long)total > ctx.slab_left) {
         unsigned long long want = (unsigned long long)total > SLAB_OPS ? (unsigned long long)total : SLAB_OPS;
         unsigned long long nb = 0;
-        if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want);
+        if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want) + wk.slab_offset;
         unsigned lo = (unsigned)wv::bcast_first((int)(unsigned)(nb & 0xffffffffull));
         unsigned hi = (unsigned)wv::bcast_first((int)(unsigned)(nb >> 32));
         ctx.slab_base = ((unsigned long long)hi << 32) | lo;

@@ -99,6 +99,10 @@ struct DevWork {
     uint32_t *out_cigar;
     uint64_t out_cap;
     unsigned long long *counters;  // [CNT_N]
+    // output slabs: when slab_pre is set, wave w of the tile kernel owns ops [w*SLAB_OPS, (w+1)*SLAB_OPS) from the start (no
+    // atomic for its first slab) and every later reservation is counters[CNT_CIGAR] + slab_offset
+    unsigned long long slab_offset;
+    uint32_t slab_pre;
     unsigned long long *wave_stats;  // [waves of the launch][4]: algorithmic bytes, input ops, output ops of every wave (summed by k_sum_stats)
     uint32_t *big_list;            // items re-queued for the large-item kernel
 };
