@@ -91,6 +91,10 @@ def main():
                          "rayon worker); batches are dealt to them in turn, so one worker's enumerate pass and host syncs overlap the "
                          "other's tile kernel.  Default 1: the HIP-event kernel times of the roofline object then measure execution "
                          "only (with several streams they include the wait behind the other stream's kernel)")
+    ap.add_argument("--async-gather", action="store_true", default=bool(os.environ.get("PLO_BENCH_ASYNC_GATHER")),
+                    help="N > 1: two contexts alternate and the record gather of batch i stays in flight while batch i+1 is "
+                         "computed (single thread per rank, same posting order on all ranks).  Opt-in: covered by the gloo "
+                         "tests, not yet exercised over RCCL on several GPUs")
     ap.add_argument("--overlap-workers", type=int, default=0,
                     help="after the timed region, repeat the same K steps with this many workers and report the rate as the "
                          "supplementary object `overlap` (N = 1 only; 0/1 = skip, the default: the extra launches would enter a "
@@ -183,6 +187,32 @@ def main():
                 t.join()
         if errors:
             raise errors[0]
+
+    async_gather = bool(args.async_gather and dist is not None and n_workers == 1)
+    if async_gather:
+        engs.append(api.Engine(index, stream=torch.cuda.Stream(device=dev).cuda_stream))  # second set of output buffers
+
+        def run_steps(n_steps, record):  # noqa: F811 -- pipelined variant of the loop above
+            pending = [None, None]
+            for i in range(n_steps):
+                k = i & 1
+                if pending[k] is not None:  # the exchange that still reads context k's outputs
+                    pending[k].wait()
+                    pending[k] = None
+                out_k = engs[k].liftover_batch_dev(desc)
+                engs[k].compact_output_dev(out_k)
+                last_out[0] = out_k
+                pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
+                if record:
+                    tm = engs[k].timing()
+                    lift_ms.append(tm.lift_ms)
+                    enum_ms.append(tm.enumerate_ms)
+                    big_ms.append(tm.big_ms)
+                    lanes_ms.append(tm.lanes_ms)
+                    retry_ms.append(tm.retry_ms)
+            for p_ in pending:
+                if p_ is not None:
+                    p_.wait()
 
     run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
     torch.cuda.synchronize()
@@ -282,7 +312,7 @@ def main():
         "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
                    "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
                    "large_items_per_gpu": int(tm.n_big_items), "lane_items_per_gpu": int(tm.n_lane_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}", "host_workers_per_gpu": n_workers,
-                   "gather": "rccl send/recv to rank 0" if world > 1 else "none"},
+                   "gather": ("rccl send/recv to rank 0" + (", overlapped with the next batch" if async_gather else "")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,

@@ -124,9 +124,59 @@ def gather_payloads(t: Dict[str, torch.Tensor], dist, rank: int, world: int, roo
     return res
 
 
+class PendingGather:
+    """An exchange posted by gather_payloads_async: the requests, the tensors that must stay alive until they complete, and
+    (on the root) the per-rank results."""
+
+    def __init__(self, works, keep, result):
+        self.works, self.keep, self.result = works, keep, result
+
+    def wait(self):
+        for q in self.works:
+            q.wait()
+        self.works = []
+        return self.result
+
+
+def gather_payloads_async(t: Dict[str, torch.Tensor], dist, rank: int, world: int, root: int = 0) -> PendingGather:
+    """gather_payloads without the final wait: the size exchange is synchronous (16 bytes per rank), the payload messages are
+    posted and returned as a PendingGather.  The caller keeps computing the next batch (into OTHER output buffers) and calls
+    wait() before it reuses the buffers `t` views -- the exchange of batch i then overlaps the compute of batch i+1.  Every
+    rank must post its exchanges in the same order (single thread per rank)."""
+    dev = t["cigar"].device
+    fields = ITEM_FIELDS + [("cigar", np.uint32, torch.int32)]
+    sizes = torch.tensor([t["item_seg"].numel(), t["cigar"].numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    if rank != root:
+        keep = [t[name].contiguous() for name, _, _ in fields if t[name].numel()]
+        ops = [dist.P2POp(dist.isend, x, root) for x in keep]
+        return PendingGather(dist.batch_isend_irecv(ops) if ops else [], keep, None)
+    res: List[Dict[str, torch.Tensor]] = []
+    ops = []
+    for r in range(world):
+        if r == root:
+            res.append({name: t[name] for name, _, _ in fields})
+            continue
+        ni, nc = (int(x) for x in all_sizes[r].tolist())
+        d = {}
+        for name, _, tdt in fields:
+            n = nc if name == "cigar" else ni
+            d[name] = torch.empty(n, dtype=tdt, device=dev)
+            if n:
+                ops.append(dist.P2POp(dist.irecv, d[name], r))
+        res.append(d)
+    return PendingGather(dist.batch_isend_irecv(ops) if ops else [], res, res)
+
+
 def gather_results(out: abi.PloBatchOut, dev, dist, rank: int, world: int, root: int = 0):
     """GPU form: zero-copy views of the engine's device outputs -> gather on `root`."""
     return gather_payloads(tensors_from_out(out, dev), dist, rank, world, root)
+
+
+def gather_results_async(out: abi.PloBatchOut, dev, dist, rank: int, world: int, root: int = 0) -> PendingGather:
+    """GPU form of gather_payloads_async (zero-copy views of the engine's device outputs)."""
+    return gather_payloads_async(tensors_from_out(out, dev), dist, rank, world, root)
 
 
 def to_result(t: Dict[str, torch.Tensor]) -> abi.BatchResult:

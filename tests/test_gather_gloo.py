@@ -69,3 +69,55 @@ def test_shard_and_gather_world_size_2():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
         assert os.path.exists(os.path.join(d, "ok"))
+
+
+def _worker_async(rank, world, port, outdir):
+    """two batches in flight: the exchange of batch 0 is still pending when batch 1 is computed and posted"""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pend, wholes = [], []
+    for step in range(3):
+        w = synth.generate(synth.config("tiny", n_reads=60 + 10 * step, seed=310 + step, split_read_frac=0.2))
+        ix = w.index_data()
+        lo, hi = gather_shard(w.n_reads, rank, world)
+        res = pyoracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, 1)
+        if len(pend) == 2:  # double buffering: wait for the exchange posted two steps ago before "reusing its buffers"
+            first = pend.pop(0)
+            got = first[0].wait()
+            if rank == 0:
+                _check_gathered(got, first[1], first[2], world)
+        pend.append((gather.gather_payloads_async(gather.tensors_from_result(res), dist, rank, world), w,
+                     pyoracle.liftover_batch(ix, w.batch_data(), abi.STAGES_ALL, 1) if rank == 0 else None))
+    for p_, w, whole in pend:
+        got = p_.wait()
+        if rank == 0:
+            _check_gathered(got, w, whole, world)
+        else:
+            assert got is None
+    if rank == 0:
+        open(os.path.join(outdir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_gathered(got, w, whole, world):
+    rows = []
+    for r in range(world):
+        rlo, _ = gather_shard(w.n_reads, r, world)
+        seg_base = int(torch.searchsorted(w.seg_read, torch.tensor(rlo)).item())
+        part = gather.to_result(got[r])
+        part.item_seg = part.item_seg + np.uint32(seg_base)
+        rows += part.canonical()
+    assert rows == whole.canonical()
+
+
+def test_async_gather_world_size_2():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_async, args=(2, _free_port(), d), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(d, "ok"))
