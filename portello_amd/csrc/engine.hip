@@ -1,16 +1,21 @@
 // engine.hip -- gfx950 kernels + the C ABI of include/portello_liftover.h.
 //
 // Kernel pipeline of one batch (all on the context's stream):
-//   k_seg_count          thread per read split segment: reference span + how many contig segments it touches (a8)
+//   k_seg_count          eight lanes per read split segment: reference span + how many contig segments it touches (a8)
 //   scan                 item offsets, n_items
-//   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3)
-//   k_class_flags/scans/k_permute   class order (strand x size) so that groups and tiles are homogeneous
-//   scan + k_tile_bounds flattened op stream of the tiled items -> first item of every tile
-//   k_lift_lanes         (optional, off by default) lane-per-item fast path for short CIGARs + k_lift_retry
+//   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3), item weights
+//   k_class_flags/scan/k_permute   class order (strand x size) so that tiles are strand-homogeneous
+//   scan + k_max_u32     weight prefix; maximum, sum and histogram of the weights -> per-batch tile geometry (one host sync)
+//   k_tile_bounds        first item of every tile (windows of the weight prefix)
+//   k_lift_lanes         (optional, off by default) lane-per-item fast path for short CIGARs
 //   k_lift_tiles         DOMINANT KERNEL: persistent waves, one wave per tile of items, the whole
 //                        shift / liftover / length check / simplify pipeline on a flattened op stream in LDS
-//   k_lift_big           items too long for an LDS tile: one wave per item, wave-private global scratch
-//   k_finish_* / k_revcomp   record finishing (plo_finish_batch_dev)
+//   k_lift_retry         items of tiles that overflowed their LDS slice: one item per wave, larger slice
+//   k_lift_big           items heavier than the routing threshold: one wave per item, wave-private global scratch
+//   k_sum_stats          per-wave statistic slots -> batch counters (after every lift kernel)
+//   k_compact_cigar      dense re-packing of the slab-allocated output CIGARs (plo_compact_output_dev)
+//   k_finish_* / k_revcomp / k_sa_*   record finishing and SA text (plo_finish_batch_dev, plo_sa_segments_dev)
+//   k_map_build          block maps of the contig segments, once per index (plo_index_create)
 // There is no CPU path: every entry point fails with PLO_ERR_NO_DEVICE / PLO_ERR_HIP when the device is unusable.
 #include <hip/hip_runtime.h>
 
