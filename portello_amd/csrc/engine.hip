@@ -134,13 +134,16 @@ __global__ void k_class_flags(const uint32_t *item_cls, uint32_t n, uint32_t *f0
     f2[i] = c == 2;
 }
 __global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *r0, const uint32_t *r1,
-                          const uint32_t *r2, uint32_t n, uint32_t *perm, uint32_t *nin_p) {
+                          const uint32_t *r2, uint32_t n, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t c = item_cls[i];
     uint32_t j = class_order_pos(i, c, r0[i], r1[i], r2[i], r0[n], r1[n], r2[n]);
     perm[j] = i;
-    nin_p[j] = c >= 2 ? item_nin[i] : 0u;  // only the large items are tiled
+    // only the large items are tiled; items no geometry can hold (heavier than huge_w) take no room in the weight stream: they
+    // ride along in their neighbours' tiles, 64 per pass, and are handed to the large-item kernel there
+    uint32_t w = item_nin[i];
+    nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
 }
 
 // thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
@@ -996,7 +999,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         if (n_items) hipLaunchKernelGGL(k_permute, dim3((n_items + 255) / 256), dim3(256), 0, st,
                                         (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
                                         (const uint32_t *)c->rank0.as<uint32_t>(), (const uint32_t *)c->rank1.as<uint32_t>(),
-                                        (const uint32_t *)c->rank2.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>());
+                                        (const uint32_t *)c->rank2.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
+                                        c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu);
         s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
     }
@@ -1036,8 +1040,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             // contig block maps (many blocks per read) thus get larger slices and fewer resident waves instead of a
             // large-item kernel that runs every read alone from global scratch.
             const uint32_t *hist = h + 8;
-            unsigned long long above = 0, allow = n_items / 500;
-            int b = WHIST_BINS - 1;
+            // items in the open-ended last bin take the large-item kernel whatever the geometry: the threshold is chosen for the rest
+            unsigned long long above = 0, allow = (n_items - std::min<uint32_t>(n_items, hist[WHIST_BINS - 1])) / 500;
+            int b = WHIST_BINS - 2;
             for (; b > 0; --b) {  // lowest threshold (b * WHIST_STEP) with at most `allow` items above it
                 if (above + hist[b] > allow) break;
                 above += hist[b];
