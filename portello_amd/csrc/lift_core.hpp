@@ -191,8 +191,11 @@ PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
 // active item's output has two neighbouring I/D ops, i.e. an indel cluster of more than one op.
 // -------------------------------------------------------------------------------------------------------------------
 PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
-                              bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false) {
+                              bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false, int *read_len = nullptr) {
+    // read_len (optional, [64] in LDS): per item, the read bases its CIGAR consumes -- the edge clean-up and the merge do not
+    // change that sum, so it is taken from the raw ops on the way (saves the length check its own pass)
     const int lane = wv::lane();
+    if (read_len) read_len[lane] = 0;
     if (!edges_known) {
         m.itf[lane] = IMAX;
         m.itl[lane] = -1;
@@ -238,6 +241,7 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             int i_act = wv::shfl((int)active, id);
             uint32_t cc = valid ? X[e] : 0;
             int t = op_type(cc), L = op_len(cc);
+            if (read_len && valid && read_consuming(t) && L > 0) wv::atomic_add(&read_len[id], L);
             int f = IMAX, l = -1;
             if (valid && i_act) {
                 f = m.itf[id];
@@ -861,6 +865,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     PLO_T(2)
     // the lifted CIGARs of the tile have an indel cluster of more than one op (known after the liftover's clean-up)
     bool lifted_pairs = true;
+    bool have_read_len = false;  // m.itc holds the read bases consumed by every item's lifted CIGAR
     // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ------------------------------------------------------------------
     if (!overflow && (stages & PLO_STAGE_LIFTOVER)) {
         // per item: the window [W0, W1) of the block map that can intersect the item was located by build_item_desc;
@@ -1054,7 +1059,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     alive = false;
                 }
                 int shift = 0, nOut = 0;
-                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true);  // :219-220
+                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true, m.itc);  // :219-220
+                have_read_len = true;
                 sA = sB;
                 cA = cB;
                 nA = nOut;
@@ -1066,7 +1072,14 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     PLO_T(5)
     // ---- LENGTH CHECK (src/read_alignment_scanner.rs:204-229) ------------------------------------------------------------------
     bool simp = alive;
-    if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
+    if (!overflow && (stages & PLO_STAGE_LENCHECK) && have_read_len) {
+        // the liftover's clean-up/compress pass has summed the read bases of every item's CIGAR into m.itc
+        int rl = m.itc[lane];
+        if (alive && seq_len != rl) {
+            status = PLO_ITEM_LEN_MISMATCH;
+            simp = false;
+        }
+    } else if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
         AddScan rs;
         for (int base = 0; base < nA; base += 64) {
             int e = base + lane;
