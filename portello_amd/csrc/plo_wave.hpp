@@ -41,6 +41,16 @@ PLO_DEV int shfl_up1(int v, int first) {
 PLO_DEV unsigned long long ballot(bool p) { return __ballot(p); }
 PLO_DEV int bcast_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
 PLO_DEV int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+PLO_DEV unsigned bcast_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+PLO_DEV unsigned long long bcast_first(unsigned long long v) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
+    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// Several waves of one workgroup working on the same tile (Coop<NW>, lift_core.hpp): index of the wave inside the workgroup
+// (in an SGPR) and the workgroup barrier (LDS writes of every wave before it are visible to every wave after it)
+PLO_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+PLO_DEV void block_sync() { __syncthreads(); }
 
 #define PLO_DPP(old, x, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (x), (ctrl), (rmask), 0xf, false)
 

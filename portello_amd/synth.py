@@ -85,9 +85,15 @@ def config(name: str, **over) -> WorkloadConfig:
         lens = tuple(int(x * scale) for x in lens)
         c = WorkloadConfig(name="wgs30x", sorted_reads=True, seed=SEED_BASE + 2, chrom_lens=lens, n_contigs_per_hap=300, n_haps=2,
                            max_segments=5, n_reads=2_000_000)
-    elif name == "stress":  # configs[4]: 20 kb reads, 5 % indel-dense CIGARs
-        lens = (64_000_000,)
-        c = WorkloadConfig(name="stress", sorted_reads=True, seed=SEED_BASE + 4, chrom_lens=lens, n_contigs_per_hap=10, n_haps=2,
+    elif name == "stress":  # configs[4]: 20 kb reads, 5 % indel-dense CIGARs, same contigs as wgs30x
+        # the read count is a parameter (8(d): default 2 M; 200 k keeps the generator's footprint and the test time bounded --
+        # a read carries ~2 000 ops, so 200 k reads are 4e8 input ops, six times wgs30x's whole batch)
+        base = config("wgs30x")
+        c = WorkloadConfig(name="stress", sorted_reads=True, seed=SEED_BASE + 4, chrom_lens=base.chrom_lens, n_contigs_per_hap=300, n_haps=2,
+                           max_segments=5, n_reads=200_000, read_len_mean=20_000, read_len_sd=2_000,
+                           read_rates=EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1))
+    elif name == "stress_small":  # the same read profile on a 64 Mb reference (quick tuning runs)
+        c = WorkloadConfig(name="stress_small", sorted_reads=True, seed=SEED_BASE + 4, chrom_lens=(64_000_000,), n_contigs_per_hap=10, n_haps=2,
                            max_segments=5, n_reads=100_000, read_len_mean=20_000, read_len_sd=2_000,
                            read_rates=EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1))
     else:

@@ -24,17 +24,27 @@
 namespace wv {
 
 struct EmuWave {
-    static constexpr int N = 64;
-    static constexpr size_t STACK = 512 * 1024;
+    // one emulated workgroup of `nw` waves (nw = 1: the single wave of the tile / retry / large-item kernels)
+    static constexpr int WAVE = 64;
+    static constexpr size_t STACK = 256 * 1024;
+    int nw = 1;
+    int N = 64;
     ucontext_t sched;
-    ucontext_t fiber[N];
+    std::vector<ucontext_t> fiber;
     std::vector<char> stacks;
-    bool done[N];
+    std::vector<char> done;
     int cur = 0;
-    // rendezvous state: double-buffered by primitive parity
-    int64_t slot[2][N][4];
-    int tag[2][N];
-    unsigned long long seq[N];
+    // rendezvous state of the wave-level primitives: double-buffered by primitive parity
+    struct Slot {
+        int64_t v[4];
+    };
+    std::vector<Slot> slot[2];
+    std::vector<int> tag[2];
+    std::vector<unsigned long long> seq;
+    // workgroup barrier (wv::block_sync): fibers wait for the generation to advance; the scheduler releases a generation
+    // at the start of a round once every live fiber has arrived, so that the lanes of a wave leave it in the same round
+    unsigned long long bar_gen = 0;
+    int bar_arrived = 0;
     std::function<void()> body;
     unsigned order_seed = 0;  // != 0: shuffle the lane execution order every round (catches missing wv::sync())
 
@@ -45,27 +55,46 @@ struct EmuWave {
     static void trampoline() {
         EmuWave *w = current();
         w->body();
-        w->done[w->cur] = true;
+        w->done[w->cur] = 1;
         swapcontext(&w->fiber[w->cur], &w->sched);
     }
     void run(std::function<void()> fn) {
         body = std::move(fn);
+        N = WAVE * nw;
+        fiber.resize(N);
+        done.assign(N, 0);
+        seq.assign(N, 0);
+        for (int p = 0; p < 2; ++p) {
+            slot[p].assign(N, Slot{{0, 0, 0, 0}});
+            tag[p].assign(N, 0);
+        }
         stacks.assign(STACK * N, 0);
+        bar_gen = 0;
+        bar_arrived = 0;
         current() = this;
         for (int l = 0; l < N; ++l) {
-            done[l] = false;
-            seq[l] = 0;
             getcontext(&fiber[l]);
             fiber[l].uc_stack.ss_sp = stacks.data() + STACK * l;
             fiber[l].uc_stack.ss_size = STACK;
             fiber[l].uc_link = &sched;
             makecontext(&fiber[l], (void (*)())trampoline, 0);
         }
-        int order[N];
+        std::vector<int> order(N);
         for (int l = 0; l < N; ++l) order[l] = l;
         unsigned rs = order_seed;
         for (;;) {
-            bool any = false;
+            int live = 0;
+            for (int l = 0; l < N; ++l) live += done[l] ? 0 : 1;
+            if (!live) break;
+            if (bar_arrived > 0) {
+                if (bar_arrived == live) {
+                    bar_arrived = 0;
+                    ++bar_gen;
+                } else if (stalled) {
+                    fprintf(stderr, "wave emulator: workgroup barrier reached by %d of %d live lanes only (divergent block_sync)\n", bar_arrived, live);
+                    abort();
+                }
+            }
             if (order_seed) {
                 for (int i = N - 1; i > 0; --i) {
                     rs = rs * 1664525u + 1013904223u;
@@ -75,30 +104,35 @@ struct EmuWave {
                     order[j] = t;
                 }
             }
+            progress = 0;
             for (int i = 0; i < N; ++i) {
                 int l = order[i];
                 if (done[l]) continue;
-                any = true;
                 cur = l;
                 swapcontext(&sched, &fiber[l]);
             }
-            if (!any) break;
+            stalled = progress == 0;
         }
         current() = nullptr;
     }
-    // rendezvous: publish (tag, payload), wait for everybody, return parity buffer index to read from
+    int progress = 0;
+    bool stalled = false;
+    int wave_base() const { return cur & ~(WAVE - 1); }
+    // rendezvous: publish (tag, payload), wait for the wave, return parity buffer index to read from
     int rendezvous(int t, const int64_t *payload, int n) {
         int par = (int)(seq[cur] & 1);
-        for (int i = 0; i < n; ++i) slot[par][cur][i] = payload[i];
+        for (int i = 0; i < n; ++i) slot[par][cur].v[i] = payload[i];
         tag[par][cur] = t;
         seq[cur]++;
+        ++progress;
         int me = cur;
         swapcontext(&fiber[me], &sched);
         cur = me;
         return par;
     }
     void check(int par, int t) {
-        for (int l = 0; l < N; ++l) {
+        int b = wave_base();
+        for (int l = b; l < b + WAVE; ++l) {
             if (seq[l] < seq[cur] || tag[par][l] != t) {
                 fprintf(stderr, "wave emulator: divergent primitive (lane %d tag %d vs lane %d tag %d, done=%d)\n", cur, t, l,
                         tag[par][l], (int)done[l]);
@@ -106,11 +140,24 @@ struct EmuWave {
             }
         }
     }
+    int64_t peer(int par, int lane_in_wave, int i = 0) const { return slot[par][wave_base() + (lane_in_wave & (WAVE - 1))].v[i]; }
+    void block_barrier() {
+        int me = cur;
+        unsigned long long g = bar_gen;
+        ++bar_arrived;
+        ++progress;
+        while (bar_gen == g) {
+            swapcontext(&fiber[me], &sched);
+            cur = me;
+        }
+    }
 };
 
 inline EmuWave &W() { return *EmuWave::current(); }
 
-inline int lane() { return W().cur; }
+inline int lane() { return W().cur & 63; }
+inline int wave_id() { return W().cur >> 6; }
+inline void block_sync() { W().block_barrier(); }
 inline long long clock() { return 0; }
 
 enum { T_SYNC = 1, T_SHFL, T_SHFL_UP1, T_BALLOT, T_BCAST_LAST, T_BCAST_FIRST, T_SCAN_ADD, T_SCAN_MAX, T_SCAN_MP };
@@ -124,7 +171,7 @@ inline void sync() {
 inline int64_t shfl64(int64_t v, int src) {
     int par = W().rendezvous(T_SHFL, &v, 1);
     W().check(par, T_SHFL);
-    return W().slot[par][src & 63][0];
+    return W().peer(par, src);
 }
 inline int shfl(int v, int src) { return (int)shfl64(v, src); }
 inline unsigned shfl(unsigned v, int src) { return (unsigned)shfl64((int64_t)v, src); }
@@ -136,7 +183,7 @@ inline int shfl_up1(int v, int first) {
     int par = W().rendezvous(T_SHFL_UP1, &p, 1);
     W().check(par, T_SHFL_UP1);
     int l = lane();
-    return l == 0 ? first : (int)W().slot[par][l - 1][0];
+    return l == 0 ? first : (int)W().peer(par, l - 1);
 }
 
 inline unsigned long long ballot(bool p) {
@@ -145,20 +192,25 @@ inline unsigned long long ballot(bool p) {
     W().check(par, T_BALLOT);
     unsigned long long m = 0;
     for (int l = 0; l < 64; ++l)
-        if (W().slot[par][l][0]) m |= 1ull << l;
+        if (W().peer(par, l)) m |= 1ull << l;
     return m;
 }
 inline int bcast_last(int v) {
     int64_t p = v;
     int par = W().rendezvous(T_BCAST_LAST, &p, 1);
     W().check(par, T_BCAST_LAST);
-    return (int)W().slot[par][63][0];
+    return (int)W().peer(par, 63);
 }
 inline int bcast_first(int v) {
     int64_t p = v;
     int par = W().rendezvous(T_BCAST_FIRST, &p, 1);
     W().check(par, T_BCAST_FIRST);
-    return (int)W().slot[par][0][0];
+    return (int)W().peer(par, 0);
+}
+inline unsigned bcast_first(unsigned v) { return (unsigned)bcast_first((int)v); }
+inline unsigned long long bcast_first(unsigned long long v) {
+    unsigned lo = bcast_first((unsigned)(v & 0xffffffffull)), hi = bcast_first((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 inline int imax(int a, int b) { return a > b ? a : b; }
 inline int imin(int a, int b) { return a < b ? a : b; }
@@ -184,7 +236,7 @@ inline int scan_add(int x) {
     int par = W().rendezvous(T_SCAN_ADD, &p, 1);
     W().check(par, T_SCAN_ADD);
     unsigned s = 0;  // wrap-around like the hardware
-    for (int l = 0; l <= lane(); ++l) s += (unsigned)(int)W().slot[par][l][0];
+    for (int l = 0; l <= lane(); ++l) s += (unsigned)(int)W().peer(par, l);
     return (int)s;
 }
 inline int scan_max(int x) {
@@ -192,7 +244,7 @@ inline int scan_max(int x) {
     int par = W().rendezvous(T_SCAN_MAX, &p, 1);
     W().check(par, T_SCAN_MAX);
     int m = (int)0x80000000;
-    for (int l = 0; l <= lane(); ++l) m = imax(m, (int)W().slot[par][l][0]);
+    for (int l = 0; l <= lane(); ++l) m = imax(m, (int)W().peer(par, l));
     return m;
 }
 inline int reduce_add(int x) { return bcast_last(scan_add(x)); }
@@ -219,7 +271,7 @@ inline MinPlus scan_minplus(MinPlus x) {
     W().check(par, T_SCAN_MP);
     MinPlus acc = {0, 0x7fffffff, 0};
     for (int l = 0; l <= lane(); ++l) {
-        MinPlus c = {(int)W().slot[par][l][0], (int)W().slot[par][l][1], (int)W().slot[par][l][2]};
+        MinPlus c = {(int)W().peer(par, l, 0), (int)W().peer(par, l, 1), (int)W().peer(par, l, 2)};
         acc = mp_compose(acc, c);
     }
     return acc;

@@ -238,6 +238,68 @@ def test_full_size_properties_chr20(oracle):
     eng_ix.close()
 
 
+def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, **over):
+    import torch
+
+    import fullsize
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config(name, **over), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    res = devbatch.run_and_download(eng, db)
+    t = eng.timing()
+    fullsize.check_properties(w, res, min_lifted)
+    # idempotence: the pipeline is a pure function of its inputs (positions, lengths and every 97th CIGAR)
+    res2 = devbatch.run_and_download(eng, db)
+    assert (res2.item_ref_pos == res.item_ref_pos).all() and (res2.item_cigar_len == res.item_cigar_len).all()
+    assert (res2.item_status == res.item_status).all()
+    for i in range(0, res.n_items, 97):
+        assert np.array_equal(res.item_cigar(i), res2.item_cigar(i))
+    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, n_blocks, block)
+    _dump(f"full_size_{name}.json", {"reads": w.n_reads, "items": int(res.n_items), "items_compared_with_oracle": n_cmp,
+                                     "of_them_flipped": n_flip, "contigs_in_sample": n_contigs, "large_items": int(t.n_big_items),
+                                     "mid_items": int(getattr(t, "n_mid_items", 0)), "retry_items": int(t.n_retry_items),
+                                     "lift_ms": t.lift_ms, "mid_ms": float(getattr(t, "mid_ms", 0.0)), "big_ms": t.big_ms})
+    assert n_cmp > 0 and n_flip > 0 and n_contigs > 1
+    eng.close()
+    eng_ix.close()
+    return t
+
+
+def test_full_size_wgs30x(oracle):
+    """BASELINE configs[2] (the bench workload) at full size: properties of all ~2 M records + oracle parity on 50 blocks of
+    400 reads spread over the whole coordinate-sorted read set"""
+    _full_size("wgs30x", oracle, 50, 400)
+
+
+def test_full_size_stress(oracle):
+    """BASELINE configs[4] read profile (20 kb, 5 % indel-dense, ~2 000 ops per read) on the wgs30x contigs: every item is
+    far heavier than a shared tile holds, so this is the test of the workgroup-per-item kernel"""
+    _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
+
+
+def test_geometry_sweep(oracle):
+    """every item of five workloads with different contig block-map densities / strand mixes (hence different per-batch tile
+    geometries, retry and large-item traffic) against the oracle (tools/soak.py at a size that finishes in a minute)"""
+    import torch
+
+    from portello_amd import devbatch
+
+    for rate, rev, seed in ((1e-4, 0.5, 1), (1e-3, 0.5, 2), (2e-3, 0.3, 3), (5e-4, 1.0, 4), (3e-3, 0.5, 5)):
+        cr = synth.EditRates(mismatch=1e-3, ins=rate, dele=rate, hpol_frac=0.3, big_indel_prob=0.02)
+        cfg = synth.config("chr20", n_reads=12_000, rev_contig_frac=rev, contig_rates=cr, seed=synth.config("chr20").seed + seed)
+        w = synth.generate(cfg, device="cuda")
+        index = api.Index(w.index_data_device())
+        eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+        got = devbatch.run_and_download(eng, devbatch.DeviceBatch.from_workload(w))
+        ref = oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, 8)
+        _assert_same(ref, got, f"sweep_{seed}")
+        eng.close()
+        index.close()
+
+
 def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
     """bench.py's N > 1 path wraps the engine's device outputs as torch tensors (no copy) before the RCCL gather"""
     import torch
