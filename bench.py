@@ -156,7 +156,7 @@ def main():
         last_out[k] = out
         return out
 
-    lift_ms, enum_ms, big_ms, lanes_ms, retry_ms = [], [], [], [], []
+    lift_ms, enum_ms, big_ms, mid_ms, retry_ms = [], [], [], [], []
 
     def run_steps(n_steps, record):
         """n_steps batches, dealt to the workers in turn; every worker drives its own context on its own stream"""
@@ -172,7 +172,7 @@ def main():
                         lift_ms.append(tm.lift_ms)
                         enum_ms.append(tm.enumerate_ms)
                         big_ms.append(tm.big_ms)
-                        lanes_ms.append(tm.lanes_ms)
+                        mid_ms.append(tm.mid_ms)
                         retry_ms.append(tm.retry_ms)
             except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
                 errors.append(e)
@@ -208,7 +208,7 @@ def main():
                     lift_ms.append(tm.lift_ms)
                     enum_ms.append(tm.enumerate_ms)
                     big_ms.append(tm.big_ms)
-                    lanes_ms.append(tm.lanes_ms)
+                    mid_ms.append(tm.mid_ms)
                     retry_ms.append(tm.retry_ms)
             for p_ in pending:
                 if p_ is not None:
@@ -279,7 +279,7 @@ def main():
         for e in o_engs:
             e.close()
     tm = eng.timing()
-    kms = {"k_lift_lanes": float(np.mean(lanes_ms)), "k_lift_tiles": float(np.mean(lift_ms)), "k_lift_big": float(np.mean(big_ms)),
+    kms = {"k_lift_mid": float(np.mean(mid_ms)), "k_lift_tiles": float(np.mean(lift_ms)), "k_lift_big": float(np.mean(big_ms)),
            "k_lift_retry": float(np.mean(retry_ms))}
     dominant = max(kms, key=kms.get)
     dom_ms = kms[dominant]
@@ -311,13 +311,13 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
                    "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
-                   "large_items_per_gpu": int(tm.n_big_items), "lane_items_per_gpu": int(tm.n_lane_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}", "host_workers_per_gpu": n_workers,
+                   "large_items_per_gpu": int(tm.n_big_items), "mid_items_per_gpu": int(tm.n_mid_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}", "host_workers_per_gpu": n_workers,
                    "gather": ("rccl send/recv to rank 0" + (", overlapped with the next batch" if async_gather else "")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
                      "enumerate_ms": float(np.mean(enum_ms)), "lift_tiles_ms": float(np.mean(lift_ms)),
-                     "lift_big_ms": float(np.mean(big_ms)), "lift_lanes_ms": float(np.mean(lanes_ms)),
+                     "lift_big_ms": float(np.mean(big_ms)), "lift_mid_ms": float(np.mean(mid_ms)),
                      "lift_retry_ms": float(np.mean(retry_ms))},
     }
     if overlap is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLO_API_VERSION 1
+#define PLO_API_VERSION 2
 
 typedef enum plo_status {
     PLO_OK = 0,
@@ -181,16 +181,18 @@ typedef struct plo_timing {
     float total_ms;      /* first kernel start -> last kernel end                                   */
     float enumerate_ms;  /* item enumeration + scans                                                */
     float lift_ms;       /* the wave-cooperative tile kernel (longer CIGARs)                         */
-    float big_ms;        /* large-item kernel (0 if not launched)                                   */
+    float big_ms;        /* one-wave-per-item kernel in global scratch (0 if not launched)          */
     uint32_t n_items;
-    uint32_t n_big_items;
+    uint32_t n_big_items; /* items of that kernel */
     uint64_t n_in_ops;   /* input CIGAR ops over all items                                          */
     uint64_t n_out_ops;  /* output CIGAR ops                                                        */
     uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device */
-    float lanes_ms;      /* lane-per-item kernel (short CIGARs)                                      */
-    float retry_ms;      /* items re-run by the tile code after overflowing the lane kernel          */
+    float lanes_ms;      /* always 0 (the lane-per-item kernel of API version 1 was removed)         */
+    float retry_ms;      /* items of tiles that overflowed their LDS slice, re-run one per wave       */
     uint32_t n_lane_items;
     uint32_t n_retry_items;
+    float mid_ms;        /* workgroup-per-item kernel (items too heavy for a shared tile)             */
+    uint32_t n_mid_items;
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

@@ -121,6 +121,8 @@ class PloTiming(C.Structure):
         ("retry_ms", C.c_float),
         ("n_lane_items", C.c_uint32),
         ("n_retry_items", C.c_uint32),
+        ("mid_ms", C.c_float),
+        ("n_mid_items", C.c_uint32),
     ]
 
 

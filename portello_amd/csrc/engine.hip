@@ -7,11 +7,12 @@
 //   k_class_flags/scan/k_permute   class order (strand x size) so that tiles are strand-homogeneous
 //   scan + k_max_u32     weight prefix; maximum, sum and histogram of the weights -> per-batch tile geometry (one host sync)
 //   k_tile_bounds        first item of every tile (windows of the weight prefix)
-//   k_lift_lanes         (optional, off by default) lane-per-item fast path for short CIGARs
 //   k_lift_tiles         DOMINANT KERNEL: persistent waves, one wave per tile of items, the whole
 //                        shift / liftover / length check / simplify pipeline on a flattened op stream in LDS
 //   k_lift_retry         items of tiles that overflowed their LDS slice: one item per wave, larger slice
-//   k_lift_big           items heavier than the routing threshold: one wave per item, wave-private global scratch
+//   k_lift_mid           items heavier than the routing threshold: one WORKGROUP per item (8 or 16 waves share the item's op
+//                        stream in LDS, scan carries cross the waves through LDS: Coop<NW>, lift_core.hpp)
+//   k_lift_big           items too heavy even for that: one wave per item, wave-private global scratch
 //   k_sum_stats          per-wave statistic slots -> batch counters (after every lift kernel)
 //   k_compact_cigar      dense re-packing of the slab-allocated output CIGARs (plo_compact_output_dev)
 //   k_finish_* / k_revcomp / k_sa_*   record finishing and SA text (plo_finish_batch_dev, plo_sa_segments_dev)
@@ -30,7 +31,6 @@
 #include "enumerate.hpp"
 #include "finish_core.hpp"
 #include "index_pack.hpp"
-#include "lane_core.hpp"
 #include "lift_core.hpp"
 
 using namespace plo;
@@ -287,27 +287,6 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(Dev
     wave_ctx_flush(wk, ctx, wave);
 }
 
-// Short-CIGAR fast path: one lane per item, 64 items per wave (lane_core.hpp); persistent waves over groups of 64.
-constexpr int LANE_WAVES = 2;
-__global__ __launch_bounds__(LANE_WAVES * 64) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
-                                                               uint32_t lds_per_wave) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int w = threadIdx.x >> 6;
-    uint32_t nb = gridDim.x, per = nb >> 3, b = blockIdx.x;
-    uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
-    const uint32_t wave = tb * LANE_WAVES + (uint32_t)w, n_waves = nb * LANE_WAVES;
-    const uint32_t n_groups = (wk.n_small + 63u) / 64u;
-    LaneMem m = carve_lane_mem(smem + (size_t)w * lds_per_wave);
-    WaveCtx ctx;
-    for (uint32_t gi = wave; gi < n_groups; gi += n_waves) {
-        uint32_t b0 = gi * 64u;
-        uint32_t left = wk.n_small - b0;
-        lift_lanes(ix, bt, wk, stages, b0, (int)(left < 64u ? left : 64u), m, ctx);
-        wv::sync();
-    }
-    wave_ctx_flush(wk, ctx, wave);
-}
-
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
 // items per wave with a larger LDS slice (retry_cap)
 constexpr uint32_t RETRY_PER = 1;
@@ -316,20 +295,49 @@ __global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, Dev
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileMem m = carve_tile_mem(smem, cap);
     WaveCtx ctx;
+    Coop<1> co;
     for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
         uint32_t left = n_retry - r;
-        lift_tile(ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+        lift_tile(co, ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx, blockIdx.x);
 }
 
+// One workgroup of NW waves per item (Coop<NW>): the item's op stream, temporaries and block-map window live in the
+// workgroup's LDS (cap elements), every pass walks it NW x 64 elements at a time.  Persistent workgroups over `list`.
+constexpr int MID_CAPK = 512;  // staged block-map entries of the one item (4 KB); longer windows are read from global memory
+// 128 VGPRs at most: 16 waves per CU, as one workgroup of 16 or two of 8
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lift_mid(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_list,
+                                                      int mid_thresh, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileMem m = carve_tile_mem(smem, cap, MID_CAPK);
+    Coop<NW> co;
+    co.w = wv::wave_id();
+    co.xch = (int *)(smem + ((tile_mem_bytes(cap, MID_CAPK) + 15) & ~(size_t)15));
+    if (threadIdx.x < (unsigned)Coop<NW>::XCH_INTS) co.xch[threadIdx.x] = 0;
+    __syncthreads();
+    WaveCtx ctx;
+    for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
+        lift_tile(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
+        co.sync();
+    }
+    wave_ctx_flush(wk, ctx, blockIdx.x * NW + (uint32_t)co.w);
+}
+template <int NW>
+static size_t mid_lds_bytes(int cap) {
+    return ((tile_mem_bytes(cap, MID_CAPK) + 15) & ~(size_t)15) + (size_t)Coop<NW>::XCH_INTS * 4;
+}
+
 __global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
-                                                 unsigned char *scratch, int big_cap, unsigned long long bytes_per_wave) {
+                                                 const uint32_t *list, unsigned char *scratch, int big_cap,
+                                                 unsigned long long bytes_per_wave) {
     TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
     WaveCtx ctx;
+    Coop<1> co;
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
+        lift_tile(co, ix, bt, wk, stages, i, 1, m, list, LEVEL_LAST, 0, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx, blockIdx.x);
@@ -436,8 +444,9 @@ __global__ __launch_bounds__(64) void k_selftest(const int *in, int *out) {
     out[8 * 64 + lane] = F.s;
     unsigned long long bm = wv::ballot((x & 1) != 0);
     out[9 * 64 + lane] = (int)((bm >> lane) & 1ull);
-    AddScan as;
-    MaxScan ms(-1);
+    Coop<1> co;
+    AddScan as(co);
+    MaxScan ms(co, -1);
     int a0 = as.excl(x & 15), a1 = as.excl((x >> 4) & 15);
     int m0 = ms.incl((x & 3) == 0 ? lane : -1);
     int e0 = ms.excl_of(m0);
@@ -525,7 +534,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, scratch, tile_lo;
+    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
@@ -534,8 +543,8 @@ struct plo_ctx {
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
     HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_big = false;
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_big = false, ev_mid = false;
     plo_timing timing{};
     unsigned long long phase_cycles[12] = {0};
     // tuning
@@ -546,10 +555,14 @@ struct plo_ctx {
     bool adaptive = true;  // geometry chosen per batch (off when any of PLO_WINDOW / PLO_BIG_THRESH / PLO_CAP is set)
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
-    // routing threshold of the lane-per-item kernel (k_lift_lanes).  Measured on MI355X (wgs30x): forward items run 1.6x
-    // faster there than in the tile kernel, reverse items 0.8x (per-lane homology probes serialise HBM latency), the mix
-    // is a net loss -> off by default (-1); PLO_LANE_MAX_IN=40 enables it.
+    // (a lane-per-item kernel for short CIGARs was measured in round 1: forward items 1.6x faster than the tile kernel of that
+    // time, reverse items 0.8x -- per-lane homology probes serialise HBM latency -- a net loss; removed.  The class order
+    // it needed stays: tiles are strand-homogeneous.)
     int lane_max_in = -1;
+    // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
+    // such items then run one wave each from global scratch) and the largest LDS capacity in elements
+    int mid_waves = 16;
+    int mid_cap_max = 4096;
 };
 
 #define HIP_TRY(ctx, call)                                                                      \
@@ -744,8 +757,10 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
         }
         c->own_stream = true;
     }
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(c->ev[k]);
+            if (c->own_stream) (void)hipStreamDestroy(c->stream);
             delete c;
             return PLO_ERR_HIP;
         }
@@ -762,8 +777,13 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
             fprintf(stderr, "[plo] cap %d: dynamic LDS %zu B/block -> %d blocks/CU (%s)\n", cap, lds, nb, hipGetErrorString(e));
         }
     }
-    if (const char *e = getenv("PLO_LANE_MAX_IN")) c->lane_max_in = std::min(atoi(e), LANE_CAP);
-    (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_mid<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_mid<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char *e = getenv("PLO_MID_WAVES")) {
+        int v = atoi(e);
+        c->mid_waves = v >= 16 ? 16 : (v >= 8 ? 8 : 0);
+    }
+    if (const char *e = getenv("PLO_MID_CAP")) c->mid_cap_max = std::min(4096, std::max(256, atoi(e) & ~63));
     (void)hipFuncSetAttribute((const void *)k_lift_retry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e)), c->adaptive = false;
@@ -780,7 +800,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
                       &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
-                      &c->counters, &c->big_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
+                      &c->counters, &c->big_list, &c->huge_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
@@ -790,7 +810,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     HostBuf *hb[] = {&c->h_item_seg, &c->h_item_cseg, &c->h_status, &c->h_flip, &c->h_mapq, &c->h_chrom, &c->h_pos,
                      &c->h_coff, &c->h_clen, &c->h_cigar, &c->h_counters};
     for (HostBuf *b : hb) b->release();
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 5; ++i)
         if (c->fev[i]) (void)hipEventDestroy(c->fev[i]);
@@ -863,6 +883,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     hipStream_t st = c->stream;
     memset(&c->timing, 0, sizeof(c->timing));
     c->ev_big = false;
+    c->ev_mid = false;
 
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     // ---- items: count -> scan -> resolve descriptors -> scan op counts -> tile bounds ----
@@ -1073,26 +1094,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
-    uint32_t n_big = 0, n_retry = 0;
+    uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0;
     for (int attempt = 0;; ++attempt) {
         wk.out_cigar = c->o_cigar.as<uint32_t>();
         wk.out_cap = c->o_cigar.cap / 4;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
         if (attempt == 0) HIP_TRY(c, hipEventRecord(c->ev[1], st));
-        if (n_small) {
-            uint32_t lpw = (uint32_t)((lane_mem_bytes() + 15) & ~(size_t)15);
-            uint32_t groups = (n_small + 63u) / 64u;
-            uint32_t nblk = (groups + LANE_WAVES - 1) / LANE_WAVES;
-            int occ = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_lanes, LANE_WAVES * 64,
-                                                             (size_t)lpw * LANE_WAVES) != hipSuccess || occ < 1)
-                occ = 1;
-            nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
-            nblk = (nblk + 7u) & ~7u;
-            hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lpw * LANE_WAVES, st, ix, bt, wk, stages, lpw);
-            PLO_SUM_STATS(nblk * LANE_WAVES);
-            HIP_TRY(c, hipGetLastError());
-        }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
         if (n_items > n_small) {
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
@@ -1132,7 +1139,42 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         }
         HIP_TRY(c, hipEventRecord(c->ev[5], st));
         n_big = (uint32_t)hc[CNT_NBIG];
-        if (n_big) {
+        n_mid = 0;
+        n_huge = n_big;
+        const uint32_t *huge_src = c->big_list.as<uint32_t>();
+        if (n_big && c->mid_waves) {
+            // One workgroup per item.  Capacity from the heaviest item of the batch: the stages at most add a deletion per block
+            // (already in the weight) and re-shape indel clusters, so a quarter on top of the weight holds every intermediate of
+            // all but pathological items; those, and items beyond the largest slice, go on to the global-scratch kernel.
+            int cap = std::min<unsigned long long>((unsigned long long)c->mid_cap_max, (((unsigned long long)max_nin * 5 / 4 + 64 + 63) & ~63ull));
+            cap = std::max(cap, 512);
+            const int mid_thresh = (cap - 64) * 4 / 5;
+            const int nw = c->mid_waves;
+            const size_t lds = nw == 16 ? mid_lds_bytes<16>(cap) : mid_lds_bytes<8>(cap);
+            const void *fn = nw == 16 ? (const void *)k_lift_mid<16> : (const void *)k_lift_mid<8>;
+            int occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nw * 64, lds) != hipSuccess || occ < 1) occ = 1;
+            uint32_t nblk = std::min<uint32_t>(n_big, (uint32_t)(c->n_cus * occ));
+            HIP_TRY(c, c->huge_list.ensure((size_t)n_big * 4));
+            wk.huge_list = c->huge_list.as<uint32_t>();
+            if (getenv("PLO_DEBUG_GEOMETRY"))
+                fprintf(stderr, "[plo] workgroup-per-item kernel: %u items, %d waves, cap %d (threshold %d), %zu B LDS, %d workgroups per CU\n", n_big, nw,
+                        cap, mid_thresh, lds, occ);
+            if (nw == 16)
+                hipLaunchKernelGGL(k_lift_mid<16>, dim3(nblk), dim3(16 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
+            else
+                hipLaunchKernelGGL(k_lift_mid<8>, dim3(nblk), dim3(8 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->ev[6], st));
+            PLO_SUM_STATS(nblk * (uint32_t)nw);
+            c->ev_mid = true;
+            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            n_huge = (uint32_t)hc[CNT_NHUGE];
+            n_mid = n_big - n_huge;
+            huge_src = c->huge_list.as<uint32_t>();
+        }
+        if (n_huge) {
             // size the wave-private scratch from the largest possible intermediate of a single item
             // (pieces <= ops + blocks, raw ops <= 2 x pieces); an item that still overflows is reported (CNT_ERROR)
             int big_cap = 4096;
@@ -1140,10 +1182,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             if (const char *e = getenv("PLO_BIG_CAP")) big_cap = std::max(1024, atoi(e));
             unsigned long long bpw = (tile_mem_bytes(big_cap) + 255) & ~(unsigned long long)255;
             // as many waves as the chip keeps resident (register-limited: 3 per SIMD), bounded by a 4 GiB scratch
-            uint32_t nw = std::min<uint32_t>(n_big, (uint32_t)c->n_cus * 12u);
+            uint32_t nw = std::min<uint32_t>(n_huge, (uint32_t)c->n_cus * 12u);
             nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
             HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
-            hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_big, c->scratch.as<unsigned char>(),
+            hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_huge, huge_src, c->scratch.as<unsigned char>(),
                                big_cap, bpw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[3], st));
@@ -1164,7 +1206,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         return PLO_ERR_INTERNAL;
     }
     c->timing.n_items = n_items;
-    c->timing.n_big_items = n_big;
+    c->timing.n_big_items = n_huge;
+    c->timing.n_mid_items = n_mid;
     c->timing.n_lane_items = n_small;
     c->timing.n_retry_items = n_retry;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
@@ -1401,18 +1444,20 @@ void plo_host_free(void *p) {
 plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     if (!c || !t) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float a = 0, l = 0, b = 0, r = 0, g = 0;
+    float a = 0, l = 0, b = 0, r = 0, g = 0, md = 0;
     (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&l, c->ev[1], c->ev[4]);
     (void)hipEventElapsedTime(&b, c->ev[4], c->ev[2]);
     (void)hipEventElapsedTime(&r, c->ev[2], c->ev[5]);
-    if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev[5], c->ev[3]);
+    if (c->ev_mid) (void)hipEventElapsedTime(&md, c->ev[5], c->ev[6]);
+    if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev_mid ? c->ev[6] : c->ev[5], c->ev[3]);
     c->timing.enumerate_ms = a;
     c->timing.lanes_ms = l;
     c->timing.lift_ms = b;
     c->timing.retry_ms = r;
+    c->timing.mid_ms = md;
     c->timing.big_ms = g;
-    c->timing.total_ms = a + l + b + r + g;
+    c->timing.total_ms = a + l + b + r + md + g;
     *t = c->timing;
     return PLO_OK;
 }

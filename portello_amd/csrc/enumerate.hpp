@@ -115,7 +115,7 @@ PLO_DEV int item_weight(int n_in, int w0, int w1, int kv1) {
     int nblk = (w1 + 1 < kv1 ? w1 + 1 : kv1) - w0;
     return n_in + 2 * (nblk > 0 ? nblk : 0);
 }
-enum { LEVEL_TILE = 0, LEVEL_RETRY = 1, LEVEL_LAST = 2 };
+enum { LEVEL_TILE = 0, LEVEL_RETRY = 1, LEVEL_LAST = 2, LEVEL_MID = 3 };
 
 // Resolves everything the tile kernel needs to know about item i = (read segment seg, contig segment cseg):
 // the caller glue of get_liftover_alignment_for_read_and_contig_segment (src/read_alignment_scanner.rs:146-176) --

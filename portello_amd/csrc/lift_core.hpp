@@ -39,11 +39,13 @@ struct TileMem {
     int capk;
 };
 constexpr int tile_capk(int cap) { return cap / 2; }
-constexpr size_t tile_mem_bytes(int cap) {
-    return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4 + (size_t)tile_capk(cap) * 8;
+// capk < 0: room for cap / 2 staged block-map entries (a tile of many short items); the workgroup-per-item kernel stages
+// the window of ONE item and passes a fixed number (longer windows are read from global memory)
+constexpr size_t tile_mem_bytes(int cap, int capk = -1) {
+    return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4 + (size_t)(capk < 0 ? tile_capk(cap) : capk) * 8;
 }
 
-PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap) {
+PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap, int capk = -1) {
     TileMem m;
     m.A = (uint32_t *)base;
     m.B = m.A + cap;
@@ -57,7 +59,7 @@ PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap) {
     m.itl = m.itf + 64;
     m.its = m.itl + 64;
     m.itp = m.its + 64;
-    m.capk = tile_capk(cap);
+    m.capk = capk < 0 ? tile_capk(cap) : capk;
     m.K = m.itp + 64;
     m.V = m.K + m.capk;
     m.idA = (uint8_t *)(m.V + m.capk);
@@ -126,41 +128,254 @@ PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, in
     return r;
 }
 
+// ---- cooperation of several waves on one tile ----------------------------------------------------------------------
+// Coop<1>: the tile belongs to one wave (k_lift_tiles, k_lift_retry, k_lift_big).  Coop<NW>, NW > 1: the NW waves of a
+// workgroup work on ONE item (k_lift_mid): a pass walks the element stream NW x 64 elements at a time, wave w taking
+// elements [64 w, 64 w + 64) of every step; the scan carries cross the waves through a few LDS words and one workgroup
+// barrier per scan; the item's scalars live in lane 0 of EVERY wave (replicated, kept identical) and reach the elements as
+// scalar broadcasts (v_readfirstlane) instead of cross-lane reads.  Control flow must then be uniform over the whole
+// workgroup wherever a scan, co.sync() or co.any() is called.
+template <int NW>
+struct Coop {
+    static constexpr int STEP = 64 * NW;
+    static constexpr int XCH_INTS = 2 * 4 * NW + 4;  // two exchange buffers of 4 x NW words + 3 rotating flags
+    int w = 0;           // index of the wave inside the workgroup
+    int *xch = nullptr;  // LDS, XCH_INTS words, zeroed before the first use
+    unsigned k = 0, kf = 0;
+
+    PLO_DEV int lo() const { return NW > 1 ? 64 * w : 0; }  // first element of the wave in a step
+    PLO_DEV bool lead() const { return NW == 1 || w == 0; }  // the wave that speaks for the item (global counters, outputs)
+    PLO_DEV void sync() const {
+        if constexpr (NW > 1) wv::block_sync();
+        else wv::sync();
+    }
+    // scalar `v` of item `id`: lane id of the wave holds it (NW == 1); lane 0 of every wave holds the one item's (NW > 1)
+    template <class T>
+    PLO_DEV T item(T v, int id) const {
+        if constexpr (NW > 1) return wv::bcast_first(v);
+        else return wv::shfl(v, id);
+    }
+    PLO_DEV int item(bool v, int id) const { return item((int)v, id); }
+    PLO_DEV int elem_id(const uint8_t *idX, int e, bool valid) const {
+        if constexpr (NW > 1) return 0;
+        else return valid ? (idX[e] & 63) : 0;
+    }
+    // true when `p` holds in any lane of the tile's wave(s)
+    PLO_DEV bool any(bool p) {
+        if constexpr (NW == 1) {
+            return wv::ballot(p) != 0ull;
+        } else {
+            // three flags in rotation: call c uses flag c % 3, the lead wave clears the flag of call c + 1 before the barrier
+            // of call c (its last readers, of call c - 2, have all passed the barrier of call c - 1)
+            int *f = xch + 2 * 4 * NW;
+            const unsigned c = kf++;
+            const bool mine = wv::ballot(p) != 0ull;
+            if (wv::lane() == 0) {
+                if (w == 0) f[(c + 1) % 3] = 0;
+                if (mine) f[c % 3] = 1;
+            }
+            wv::block_sync();
+            return f[c % 3] != 0;
+        }
+    }
+    // Exchange buffers alternate: a wave can write the buffer of call k + 2 only after passing the barrier of call k + 1,
+    // which every wave reaches only after reading the buffer of call k.
+    PLO_DEV int *slot() {
+        int *s_ = xch + (k & 1u) * 4 * NW;
+        ++k;
+        return s_;
+    }
+    // One exchange (one barrier) for NA sums and NM maxima: per value, the total of the waves before this one (`pre`) and of
+    // all waves of the step (`all`).  Every wave leaves its totals in the buffer; after the barrier lane l < NW reads wave l's
+    // and a DPP scan over those lanes gives both numbers with two scalar reads.
+    template <int NA, int NM>
+    PLO_DEV void exch(const int *ta, const int *tm, int *prea, int *alla, int *prem, int *allm) {
+        static_assert(NA + NM <= 4, "an exchange buffer holds four words per wave");
+        int *s_ = slot();
+        const int l = wv::lane();
+        if (l == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) s_[i * NW + w] = ta[i];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) s_[(NA + i) * NW + w] = tm[i];
+        }
+        wv::block_sync();
+        const bool in = l < NW;
+        int va[NA > 0 ? NA : 1], vm[NM > 0 ? NM : 1];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[i] = in ? s_[i * NW + l] : 0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) vm[i] = in ? s_[(NA + i) * NW + l] : (int)0x80000000;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int inc = wv::scan_add(va[i]);
+            alla[i] = wv::read_lane(inc, NW - 1);
+            int p_ = wv::read_lane(inc, w - 1);
+            prea[i] = w ? p_ : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            int inc = wv::scan_max(vm[i]);
+            allm[i] = wv::read_lane(inc, NW - 1);
+            int p_ = wv::read_lane(inc, w - 1);
+            prem[i] = w ? p_ : (int)0x80000000;
+        }
+    }
+    PLO_DEV void exch_add(int tot, int &pre, int &all) { exch<1, 0>(&tot, nullptr, &pre, &all, nullptr, nullptr); }
+    PLO_DEV void exch_max(int tot, int &pre, int &all) { exch<0, 1>(nullptr, &tot, nullptr, nullptr, &pre, &all); }
+    // min-plus functions: `pre` = carry composed with the waves before this one, `all` = carry composed with all waves
+    PLO_DEV void exch_minplus(wv::MinPlus t, wv::MinPlus carry, wv::MinPlus &pre, wv::MinPlus &all) {
+        int *s_ = slot();
+        if (wv::lane() == 0) {
+            s_[w] = t.a;
+            s_[NW + w] = t.b;
+            s_[2 * NW + w] = t.s;
+        }
+        wv::block_sync();
+        wv::MinPlus acc = carry;
+        pre = carry;
+        for (int j = 0; j < NW; ++j) {
+            if (j == w) pre = acc;
+            wv::MinPlus c = {s_[j], s_[NW + j], s_[2 * NW + j]};
+            acc = wv::mp_compose(acc, c);
+        }
+        all = acc;
+    }
+    // value of the previous element: lane - 1, or the last lane of the previous wave / of the previous step (`carry`)
+    PLO_DEV int shift_up1(int v, int &carry) {
+        if constexpr (NW == 1) {
+            int r = wv::shfl_up1(v, carry);
+            carry = wv::bcast_last(v);
+            return r;
+        } else {
+            int last = wv::bcast_last(v);
+            int *s_ = slot();
+            if (wv::lane() == 0) s_[w] = last;
+            wv::block_sync();
+            int first = w ? s_[w - 1] : carry;
+            carry = s_[NW - 1];
+            return wv::shfl_up1(v, first);
+        }
+    }
+    // a value of the lead wave, handed to every wave
+    PLO_DEV unsigned long long from_lead(unsigned long long v) {
+        if constexpr (NW == 1) {
+            return v;
+        } else {
+            int *s_ = slot();
+            if (w == 0 && wv::lane() == 0) {
+                s_[0] = (int)(unsigned)(v & 0xffffffffull);
+                s_[1] = (int)(unsigned)(v >> 32);
+            }
+            wv::block_sync();
+            return ((unsigned long long)(unsigned)s_[1] << 32) | (unsigned)s_[0];
+        }
+    }
+};
+// elements of a pass: `base` runs over the chunks of 64 this wave handles; every wave makes the same number of steps
+#define PLO_CHUNKS(base, n) for (int base = co.lo(); base - co.lo() < (n); base += Coop<NW>::STEP)
+
 // ---- chunked scans with a running carry ---------------------------------------------------------------------------
-struct AddScan {
+template <int NW>
+struct AddScanT {
+    Coop<NW> &co;
     int carry = 0;
+    PLO_DEV explicit AddScanT(Coop<NW> &c) : co(c) {}
     PLO_DEV int incl(int x) {
         int inc = wv::scan_add(x);
-        int r = carry + inc;
-        carry += wv::bcast_last(inc);
+        int tot = wv::bcast_last(inc);
+        int pre = 0, all = tot;
+        if constexpr (NW > 1) co.exch_add(tot, pre, all);
+        int r = carry + pre + inc;
+        carry += all;
         return r;
     }
     PLO_DEV int excl(int x) { return incl(x) - x; }
 };
-struct MaxScan {
+template <int NW>
+struct MaxScanT {
+    Coop<NW> &co;
     int carry;
     int prev_carry;
-    PLO_DEV explicit MaxScan(int init) : carry(init), prev_carry(init) {}
+    PLO_DEV MaxScanT(Coop<NW> &c, int init) : co(c), carry(init), prev_carry(init) {}
     PLO_DEV int incl(int x) {
-        int m = wv::imax(wv::scan_max(x), carry);
-        prev_carry = carry;
-        carry = wv::bcast_last(m);
-        return m;
+        int m = wv::scan_max(x);
+        int tot = wv::bcast_last(m);
+        int pre = (int)0x80000000, all = tot;
+        if constexpr (NW > 1) co.exch_max(tot, pre, all);
+        prev_carry = wv::imax(carry, pre);  // inclusive value just before this wave's first lane
+        carry = wv::imax(carry, all);
+        return wv::imax(m, prev_carry);
     }
     // exclusive value belonging to the last incl() call
     PLO_DEV int excl_of(int incl_value) { return wv::shfl_up1(incl_value, prev_carry); }
 };
 // segmented exclusive sum of non-negative values: plain prefix minus the prefix at the segment head, the latter
-// propagated by a max-scan (prefixes are non-decreasing)
-struct SegSum {
-    AddScan a;
-    MaxScan m{0};
+// propagated by a max-scan (prefixes are non-decreasing).  One item per workgroup: its only head is element 0.
+template <int NW>
+struct SegSumT {
+    AddScanT<NW> a;
+    MaxScanT<NW> m;
+    PLO_DEV explicit SegSumT(Coop<NW> &c) : a(c), m(c, 0) {}
     PLO_DEV int excl(int x, bool head) {
         int p = a.excl(x);
-        int base = m.incl(head ? p : 0);
-        return p - base;
+        if constexpr (NW > 1) {
+            return p;
+        } else {
+            int base = m.incl(head ? p : 0);
+            return p - base;
+        }
     }
 };
+// NA add-scans and NM max-scans of the same step with ONE exchange between the waves (Coop<NW>, NW > 1); for a single wave
+// they are simply independent scans.
+template <int NW, int NA, int NM>
+struct MultiScanT {
+    Coop<NW> &co;
+    int ca[NA > 0 ? NA : 1];
+    int cm[NM > 0 ? NM : 1], pm[NM > 0 ? NM : 1];
+    PLO_DEV MultiScanT(Coop<NW> &c, int max_init) : co(c) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ca[i] = 0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) cm[i] = pm[i] = max_init;
+    }
+    // xa / xm: the lane's inputs; ra / rm: inclusive results
+    PLO_DEV void incl(const int *xa, const int *xm, int *ra, int *rm) {
+        int ia[NA > 0 ? NA : 1], im[NM > 0 ? NM : 1], ta[NA > 0 ? NA : 1], tm[NM > 0 ? NM : 1];
+        int prea[NA > 0 ? NA : 1], alla[NA > 0 ? NA : 1], prem[NM > 0 ? NM : 1], allm[NM > 0 ? NM : 1];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            ia[i] = wv::scan_add(xa[i]);
+            ta[i] = wv::bcast_last(ia[i]);
+            prea[i] = 0;
+            alla[i] = ta[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            im[i] = wv::scan_max(xm[i]);
+            tm[i] = wv::bcast_last(im[i]);
+            prem[i] = (int)0x80000000;
+            allm[i] = tm[i];
+        }
+        if constexpr (NW > 1) co.template exch<NA, NM>(ta, tm, prea, alla, prem, allm);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            ra[i] = ca[i] + prea[i] + ia[i];
+            ca[i] += alla[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            pm[i] = wv::imax(cm[i], prem[i]);
+            cm[i] = wv::imax(cm[i], allm[i]);
+            rm[i] = wv::imax(im[i], pm[i]);
+        }
+    }
+    PLO_DEV int excl_of(int k, int incl_value) { return wv::shfl_up1(incl_value, pm[k]); }
+};
+
+using AddScan = AddScanT<1>;
+using MaxScan = MaxScanT<1>;
 
 // appends one op of item `id` at Y[p] when `on` (p advances): the emission passes write up to four ops per element this way
 PLO_DEV void put_op(uint32_t *Y, uint8_t *idY, int &p, bool on, uint32_t v, int id) {
@@ -190,7 +405,8 @@ PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
 // Returns the leading-deletion shift of the lane's item in `shift`, and in `indel_pairs` (wave-uniform) whether some
 // active item's output has two neighbouring I/D ops, i.e. an indel cluster of more than one op.
 // -------------------------------------------------------------------------------------------------------------------
-PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
+template <int NW>
+PLO_DEV void cleanup_compress(Coop<NW> &co, TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
                               bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false, int *read_len = nullptr) {
     // read_len (optional, [64] in LDS): per item, the read bases its CIGAR consumes -- the edge clean-up and the merge do not
     // change that sum, so it is taken from the raw ops on the way (saves the length check its own pass)
@@ -201,23 +417,42 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
         m.itl[lane] = -1;
     }
     m.its[lane] = 0;
-    wv::sync();
+    co.sync();
     // pass 1: first / last alignment-match element of every item (the edges are everything outside them); a producer that
     // knows where it puts its match ops publishes m.itf / m.itl itself (edges_known) and only the run sums are zeroed
     if (edges_known) {
-        for (int base = 0; base < n; base += 64) {
+        PLO_CHUNKS(base, n) {
             int e = base + lane;
             if (e < n) Y[e] = 0;
         }
+    } else if constexpr (NW > 1) {  // one item: its first / last match are a minimum and a maximum, no scan (no exchange)
+        const int i_act = co.item((int)active, 0);
+        int fmin = IMAX, lmax = -1;
+        PLO_CHUNKS(base, n) {
+            int e = base + lane;
+            if (e < n) {
+                if (i_act && is_match(op_type(X[e]))) {
+                    fmin = wv::imin(fmin, e);
+                    lmax = e;  // a lane's elements come in increasing order
+                }
+                Y[e] = 0;
+            }
+        }
+        fmin = -wv::reduce_max(-fmin);
+        lmax = wv::reduce_max(lmax);
+        if (lane == 0) {
+            wv::atomic_min(&m.itf[0], fmin);
+            wv::atomic_max(&m.itl[0], lmax);
+        }
     } else {
-        MaxScan lastm(-1);
-        for (int base = 0; base < n; base += 64) {
+        MaxScanT<NW> lastm(co, -1);
+        PLO_CHUNKS(base, n) {
             int e = base + lane;
             bool valid = e < n;
-            int id = valid ? (idX[e] & 63) : 0;
-            int i_s = wv::shfl(s, id);
-            int i_c = wv::shfl(c, id);
-            int i_act = wv::shfl((int)active, id);
+            int id = co.elem_id(idX, e, valid);
+            int i_s = co.item(s, id);
+            int i_c = co.item(c, id);
+            int i_act = co.item((int)active, id);
             bool ism = valid && i_act && is_match(op_type(X[e]));
             int li = lastm.incl(ism ? e : -1);
             int le = lastm.excl_of(li);
@@ -226,29 +461,35 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             if (valid) Y[e] = 0;  // run sums of pass 2 start from zero
         }
     }
-    wv::sync();
+    co.sync();
     // pass 2: edge I -> S(len), edge D -> S(0) (+ leading D lengths summed into the position shift), applied on the fly;
     // then drop zero-length ops and merge equal neighbours (head flags + run sums)
     {
-        MaxScan lasta(-1);
-        AddScan heads;
+        MaxScanT<NW> lasta(co, -1);
+        AddScanT<NW> heads(co);
         bool pairs = false;
-        for (int base = 0; base < n; base += 64) {
+        int rl_acc = 0, shift_acc = 0;  // NW > 1: per-lane sums of the one item, one LDS atomic per wave at the end
+        PLO_CHUNKS(base, n) {
             int e = base + lane;
             bool valid = e < n;
-            int id = valid ? (idX[e] & 63) : 0;
-            int i_s = wv::shfl(s, id);
-            int i_act = wv::shfl((int)active, id);
+            int id = co.elem_id(idX, e, valid);
+            int i_s = co.item(s, id);
+            int i_act = co.item((int)active, id);
             uint32_t cc = valid ? X[e] : 0;
             int t = op_type(cc), L = op_len(cc);
-            if (read_len && valid && read_consuming(t) && L > 0) wv::atomic_add(&read_len[id], L);
+            if constexpr (NW > 1) {
+                if (valid && read_consuming(t)) rl_acc += L;
+            } else {
+                if (read_len && valid && read_consuming(t) && L > 0) wv::atomic_add(&read_len[id], L);
+            }
             int f = IMAX, l = -1;
             if (valid && i_act) {
                 f = m.itf[id];
                 l = m.itl[id];
                 if (e < f || e > l) {  // clean_up_cigar_edge_indels (:265-291)
                     if (t == OP_D) {
-                        if (e < f) wv::atomic_add(&m.its[id], L);
+                        if constexpr (NW > 1) shift_acc += e < f ? L : 0;
+                        else if (e < f) wv::atomic_add(&m.its[id], L);
                         t = OP_S;
                         L = 0;
                     } else if (t == OP_I) {
@@ -288,15 +529,23 @@ PLO_DEV void cleanup_compress(TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y
             if (valid) m.T0[e] = hi;
         }
         n_out = heads.carry;
-        indel_pairs = wv::ballot(pairs) != 0ull;
+        if constexpr (NW > 1) {
+            rl_acc = wv::reduce_add(rl_acc);
+            shift_acc = wv::reduce_add(shift_acc);
+            if (lane == 0) {
+                if (read_len && rl_acc) wv::atomic_add(&read_len[0], rl_acc);
+                if (shift_acc) wv::atomic_add(&m.its[0], shift_acc);
+            }
+        }
+        indel_pairs = co.any(pairs);
     }
-    wv::sync();
+    co.sync();
     int ns, nc;
     finish_counts(m.T0, s, c, ns, nc);
     shift = m.its[lane];
     s = ns;
     c = nc;
-    wv::sync();
+    co.sync();
 }
 
 // ---- sequence comparison ------------------------------------------------------------------------------------------
@@ -507,8 +756,11 @@ struct TilePre {
     uint32_t g = 0, in_off = 0, n_in = 0, w0 = 0, w1 = 0, kv1 = 0, fl = 0;
 };
 
-PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
+template <int NW>
+PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
                        int nit, TileMem m, const uint32_t *list, int level, int big_thresh, WaveCtx &ctx, const TilePre *pre = nullptr) {
+    // NW > 1 (k_lift_mid): nit == 1, every wave of the workgroup runs this function on the same item; lane 0 of every wave
+    // carries the item's scalars (kept identical), the lead wave alone touches global counters and the per-item outputs
     // level: LEVEL_TILE (shared tile; a tile that overflows its capacity re-queues its items on the retry list),
     // LEVEL_RETRY (few items, larger capacity; overflow -> large-item list), LEVEL_LAST (one item, global scratch)
     const bool last_resort = level == LEVEL_LAST;
@@ -564,19 +816,24 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
         do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
     }
-    // items too long for a shared tile go to the large-item kernel (one item per wave, global scratch)
+    // Items too heavy for this level are handed on: from a shared tile to the workgroup-per-item kernel (big_list), from
+    // there to the one-wave-per-item kernel that works in global scratch (huge_list)
+    uint32_t *const next_list = level == LEVEL_MID ? wk.huge_list : wk.big_list;
+    const int next_cnt = level == LEVEL_MID ? CNT_NHUGE : CNT_NBIG;
     {
         bool defer = has && !last_resort && item_weight(n_in, W0, W1, kv1) > big_thresh;
         unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int nd = __builtin_popcountll(dm);
             int slot = 0;
-            if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NBIG], (unsigned long long)nd);
+            if (lane == 0 && co.lead()) slot = (int)wv::atomic_add_global(&wk.counters[next_cnt], (unsigned long long)nd);
             slot = wv::bcast_first(slot);
             if (defer) {
                 int rank = __builtin_popcountll(dm & ((1ull << lane) - 1ull));
-                wk.big_list[slot + rank] = g;
-                wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+                if (co.lead()) {
+                    next_list[slot + rank] = g;
+                    wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+                }
                 has = false;
                 n_in = 0;
             }
@@ -601,24 +858,33 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     const int nkT = wv::bcast_last(inck);
     const bool staged = nkT <= m.capk;
     int *const srcK = (int *)m.B;
-    if (staged && nkT > 0) {
-        for (int base = 0; base < nkT; base += 64) {
+    if constexpr (NW > 1) {  // one item: entry j of the staged window is entry W0 + j of the map, no owner search
+        if (staged && nkT > 0) {
+            const int i_w0 = co.item(W0, 0);
+            PLO_CHUNKS(base, nkT) {
+                int j = base + lane;
+                if (j < nkT) srcK[j] = i_w0 + j;
+            }
+            co.sync();
+        }
+    } else if (staged && nkT > 0) {
+        PLO_CHUNKS(base, nkT) {
             int j = base + lane;
             if (j < nkT) m.T3[j] = 0;
         }
-        wv::sync();
+        co.sync();
         if (nk_all > 0) m.T3[kb] = lane + 1;
-        wv::sync();
-        MaxScan owner(0);
-        for (int base = 0; base < nkT; base += 64) {
+        co.sync();
+        MaxScanT<NW> owner(co, 0);
+        PLO_CHUNKS(base, nkT) {
             int j = base + lane;
             bool valid = j < nkT;
             int id = owner.incl(valid ? m.T3[j] : 0) - 1;
             if (id < 0) id = 0;
-            int i_w0 = wv::shfl(W0, id), i_kb = wv::shfl(kb, id);
+            int i_w0 = co.item(W0, id), i_kb = co.item(kb, id);
             if (valid) srcK[j] = i_w0 + (j - i_kb);
         }
-        wv::sync();
+        co.sync();
     }
     PLO_T(0)
     // ---- LOAD: flattened op stream of the tile (reversed for reverse-mapped contig segments, :167) --------------
@@ -629,21 +895,33 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     if (nA > m.cap) overflow = true;
     m.itp[lane] = 0;
     if (!overflow) {
-        for (int base = 0; base < nA; base += 64) {
+        if constexpr (NW > 1) {  // one item: every element is its
+            const int i_off = co.item(in_off, 0), i_n = co.item(n_in, 0), i_rev = co.item((int)rev, 0);
+            PLO_CHUNKS(base, nA) {
+                int e = base + lane;
+                if (e < nA) {
+                    m.T0[e] = i_off + (i_rev ? (i_n - 1 - e) : e);
+                    m.idA[e] = 0;
+                    m.T3[e] = 0;
+                    m.T4[e] = 0;
+                }
+            }
+        } else {
+        PLO_CHUNKS(base, nA) {
             int e = base + lane;
             if (e < nA) m.T3[e] = 0;
         }
-        wv::sync();
+        co.sync();
         if (has && cA > 0) m.T3[sA] = lane + 1;
-        wv::sync();
-        MaxScan owner(0);
-        for (int base = 0; base < nA; base += 64) {
+        co.sync();
+        MaxScanT<NW> owner(co, 0);
+        PLO_CHUNKS(base, nA) {
             int e = base + lane;
             bool valid = e < nA;
             int id = owner.incl(valid ? m.T3[e] : 0) - 1;
             if (id < 0) id = 0;
-            int i_off = wv::shfl(in_off, id), i_n = wv::shfl(n_in, id), i_s = wv::shfl(sA, id);
-            int i_rev = wv::shfl((int)rev, id);
+            int i_off = co.item(in_off, id), i_n = co.item(n_in, id), i_s = co.item(sA, id);
+            int i_rev = co.item((int)rev, id);
             if (valid) {
                 int k = e - i_s;
                 m.T0[e] = i_off + (i_rev ? (i_n - 1 - k) : k);  // source op of the element
@@ -652,11 +930,13 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 m.T4[e] = 0;
             }
         }
+        }
         // the gather carries no cross-lane dependency: the loads of four chunks are in flight together (indices first,
         // then all loads, then all stores -- written out because the compiler must assume that m.A aliases m.T0 and
         // would otherwise finish every chunk's store before the next chunk's index read)
         const int nkS = staged ? nkT : 0;  // block-map entries to stage
-        for (int base = 0; base < nA || base < nkS; base += 256) {
+        if constexpr (NW > 1) co.sync();  // the gather below cuts the elements differently (256 per wave and step)
+        for (int base = 4 * co.lo(); base - 4 * co.lo() < nA || base - 4 * co.lo() < nkS; base += 4 * Coop<NW>::STEP) {
             int src[4], ksrc[4];
             uint32_t v[4];
             KV kvv[4];
@@ -683,7 +963,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
             }
         }
-        wv::sync();
+        co.sync();
     }
 
     PLO_T(1)
@@ -694,15 +974,17 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         int nH = 0;
         int *const heads_list = (int *)m.B;
         {
-            SegSum sr, sq, sm;
-            MaxScan pnz(-1), heads(-1);
-            AddScan hcount;
-            for (int base = 0; base < nA; base += 64) {
+            SegSumT<NW> sr(co), sq(co), sm(co);
+            MaxScanT<NW> pnz(co, -1), heads(co, -1);
+            AddScanT<NW> hcount(co);
+            MultiScanT<NW, 3, 1> grp1(co, -1);  // NW > 1: the scans of a step that do not depend on each other share one exchange
+            MultiScanT<NW, 1, 1> grp2(co, -1);
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 bool valid = e < nA;
                 uint32_t c = valid ? m.A[e] : 0;
-                int id = valid ? (m.idA[e] & 63) : 0;
-                int i_do = wv::shfl((int)do_shift, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
+                int id = co.elem_id(m.idA, e, valid);
+                int i_do = co.item((int)do_shift, id), i_s = co.item(sA, id), i_pos = co.item(pos1, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_do;
                 bool isC = on && is_indel(t) && L > 0;       // cluster member      (:73-85: len > 0 only)
@@ -710,11 +992,23 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 bool isM = on && is_match(t);
                 bool isO = on && !is_indel(t) && !isM;
                 bool ihead = valid && e == i_s;
-                int R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
-                int Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
-                int PM = sm.excl(isM ? L : 0, ihead);
-                int pi = pnz.incl((valid && !isZ) ? e : -1);
-                int pp = pnz.excl_of(pi);
+                int R, Q, PM, pp;
+                if constexpr (NW > 1) {
+                    const int xa[3] = {(on && ref_consuming(t)) ? L : 0, (on && read_consuming(t)) ? L : 0, isM ? L : 0};
+                    const int xm[1] = {(valid && !isZ) ? e : -1};
+                    int ra[3], rm[1];
+                    grp1.incl(xa, xm, ra, rm);
+                    R = ra[0] - xa[0];
+                    Q = ra[1] - xa[1];
+                    PM = ra[2] - xa[2];
+                    pp = grp1.excl_of(0, rm[0]);
+                } else {
+                    R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
+                    Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
+                    PM = sm.excl(isM ? L : 0, ihead);
+                    int pi = pnz.incl((valid && !isZ) ? e : -1);
+                    pp = pnz.excl_of(pi);
+                }
                 bool prevC = false;
                 if (on && pp >= i_s) {
                     uint32_t pc = m.A[pp];
@@ -722,8 +1016,17 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
                 bool chead = isC && !prevC;
                 bool event = chead || isO;
-                int hidx = heads.incl(chead ? e : -1);
-                int hrank = hcount.excl(chead ? 1 : 0);
+                int hidx, hrank;
+                if constexpr (NW > 1) {
+                    const int xa[1] = {chead ? 1 : 0}, xm[1] = {chead ? e : -1};
+                    int ra[1], rm[1];
+                    grp2.incl(xa, xm, ra, rm);
+                    hidx = rm[0];
+                    hrank = ra[0] - xa[0];
+                } else {
+                    hidx = heads.incl(chead ? e : -1);
+                    hrank = hcount.excl(chead ? 1 : 0);
+                }
                 if (chead) heads_list[hrank] = e;  // compact list of cluster heads (hrank < nA <= cap)
                 if (valid) {
                     m.T0[e] = i_pos + R;  // indel_block_ref_start
@@ -733,20 +1036,20 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
                 }
             }
-            nH = hcount.carry;
+            nH = NW > 1 ? grp2.ca[0] : hcount.carry;
         }
-        overflow = wv::ballot(overflow) != 0ull;
-        wv::sync();
+        overflow = co.any(overflow);
+        co.sync();
         PLO_T(1)
         // pass H: one lane per indel cluster (all clusters of the tile at once): left breakend homology.  This is
         // the only part of the shift that touches the sequences, so the HBM round trips are paid once per tile.
-        for (int base = 0; base < nH && !overflow; base += 64) {
+        if (!overflow) PLO_CHUNKS(base, nH) {
             int hl = base + lane;
             bool valid = hl < nH;
             int e = valid ? heads_list[hl] : 0;
-            int id = m.idA[e] & 63;
-            int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(shift_ref_len, id);
-            unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(shift_ref, id);
+            int id = co.elem_id(m.idA, e, true);
+            int i_flip = co.item((int)flip, id), i_slen = co.item(seq_len, id), i_rlen = co.item(shift_ref_len, id);
+            unsigned long long i_soff = co.item(seq_off, id), i_ref = co.item(shift_ref, id);
             if (valid) {
                 bool panic = false;
                 int probes = 0;
@@ -758,23 +1061,22 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 m.T1[e] = h;  // the read start is not needed any more: the head's slot carries the homology to pass B
             }
         }
-        wv::sync();
+        co.sync();
         PLO_T(10)
         // pass B: homology, carried match run (min-plus scan), emission
         int nB = 0;
         {
-            MaxScan ev(-1);
-            AddScan emit;
+            MaxScanT<NW> ev(co, -1);
+            AddScanT<NW> emit(co);
             wv::MinPlus carryF = {0, IMAX, 0};
-            int carry_r = 0;
-            for (int base = 0; base < nA; base += 64) {
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 bool valid = e < nA;
                 uint32_t c = valid ? m.A[e] : 0;
                 int idf = valid ? m.idA[e] : 0;
                 int id = idf & 63;
                 bool chead = (idf & 64) != 0, event = (idf & 128) != 0;
-                int i_do = wv::shfl((int)do_shift, id), i_s = wv::shfl(sA, id), i_c = wv::shfl(cA, id);
+                int i_do = co.item((int)do_shift, id), i_s = co.item(sA, id), i_c = co.item(cA, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_do;
                 int li = ev.incl((on && event) ? e : -1);
@@ -799,11 +1101,13 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     f.s = have_prev ? 0 : 1;
                 }
                 wv::MinPlus F = wv::scan_minplus(f);
-                F = wv::mp_compose(carryF, F);
+                wv::MinPlus Fpre = carryF, Fall = carryF;  // carried function before this wave's first lane / after the step
+                if constexpr (NW > 1) co.exch_minplus(wv::bcast_last(F), carryF, Fpre, Fall);
+                F = wv::mp_compose(Fpre, F);
                 int r_after = wv::imin(F.a, F.b);
-                int r_excl = wv::shfl_up1(r_after, carry_r);
-                carryF = wv::bcast_last(F);
-                carry_r = wv::bcast_last(r_after);
+                int r_excl = wv::shfl_up1(r_after, wv::imin(Fpre.a, Fpre.b));  // match run carried out of the previous element
+                if constexpr (NW > 1) carryF = Fall;
+                else carryF = wv::bcast_last(F);
                 int r_before = have_prev ? r_excl : 0;
                 int x = r_before + m_e;
                 // Up to four ops per element, as flags + values (no indexed local array: that would live in scratch):
@@ -841,16 +1145,16 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             nB = emit.carry;
         }
-        overflow = wv::ballot(overflow) != 0ull;
-        wv::sync();
+        overflow = co.any(overflow);
+        co.sync();
         PLO_T(11)
         if (!overflow) {
             int sB, cB;
             finish_counts(m.T0, sA, cA, sB, cB);
-            wv::sync();
+            co.sync();
             int shift = 0, nOut = 0;
             bool pairs_;
-            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, has && do_shift, shift, nOut, pairs_);
+            cleanup_compress(co, m, m.B, m.idB, m.A, m.idA, nB, sB, cB, has && do_shift, shift, nOut, pairs_);
             sA = sB;
             cA = cB;
             nA = nOut;
@@ -873,7 +1177,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         if (alive) {
             int nb = kv1 - kv0, lg = 0;
             while ((1 << lg) < nb) ++lg;
-            algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
+            if (co.lead()) algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
         } else {
             W1 = W0;
         }
@@ -883,15 +1187,15 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         int P = 0;
         auto pass_a = [&](auto staged_c) {
             constexpr bool STAGED = decltype(staged_c)::value;
-            SegSum sr;
-            AddScan pieces;
-            for (int base = 0; base < nA; base += 64) {
+            SegSumT<NW> sr(co);
+            AddScanT<NW> pieces(co);
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 bool valid = e < nA;
                 uint32_t c = valid ? m.A[e] : 0;
-                int id = valid ? (m.idA[e] & 63) : 0;
-                int i_alive = wv::shfl((int)alive, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
-                int i_w0 = wv::shfl(W0, id), i_w1 = wv::shfl(W1, id), i_kb = wv::shfl(kb, id);
+                int id = co.elem_id(m.idA, e, valid);
+                int i_alive = co.item((int)alive, id), i_s = co.item(sA, id), i_pos = co.item(pos1, id);
+                int i_w0 = co.item(W0, id), i_w1 = co.item(W1, id), i_kb = co.item(kb, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_alive;
                 bool rc = ref_consuming(t);
@@ -935,7 +1239,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         PLO_T(3)
         if (P > m.cap) overflow = true;
         if (!overflow) {
-            for (int base = 0; base < P; base += 64) {
+            PLO_CHUNKS(base, P) {
                 int j = base + lane;
                 if (j < P) m.T3[j] = 0;
             }
@@ -943,26 +1247,28 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             m.itc[lane] = 0;
             m.itf[lane] = IMAX;    // first / last match op of the item's lifted CIGAR, published by pass B for the clean-up
             m.itl[lane] = -1;
-            wv::sync();
-            for (int base = 0; base < nA; base += 64) {
+            co.sync();
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 if (e < nA && m.T2[e] >= 0) m.T3[m.T2[e]] = e + 1;
             }
-            wv::sync();
+            co.sync();
             // pass B: one lane per piece (update_ref2_cigar_segment, :35-133)
             int nB = 0;
             auto pass_b = [&](auto staged_c) {
                 constexpr bool STAGED = decltype(staged_c)::value;
-                MaxScan owner(0), lastmap(-1), lastfm(-1);
-                AddScan emit;
-                for (int base = 0; base < P; base += 64) {
+                MaxScanT<NW> owner(co, 0), lastmap(co, -1), lastfm(co, -1);
+                AddScanT<NW> emit(co);
+                MultiScanT<NW, 0, 2> grp(co, NONE32);
+                int last_fm = -1;  // NW > 1: the lane's last match piece position (one reduction instead of an atomic per piece)
+                PLO_CHUNKS(base, P) {
                     int j = base + lane;
                     bool valid = j < P;
                     int i = owner.incl(valid ? m.T3[j] : 0) - 1;
                     if (i < 0) i = 0;
                     uint32_t c = valid ? m.A[i] : 0;
-                    int id = valid ? (m.idA[i] & 63) : 0;
-                    int i_w0 = wv::shfl(W0, id), i_kv1 = wv::shfl(kv1, id), i_kb = wv::shfl(kb, id);
+                    int id = co.elem_id(m.idA, i, valid);
+                    int i_w0 = co.item(W0, id), i_kv1 = co.item(kv1, id), i_kb = co.item(kb, id);
                     int t = op_type(c), L = op_len(c);
                     bool piece = valid && ref_consuming(t);
                     bool ism = is_match(t);
@@ -997,18 +1303,38 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                             startval = val + (pstart - bkey);  // :84-88
                         }
                     }
+                    // at most two ops per piece, as flags + values (no indexed local array: that would live in scratch)
+                    bool e0 = false, started = false, started_before = false;  // e0: the jump deletion of :91-96
+                    uint32_t v0 = 0;
+                    if constexpr (NW > 1) {
+                        // One item: "the previous mapped piece" needs no owner test, and its end (ref2_end_pos) is the running
+                        // maximum of the ends -- reference positions never decrease along a block map built from a CIGAR -- so
+                        // it comes out of the scan itself instead of an LDS hand-off between the waves.
+                        const int xm[2] = {mapped ? endval : NONE32, fm ? j : NONE32};
+                        int rm[2];
+                        grp.incl(nullptr, xm, nullptr, rm);
+                        const int prev_end = grp.excl_of(0, rm[0]);
+                        const int fi = rm[1], fe = grp.excl_of(1, rm[1]);
+                        if (mapped) {
+                            started = fi >= 0;
+                            started_before = fe >= 0;
+                            if (fm && !started_before) m.its[id] = startval;
+                            if (prev_end != NONE32) {  // :91-96
+                                int d = val - prev_end;
+                                e0 = d > 0 && started;
+                                v0 = mk_op(OP_D, d);
+                            }
+                        }
+                    } else {
                     if (valid) {
                         m.T3[j] = id | (mapped ? 256 : 0);
                         m.T4[j] = endval;
                     }
-                    wv::sync();
+                    co.sync();
                     int mi = lastmap.incl(mapped ? j : -1);
                     int pmap = lastmap.excl_of(mi);
                     int fi = lastfm.incl(fm ? j : -1);
                     int fe = lastfm.excl_of(fi);
-                    // at most two ops per piece, as flags + values (no indexed local array: that would live in scratch)
-                    bool e0 = false, started = false, started_before = false;  // e0: the jump deletion of :91-96
-                    uint32_t v0 = 0;
                     if (mapped) {
                         bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
                         started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
@@ -1019,6 +1345,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                             e0 = d > 0 && started;
                             v0 = mk_op(OP_D, d);
                         }
+                    }
                     }
                     // copied op | mapped piece (:102-109) | insertion over an unmapped block (:111-115) | soft clip before the
                     // first block (:117-123)
@@ -1034,32 +1361,42 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         if (fm) {  // the only match ops of the output are the mapped match pieces: position p (+1 after a jump D)
                             int pm = p + (e0 ? 1 : 0);
                             if (!started_before) m.itf[id] = pm;  // single writer, like m.its
-                            wv::atomic_max(&m.itl[id], pm);
+                            if constexpr (NW > 1) last_fm = pm;  // positions grow with j
+                            else wv::atomic_max(&m.itl[id], pm);
                         }
                         put_op(m.B, m.idB, p, e0, v0, id);
                         put_op(m.B, m.idB, p, e1, v1, id);
                     }
-                    if (ne > 0) wv::atomic_add(&m.itc[id], ne);
+                    if constexpr (NW == 1) {
+                        if (ne > 0) wv::atomic_add(&m.itc[id], ne);
+                    }
                 }
                 nB = emit.carry;
+                if constexpr (NW > 1) {  // one item: its op count is the total, its last match piece one maximum per wave
+                    int lm = wv::reduce_max(last_fm);
+                    if (lane == 0) {
+                        if (lm >= 0) wv::atomic_max(&m.itl[0], lm);
+                        m.itc[0] = nB;
+                    }
+                }
             };
             if (staged) pass_b(std::true_type{});
             else pass_b(std::false_type{});
-            overflow = wv::ballot(overflow) != 0ull;
-            wv::sync();
+            overflow = co.any(overflow);
+            co.sync();
             PLO_T(4)
             if (!overflow) {
                 int cB = m.itc[lane];
                 int incB = wv::scan_add(cB);
                 int sB = incB - cB;
                 int r2s = m.its[lane];
-                wv::sync();
+                co.sync();
                 if (alive && r2s == NONE32) {  // :218 ref2_start_pos.map(...) on None
                     status = PLO_ITEM_NO_LIFTOVER;
                     alive = false;
                 }
                 int shift = 0, nOut = 0;
-                cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true, m.itc);  // :219-220
+                cleanup_compress(co, m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true, m.itc);  // :219-220
                 have_read_len = true;
                 sA = sB;
                 cA = cB;
@@ -1080,18 +1417,18 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             simp = false;
         }
     } else if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
-        AddScan rs;
-        for (int base = 0; base < nA; base += 64) {
+        AddScanT<NW> rs(co);
+        PLO_CHUNKS(base, nA) {
             int e = base + lane;
             bool valid = e < nA;
             uint32_t c = valid ? m.A[e] : 0;
             int r = rs.incl((valid && read_consuming(op_type(c))) ? op_len(c) : 0);
             if (valid) m.T0[e] = r;
         }
-        wv::sync();
+        co.sync();
         int ns, rl;
         finish_counts(m.T0, sA, cA, ns, rl);
-        wv::sync();
+        co.sync();
         if (alive) {
             if (seq_len != rl) {
                 status = PLO_ITEM_LEN_MISMATCH;
@@ -1106,41 +1443,65 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // simplify_alignment_indels is the identity unless some cluster has more than one op: end_indel re-emits a single
     // I or D unchanged (:41-44) and :153-155 change nothing.  Such tiles skip the stage.
     if (!overflow && (stages & PLO_STAGE_SIMPLIFY) && !((stages & PLO_STAGE_LIFTOVER) && !lifted_pairs)) {
-        for (int base = 0; base < nA; base += 64) {  // cluster sums start from zero
+        PLO_CHUNKS(base, nA) {  // cluster sums start from zero
             int e = base + lane;
             if (e < nA) {
                 m.T3[e] = 0;
                 m.T4[e] = 0;
             }
         }
-        wv::sync();
+        co.sync();
         // pass A: clusters = maximal runs of I/D ops; sums at the cluster head; compact list of cluster heads
         int nH = 0;
         int *const heads_list = (int *)m.B;
         bool changes = false;  // some cluster is not a single I/D op of non-zero length
         {
-            SegSum sr, sq;
-            MaxScan heads(-1);
-            AddScan hcount;
+            SegSumT<NW> sr(co), sq(co);
+            MaxScanT<NW> heads(co, -1);
+            AddScanT<NW> hcount(co);
             int carry_c = 0;
-            for (int base = 0; base < nA; base += 64) {
+            MultiScanT<NW, 2, 1> grp1(co, -1);
+            MultiScanT<NW, 1, 1> grp2(co, -1);
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 bool valid = e < nA;
                 uint32_t c = valid ? m.A[e] : 0;
-                int id = valid ? (m.idA[e] & 63) : 0;
-                int i_on = wv::shfl((int)simp, id), i_s = wv::shfl(sA, id), i_pos = wv::shfl(pos1, id);
+                int id = co.elem_id(m.idA, e, valid);
+                int i_on = co.item((int)simp, id), i_s = co.item(sA, id), i_pos = co.item(pos1, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_on;
                 bool isC = on && is_indel(t);
                 bool ihead = valid && e == i_s;
-                int R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
-                int Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
-                int prevC = wv::shfl_up1((int)isC, carry_c);
-                carry_c = wv::bcast_last((int)isC);
+                int R, Q, prevC;
+                if constexpr (NW > 1) {
+                    // "the previous element is a cluster member" as a max-scan (index of the last member before this element),
+                    // so that it shares the exchange of the two position sums
+                    const int xa[2] = {(on && ref_consuming(t)) ? L : 0, (on && read_consuming(t)) ? L : 0};
+                    const int xm[1] = {isC ? e : -1};
+                    int ra[2], rm[1];
+                    grp1.incl(xa, xm, ra, rm);
+                    R = ra[0] - xa[0];
+                    Q = ra[1] - xa[1];
+                    const int lastC = grp1.excl_of(0, rm[0]);  // (a cross-lane read: outside the short-circuit below)
+                    prevC = (e > 0 && lastC == e - 1) ? 1 : 0;
+                } else {
+                    R = sr.excl((on && ref_consuming(t)) ? L : 0, ihead);
+                    Q = sq.excl((on && read_consuming(t)) ? L : 0, ihead);
+                    prevC = co.shift_up1((int)isC, carry_c);
+                }
                 bool chead = isC && !(prevC && !ihead);
                 changes |= isC && (!chead || L == 0);
-                int hidx = heads.incl(chead ? e : -1);
-                int hrank = hcount.excl(chead ? 1 : 0);
+                int hidx, hrank;
+                if constexpr (NW > 1) {
+                    const int xa[1] = {chead ? 1 : 0}, xm[1] = {chead ? e : -1};
+                    int ra[1], rm[1];
+                    grp2.incl(xa, xm, ra, rm);
+                    hidx = rm[0];
+                    hrank = ra[0] - xa[0];
+                } else {
+                    hidx = heads.incl(chead ? e : -1);
+                    hrank = hcount.excl(chead ? 1 : 0);
+                }
                 if (chead) heads_list[hrank] = e;
                 if (valid) {
                     m.T0[e] = i_pos + R;  // block_ref_start
@@ -1149,22 +1510,22 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (isC) wv::atomic_add(t == OP_D ? &m.T3[hidx] : &m.T4[hidx], L);
                 }
             }
-            nH = hcount.carry;
+            nH = NW > 1 ? grp2.ca[0] : hcount.carry;
         }
-        overflow = wv::ballot(overflow) != 0ull;
-        wv::sync();
+        overflow = co.any(overflow);
+        co.sync();
         // (same test on the clusters themselves: complex clusters of items that take no part do not count)
-        const bool identity = (stages & PLO_STAGE_LIFTOVER) && wv::ballot(changes) == 0ull;
+        const bool identity = (stages & PLO_STAGE_LIFTOVER) && !co.any(changes);
         if (!identity) {
         // pass H: one lane per cluster; only complex clusters (both I and D, not 1/1) look at the sequences
         // (CigarBlockInfo::end_indel :49-105).  Results overwrite the head's slots: T0 pre, T1 post, T3 del, T4 ins.
-        for (int base = 0; base < nH && !overflow; base += 64) {
+        if (!overflow) PLO_CHUNKS(base, nH) {
             int hl = base + lane;
             bool valid = hl < nH;
             int e = valid ? heads_list[hl] : 0;
-            int id = m.idA[e] & 63;
-            int i_flip = wv::shfl((int)flip, id), i_slen = wv::shfl(seq_len, id), i_rlen = wv::shfl(chrom_ref_len, id);
-            unsigned long long i_soff = wv::shfl(seq_off, id), i_ref = wv::shfl(chrom_ref, id);
+            int id = co.elem_id(m.idA, e, true);
+            int i_flip = co.item((int)flip, id), i_slen = co.item(seq_len, id), i_rlen = co.item(chrom_ref_len, id);
+            unsigned long long i_soff = co.item(seq_off, id), i_ref = co.item(chrom_ref, id);
             if (valid) {
                 int del = m.T3[e], ins = m.T4[e];
                 int complex_done = 0;
@@ -1199,19 +1560,19 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 m.T2[e] = complex_done;
             }
         }
-        wv::sync();
+        co.sync();
         // pass B: emission
         int nB = 0;
         {
-            AddScan emit;
-            for (int base = 0; base < nA; base += 64) {
+            AddScanT<NW> emit(co);
+            PLO_CHUNKS(base, nA) {
                 int e = base + lane;
                 bool valid = e < nA;
                 uint32_t c = valid ? m.A[e] : 0;
                 int idf = valid ? m.idA[e] : 0;
                 int id = idf & 63;
                 bool chead = (idf & 64) != 0;
-                int i_on = wv::shfl((int)simp, id);
+                int i_on = co.item((int)simp, id);
                 int t = op_type(c);
                 bool on = valid && i_on;
                 // up to four ops per element, as flags + values (no indexed local array: that would live in scratch)
@@ -1254,16 +1615,16 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             nB = emit.carry;
         }
-        overflow = wv::ballot(overflow) != 0ull;
-        wv::sync();
+        overflow = co.any(overflow);
+        co.sync();
         PLO_T(7)
         if (!overflow) {
             int sB, cB;
             finish_counts(m.T2, sA, cA, sB, cB);
-            wv::sync();
+            co.sync();
             int shift = 0, nOut = 0;
             bool pairs_;
-            cleanup_compress(m, m.B, m.idB, m.A, m.idA, nB, sB, cB, simp, shift, nOut, pairs_);  // :153-154
+            cleanup_compress(co, m, m.B, m.idB, m.A, m.idA, nB, sB, cB, simp, shift, nOut, pairs_);  // :153-154
             sA = sB;
             cA = cB;
             nA = nOut;
@@ -1278,7 +1639,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 
     PLO_T(8)
     // ---- OUTPUT --------------------------------------------------------------------------------------------------------------
-    overflow = wv::ballot(overflow) != 0ull;
+    overflow = co.any(overflow);
     if (overflow) {
         if (last_resort) {
             if (has) {
@@ -1288,18 +1649,18 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 wk.pos[g] = -1;
             }
             if (lane == 0) wv::atomic_add_global(&wk.counters[CNT_ERROR], 1ull);
-        } else {
+        } else if (co.lead()) {
             // capacity exceeded: re-queue every item -- of a shared tile on the retry list (few items per wave, larger
-            // capacity), of a retry group on the large-item list (one item per wave, global scratch)
-            const bool to_big = level != LEVEL_TILE;
+            // capacity), of a retry group on the workgroup-per-item list, of a workgroup on the global-scratch list
+            const bool to_next = level != LEVEL_TILE;
             unsigned long long hm = wv::ballot(has);
             int slot = 0;
             if (lane == 0)
-                slot = (int)wv::atomic_add_global(&wk.counters[to_big ? CNT_NBIG : CNT_NRETRY], (unsigned long long)__builtin_popcountll(hm));
+                slot = (int)wv::atomic_add_global(&wk.counters[to_next ? next_cnt : CNT_NRETRY], (unsigned long long)__builtin_popcountll(hm));
             slot = wv::bcast_first(slot);
             if (has) {
                 int rank = __builtin_popcountll(hm & ((1ull << lane) - 1ull));
-                (to_big ? wk.big_list : wk.retry_list)[slot + rank] = g;
+                (to_next ? next_list : wk.retry_list)[slot + rank] = g;
                 wk.status[g] = (uint8_t)ITEM_NEED_BIG;
             }
         }
@@ -1310,28 +1671,30 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     int inco = wv::scan_add(oc);
     int oS = inco - oc;
     int total = wv::bcast_last(inco);
-    if ((unsigned long long)total > ctx.slab_left) {  // wave-uniform: reserve a new slab
-        unsigned long long want = (unsigned long long)total > SLAB_OPS ? (unsigned long long)total : SLAB_OPS;
-        unsigned long long nb = 0;
-        if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want) + wk.slab_offset;
-        unsigned lo = (unsigned)wv::bcast_first((int)(unsigned)(nb & 0xffffffffull));
-        unsigned hi = (unsigned)wv::bcast_first((int)(unsigned)(nb >> 32));
-        ctx.slab_base = ((unsigned long long)hi << 32) | lo;
-        ctx.slab_left = want;
+    unsigned long long gbase = 0;
+    if (co.lead()) {  // the slab state of a workgroup is the lead wave's
+        if ((unsigned long long)total > ctx.slab_left) {  // wave-uniform: reserve a new slab
+            unsigned long long want = (unsigned long long)total > SLAB_OPS ? (unsigned long long)total : SLAB_OPS;
+            unsigned long long nb = 0;
+            if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want) + wk.slab_offset;
+            ctx.slab_base = wv::bcast_first(nb);
+            ctx.slab_left = want;
+        }
+        gbase = ctx.slab_base;
+        ctx.slab_base += (unsigned long long)total;
+        ctx.slab_left -= (unsigned long long)total;
     }
-    const unsigned long long gbase = ctx.slab_base;
-    ctx.slab_base += (unsigned long long)total;
-    ctx.slab_left -= (unsigned long long)total;
+    gbase = co.from_lead(gbase);
     bool fits = gbase + (unsigned long long)total <= wk.out_cap;
-    if (!fits && lane == 0) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
-    for (int base = 0; base < nA; base += 64) {
+    if (!fits && lane == 0 && co.lead()) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
+    PLO_CHUNKS(base, nA) {
         int e = base + lane;
         bool valid = e < nA;
-        int id = valid ? (m.idA[e] & 63) : 0;
-        int i_em = wv::shfl((int)emit_cigar, id), i_s = wv::shfl(sA, id), i_o = wv::shfl(oS, id);
+        int id = co.elem_id(m.idA, e, valid);
+        int i_em = co.item((int)emit_cigar, id), i_s = co.item(sA, id), i_o = co.item(oS, id);
         if (valid && i_em && fits) wk.out_cigar[gbase + (unsigned long long)(i_o + (e - i_s))] = m.A[e];
     }
-    if (has) {
+    if (has && co.lead()) {
         wk.status[g] = (uint8_t)status;
         wk.pos[g] = emit_cigar ? (int64_t)pos1 : (int64_t)-1;
         wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
@@ -1340,8 +1703,8 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     }
     // statistics stay in registers until the wave retires (wave_ctx_flush)
     ctx.algo_bytes += algo_bytes;
-    ctx.in_ops += has ? (unsigned long long)n_in : 0ull;
-    ctx.out_ops += (unsigned long long)oc;
+    ctx.in_ops += (has && co.lead()) ? (unsigned long long)n_in : 0ull;
+    ctx.out_ops += co.lead() ? (unsigned long long)oc : 0ull;
     PLO_T(9)
 #ifdef PLO_PHASE_TIMING
     if (lane == 0)
@@ -1362,6 +1725,7 @@ PLO_DEV void lift_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first,
                                    uint32_t stride, uint32_t n_tiles, int big_thresh, TileMem m, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
+    Coop<1> co;
     auto bounds = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {  // per lane, same value in every lane
         lo = 0;
         hi = 0;
@@ -1400,7 +1764,7 @@ PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         const uint32_t lo = (uint32_t)wv::bcast_first((int)lo0), hi = (uint32_t)wv::bcast_first((int)hi0);
         for (uint32_t b = lo; b < hi; b += 64) {
             int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-            lift_tile(ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx, b == lo ? &d0 : nullptr);
+            lift_tile(co, ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx, b == lo ? &d0 : nullptr);
             wv::sync();
         }
         lo0 = lo1;

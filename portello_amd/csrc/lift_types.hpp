@@ -50,7 +50,7 @@ struct DevBatch {
     uint32_t n_reads, n_segs;
 };
 
-enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_N = 24 };
+enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_NHUGE = 20, CNT_N = 24 };
 
 // Resolved per-item descriptors, written once per batch by the item kernels (thread per item, full occupancy) so that
 // the tile kernel starts from ONE level of coalesced loads instead of chasing item -> segment -> contig -> block map.
@@ -104,7 +104,8 @@ struct DevWork {
     unsigned long long slab_offset;
     uint32_t slab_pre;
     unsigned long long *wave_stats;  // [waves of the launch][4]: algorithmic bytes, input ops, output ops of every wave (summed by k_sum_stats)
-    uint32_t *big_list;            // items re-queued for the large-item kernel
+    uint32_t *big_list;            // items too heavy for a shared tile: workgroup-per-item kernel (k_lift_mid)
+    uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
 };
 
 }  // namespace plo

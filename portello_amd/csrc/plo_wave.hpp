@@ -49,6 +49,7 @@ PLO_DEV unsigned long long bcast_first(unsigned long long v) {
 }
 // Several waves of one workgroup working on the same tile (Coop<NW>, lift_core.hpp): index of the wave inside the workgroup
 // (in an SGPR) and the workgroup barrier (LDS writes of every wave before it are visible to every wave after it)
+PLO_DEV int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l & 63); }  // l wave-uniform
 PLO_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 PLO_DEV void block_sync() { __syncthreads(); }
 

@@ -8,7 +8,6 @@
 #include "../../portello_amd/csrc/enumerate.hpp"
 #include "../../portello_amd/csrc/finish_core.hpp"
 #include "../../portello_amd/csrc/index_pack.hpp"
-#include "../../portello_amd/csrc/lane_core.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
 
 using namespace plo;
@@ -23,8 +22,10 @@ struct Out {
 }  // namespace
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
-                                  int big_thresh, int big_cap, unsigned order_seed, int lane_max_in, plo_batch_out *out,
+                                  int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, plo_batch_out *out,
                                   unsigned long long *counters_out) {
+    // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
+    // code (lift_tile<NW>, LEVEL_MID) with an LDS capacity of mid_cap elements, under the multi-wave emulator
     PackedIndex pk;
     std::string err;
     if (pack_index(ixd, pk, err) != PLO_OK) {
@@ -87,7 +88,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     o->cig_off.assign(a, 0);
     o->cig_len.assign(a, 0);
     std::vector<uint32_t> item_cls(a, 0), item_nin(a, 0), d_in_off(a), d_n_in(a), d_w0(a), d_w1(a), d_kv0(a), d_kv1(a), d_flags(a), d_contig(a),
-        d_seq_len(a), big_list(a, 0);
+        d_seq_len(a), big_list(a, 0), huge_list(a, 0);
     std::vector<int> d_pos1(a);
     std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
     std::vector<int> d_shift_ref_len(a), d_chrom_ref_len(a);
@@ -97,7 +98,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     DevWork wk;
     memset(&wk, 0, sizeof(wk));
     wk.n_items = n_items;
-    wk.lane_max_in = lane_max_in;
+    wk.lane_max_in = -1;
     wk.item_seg = o->item_seg.data();
     wk.item_cseg = o->item_cseg.data();
     wk.item_nin = item_nin.data();
@@ -134,6 +135,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         wave_stats[0] = wave_stats[1] = wave_stats[2] = 0;
     };
     wk.big_list = big_list.data();
+    wk.huge_list = huge_list.data();
     if (in->item_seg) {
         for (uint32_t i = 0; i < n_items; ++i)
             build_item_desc(ix, bt, wk, stages, i, in->item_seg[i], in->item_cseg[i], segment_ref_len(bt, in->item_seg[i]));
@@ -180,25 +182,6 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         wk.out_cigar = o->cigar.data();
         wk.out_cap = out_cap;
         std::vector<unsigned char> lds(tile_mem_bytes(cap) + 64);
-        {   // lane-per-item kernel: groups of 64 class-order positions, persistent waves
-            std::vector<unsigned char> llds(lane_mem_bytes() + 64);
-            const uint32_t n_groups = (n_small + 63) / 64, n_lw = 2;
-            for (uint32_t wv_id = 0; wv_id < n_lw && n_groups; ++wv_id) {
-                wv::EmuWave w;
-                w.order_seed = order_seed ? order_seed + 333 + wv_id : 0;
-                LaneMem lm = carve_lane_mem(llds.data());
-                w.run([&]() {
-                    WaveCtx ctx;
-                    for (uint32_t gidx = wv_id; gidx < n_groups; gidx += n_lw) {
-                        uint32_t b0 = gidx * 64;
-                        lift_lanes(ix, bt, wk, stages, b0, (int)std::min<uint32_t>(64u, n_small - b0), lm, ctx);
-                        wv::sync();
-                    }
-                    wave_ctx_flush(wk, ctx, 0);
-                });
-                sum_stats();
-            }
-        }
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
         for (uint32_t wv_id = 0; wv_id < n_waves && n_large; ++wv_id) {
             wv::EmuWave w;
@@ -223,13 +206,55 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 TileMem m = carve_tile_mem(rlds.data(), retry_cap);
                 w.run([&]() {
                     WaveCtx ctx;
-                    lift_tile(ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+                    Coop<1> co;
+                    lift_tile(co, ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();
             }
         }
         uint32_t n_big = (uint32_t)counters[CNT_NBIG];
+        const uint32_t *last_list = wk.big_list;
+        if (n_big && mid_waves > 1) {  // k_lift_mid: one emulated workgroup per item
+            auto run_mid = [&](auto nw_c) {
+                constexpr int NW = decltype(nw_c)::value;
+                std::vector<unsigned char> mlds(((tile_mem_bytes(mid_cap) + 15) & ~(size_t)15) + Coop<NW>::XCH_INTS * 4 + 64);
+                const int mid_thresh = (mid_cap - 64) * 4 / 5;
+                const uint32_t n_blocks = 2;
+                for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+                    wv::EmuWave w;
+                    w.nw = NW;
+                    w.order_seed = order_seed ? order_seed + 4242 + blk : 0;
+                    TileMem m = carve_tile_mem(mlds.data(), mid_cap);
+                    int *xch = (int *)(mlds.data() + ((tile_mem_bytes(mid_cap) + 15) & ~(size_t)15));
+                    memset(xch, 0, Coop<NW>::XCH_INTS * 4);
+                    w.run([&]() {
+                        WaveCtx ctx;
+                        Coop<NW> co;
+                        co.w = wv::wave_id();
+                        co.xch = xch;
+                        for (uint32_t i = blk; i < n_big; i += n_blocks) {
+                            lift_tile(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
+                            co.sync();
+                        }
+                        // the waves of the emulated workgroup share the one statistics slot: one wave at a time
+                        for (int ww = 0; ww < NW; ++ww) {
+                            if (ww == co.w) {
+                                wave_ctx_flush(wk, ctx, 0);
+                                if (wv::lane() == 0) sum_stats();
+                            }
+                            co.sync();
+                        }
+                    });
+                }
+            };
+            if (mid_waves >= 16) run_mid(std::integral_constant<int, 16>{});
+            else if (mid_waves >= 8) run_mid(std::integral_constant<int, 8>{});
+            else if (mid_waves >= 4) run_mid(std::integral_constant<int, 4>{});
+            else run_mid(std::integral_constant<int, 2>{});
+            n_big = (uint32_t)counters[CNT_NHUGE];
+            last_list = wk.huge_list;
+        }
         if (n_big) {
             std::vector<unsigned char> scratch(tile_mem_bytes(big_cap) + 64);
             const uint32_t n_bw = 2;
@@ -239,8 +264,9 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 TileMem m = carve_tile_mem(scratch.data(), big_cap);
                 w.run([&]() {
                     WaveCtx ctx;
+                    Coop<1> co;
                     for (uint32_t i = wv_id; i < n_big; i += n_bw) {
-                        lift_tile(ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_LAST, 0, ctx);
+                        lift_tile(co, ix, bt, wk, stages, i, 1, m, last_list, LEVEL_LAST, 0, ctx);
                         wv::sync();
                     }
                     wave_ctx_flush(wk, ctx, 0);

@@ -104,14 +104,22 @@ struct EmuWave {
                     order[j] = t;
                 }
             }
+            // waves of a workgroup drift apart between two workgroup barriers on the hardware: in shuffle mode whole waves sit
+            // out rounds at random, so that a wave can run several wave-level primitives ahead of another one
+            unsigned skip = 0;
+            if (order_seed && nw > 1) {
+                rs = rs * 1664525u + 1013904223u;
+                skip = (rs >> 9) & (rs >> 17) & ((1u << nw) - 1u);  // each wave sits out with probability 1/4
+                if (skip == (1u << nw) - 1u) skip = 0;
+            }
             progress = 0;
             for (int i = 0; i < N; ++i) {
                 int l = order[i];
-                if (done[l]) continue;
+                if (done[l] || ((skip >> (l >> 6)) & 1u)) continue;
                 cur = l;
                 swapcontext(&sched, &fiber[l]);
             }
-            stalled = progress == 0;
+            stalled = progress == 0 && skip == 0;
         }
         current() = nullptr;
     }
@@ -177,6 +185,8 @@ inline int shfl(int v, int src) { return (int)shfl64(v, src); }
 inline unsigned shfl(unsigned v, int src) { return (unsigned)shfl64((int64_t)v, src); }
 inline long long shfl(long long v, int src) { return (long long)shfl64(v, src); }
 inline unsigned long long shfl(unsigned long long v, int src) { return (unsigned long long)shfl64((int64_t)v, src); }
+
+inline int read_lane(int v, int l) { return shfl(v, l & 63); }
 
 inline int shfl_up1(int v, int first) {
     int64_t p = v;

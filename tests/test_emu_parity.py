@@ -114,3 +114,33 @@ def test_comp_base_all_bytes(oracle):
     O = oracle.lib()
     for b in range(256):
         assert L.emu_comp_base(b) == O.orc_comp_base(b), b
+
+
+@pytest.mark.parametrize("mid_waves", [2, 4, 8, 16])
+def test_workgroup_per_item_path(oracle, mid_waves):
+    """items beyond the routing threshold run through lift_tile<NW> (several waves of one workgroup on one item, scan carries
+    crossing the waves through the exchange words) under the multi-wave emulator, lane order shuffled every round; a small
+    mid_cap sends some of them on to the one-wave path (LEVEL_MID -> huge list)"""
+    cfg = synth.config("tiny", n_reads=16, seed=112, read_len_mean=3000, read_len_sd=800,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1)
+    for mid_cap, seed in ((2048, 0), (512, 991)):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, big_thresh=100, mid_waves=mid_waves, mid_cap=mid_cap, order_seed=seed)
+        assert rc == 0 and cnt[2] > 0
+        if mid_cap == 2048:
+            assert cnt[20] < cnt[2]  # most items finish in the workgroup path
+        else:
+            assert cnt[20] > 0  # some are handed on
+        _assert_same(ref, res)
+
+
+def test_workgroup_per_item_stage_subsets(oracle):
+    w = synth.generate(synth.config("tiny", n_reads=12, seed=113, split_read_frac=0.3, read_len_mean=2500))
+    ix, b = w.index_data(), w.batch_data()
+    for stages in (abi.STAGES_ALL & ~abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LIFTOVER, abi.STAGE_LSHIFT, abi.STAGE_SIMPLIFY):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, big_thresh=8, mid_waves=4, mid_cap=1024)
+        assert rc == 0 and cnt[2] > 0
+        _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)

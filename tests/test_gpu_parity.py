@@ -107,18 +107,31 @@ def _indel_dense_workload():
     return synth.generate(cfg)
 
 
-def test_synthetic_indel_dense_large_item_kernel(oracle, monkeypatch):
-    """fixed geometry: items heavier than the routing threshold run alone from global scratch (k_lift_big), tiles that
-    overflow their LDS slice are re-run one item per wave (k_lift_retry)"""
+@pytest.mark.parametrize("mid", ["16", "8", "8:512", "0"])
+def test_synthetic_indel_dense_large_item_kernels(oracle, monkeypatch, mid):
+    """fixed geometry: items heavier than the routing threshold go to the workgroup-per-item kernel (k_lift_mid, 16 or 8 waves
+    per item); with a small capacity the heaviest of them are handed on to the one-wave-per-item kernel in global scratch
+    (k_lift_big), with PLO_MID_WAVES=0 all of them; tiles that overflow their LDS slice are re-run one item per wave
+    (k_lift_retry)"""
     monkeypatch.setenv("PLO_WINDOW", "256")
     monkeypatch.setenv("PLO_BIG_THRESH", "176")
     monkeypatch.setenv("PLO_CAP", "320")
+    waves, _, cap = mid.partition(":")
+    monkeypatch.setenv("PLO_MID_WAVES", waves)
+    if cap:
+        monkeypatch.setenv("PLO_MID_CAP", cap)
     w = _indel_dense_workload()
     ix, b = w.index_data(), w.batch_data()
     eng_ix = api.Index(ix)
     eng = api.Engine(eng_ix)
     got = eng.liftover_batch(b)
-    assert eng.timing().n_big_items > 0
+    t = eng.timing()
+    if waves == "0":
+        assert t.n_big_items > 0 and t.n_mid_items == 0
+    elif cap:
+        assert t.n_big_items > 0 and t.n_mid_items > 0
+    else:
+        assert t.n_mid_items > 0 and t.n_big_items == 0
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "indel_dense")
     eng.close()
     eng_ix.close()
@@ -317,31 +330,6 @@ def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
     _assert_same(oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, 2), via_views, "views_vs_oracle")
     eng.close()
     eng_ix.close()
-
-
-def test_lane_per_item_kernel_when_enabled(oracle, monkeypatch):
-    """the short-CIGAR lane-per-item kernel (off by default) + its overflow retry path"""
-    monkeypatch.setenv("PLO_LANE_MAX_IN", "64")
-    w = synth.generate(synth.config("tiny", n_reads=500, seed=207, split_read_frac=0.1, read_len_mean=25000))
-    ix, b = w.index_data(), w.batch_data()
-    eng_ix = api.Index(ix)
-    eng = api.Engine(eng_ix)
-    got = eng.liftover_batch(b)
-    t = eng.timing()
-    assert t.n_lane_items > 0
-    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "lanes")
-    eng.close()
-    eng_ix.close()
-    for seed in range(5):
-        import fuzz_cases
-
-        fix, fb = fuzz_cases.make(3000 + seed, n_reads=150, alphabet=b"AC")
-        fi = api.Index(fix)
-        fe = api.Engine(fi)
-        for stages in (31, 7, 18):
-            _assert_same(oracle.liftover_batch(fix, fb, stages, 1), fe.liftover_batch(fb, stages), f"lanes_fuzz_{seed}_{stages}")
-        fe.close()
-        fi.close()
 
 
 def test_boundary_validation_errors():
