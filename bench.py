@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- lifted HiFi reads/sec of the MI355X liftover engine (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload wgs30x|chr20|stress|plumbing] [--reads R]
+    python bench.py --gpus N --steps K --warmup W [--workload wgs30x|chr20|stress|plumbing] [--reads R] [--scaling strong|weak]
 
 One *step* = one pass of the hot path (plo_liftover_batch_dev: item enumeration, strand preparation, left-shift,
 liftover, length check, simplify) over one batch of synthetic reads that is already resident in HBM when the timed
-region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank lifts its own shard of
-the same size (weak scaling, reads shard with no data-path collective) and the compact result records are then
-gathered to rank 0 over RCCL (peer -> root send/recv, the path's only exchange step).  Rank 0 prints ONE JSON line.
+region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU), default `--scaling strong` = BASELINE.json configs[3]: ONE
+read set (same seed on every rank) is cut into the reference's own windows (<= 20 Mb of a contig,
+src/read_alignment_scanner.rs:508), the windows are dealt to the ranks balanced by their input CIGAR ops
+(portello_amd/shard.py), every rank lifts its windows with no data-path collective, and the compact result records are
+gathered to rank 0 over RCCL (peer -> root send/recv, the path's only exchange step).  After the timed region rank 0 checks
+that the gathered records equal its own single-GPU result of the whole read set, bit for bit.  `--scaling weak` gives every
+rank its own read set of the full size instead.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -29,20 +34,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from portello_amd import abi, api, devbatch, synth  # noqa: E402
+from portello_amd import abi, api, devbatch, shard, synth  # noqa: E402
 from portello_amd import gather as plo_gather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBS = 6300.0  # measured copy ceiling (same guide)
+_FIELDS = ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq", "item_chrom_index", "item_ref_pos",
+           "item_cigar_off", "item_cigar_len", "cigar")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(w, eng, db, got_out, budget_s: float = 12.0):
-    """Times the oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload and
-    checks the GPU result of those reads against it.  Rank 0, N = 1 only."""
+def cpu_baseline(w, got, budget_s: float = 12.0):
+    """Times the oracle (CPU restatement of the reference algorithm: sorted-array block maps + bisection instead of the
+    reference's BTreeMap, read segments split evenly over pthreads instead of rayon tasks per 20 Mb window) on a bounded sample
+    of the same workload -- blocks of consecutive reads spread evenly over the whole coordinate-sorted read set -- and checks the
+    GPU result of those reads against it.  Rank 0, N = 1 only."""
     from oracle import pyoracle
 
     pyoracle.build()
@@ -54,28 +63,39 @@ def cpu_baseline(w, eng, db, got_out, budget_s: float = 12.0):
     b = w.batch_data(0, probe)
     t0 = time.perf_counter()
     pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
-    t_probe = max(1e-4, time.perf_counter() - t0)
-    rate = probe / t_probe
+    rate = probe / max(1e-4, time.perf_counter() - t0)
     sample = int(min(n_reads, 300_000, max(probe, rate * budget_s)))
-    b = w.batch_data(0, sample)
-    t0 = time.perf_counter()
-    ref = pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
-    dt = time.perf_counter() - t0
+    n_blocks = 24 if n_reads >= 24 * 64 else 1
+    block = max(1, sample // n_blocks)
+    stride = n_reads // n_blocks
+    dt = 0.0
+    n_done = n_items = 0
+    ok = True
+    for k in range(n_blocks):
+        lo = k * stride
+        hi = min(n_reads, lo + block)
+        b = w.batch_data(lo, hi)
+        t0 = time.perf_counter()
+        ref = pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, cores)
+        dt += time.perf_counter() - t0
+        n_done += hi - lo
+        # parity of the block: GPU items of its read segments vs the oracle (item order is (segment, contig segment))
+        s0 = int(torch.searchsorted(w.seg_read, torch.tensor(lo, device=w.device)).item())
+        s1 = int(torch.searchsorted(w.seg_read, torch.tensor(hi, device=w.device)).item())
+        keep = (got.item_seg >= s0) & (got.item_seg < s1)
+        d = {f: (getattr(got, f)[keep] if f != "cigar" else got.cigar) for f in _FIELDS}
+        d["item_seg"] = (d["item_seg"] - s0).astype(np.uint32)
+        ok = ok and abi.BatchResult(**d).canonical() == ref.canonical()
+        n_items += int(keep.sum())
     t0 = time.perf_counter()
     pyoracle.liftover_batch(ixd, w.batch_data(0, probe), abi.STAGES_ALL, 1)
     rate1 = probe / max(1e-4, time.perf_counter() - t0)
-    # parity of the sampled reads: GPU items of reads [0, sample) vs oracle (item order is (segment, contig segment))
-    got = devbatch.download(eng, got_out)
-    n_seg_sample = b.n_segs
-    keep = got.item_seg < n_seg_sample
-    sub = abi.BatchResult(*(getattr(got, f)[keep] if f != "cigar" else got.cigar for f in
-                            ("item_seg", "item_cseg", "item_status", "item_need_flipped", "item_mapq", "item_chrom_index",
-                             "item_ref_pos", "item_cigar_off", "item_cigar_len", "cigar")))
-    ok = sub.canonical() == ref.canonical()
-    return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample} reads of the workload, oracle/liboracle.so (C restatement of the reference algorithm, "
-                      f"not the reference binary), {cores} threads; 1 thread: {rate1:.0f} reads/s",
-            "single_thread_value": rate1, "seconds": dt}, ok, int(keep.sum())
+    return {"value": n_done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"{n_blocks} blocks of {block} consecutive reads spread evenly over the read set ({n_done} reads), "
+                      f"oracle/liboracle.so = C restatement of the reference algorithm, not the reference binary (sorted-array block "
+                      f"maps with bisection where the reference has a BTreeMap; segments split evenly over {cores} pthreads where the "
+                      f"reference spawns rayon tasks per 20 Mb window); 1 thread: {rate1:.0f} reads/s",
+            "single_thread_value": rate1, "seconds": dt}, ok, n_items
 
 
 def main():
@@ -85,16 +105,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("PLO_BENCH_WORKLOAD", "wgs30x"))
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=os.environ.get("PLO_BENCH_SCALING", "strong"),
+                    help="N > 1: strong = one read set sharded by windows over the ranks (BASELINE configs[3]); weak = every rank "
+                         "its own read set of the full size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip rank 0's comparison of the gathered records "
+                                                             "with its own single-GPU result (after the timed region)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("PLO_BENCH_WORKERS", "1")),
                     help="host worker threads per GPU, each with its own context and HIP stream (INTEGRATION.md: one plo_ctx per "
                          "rayon worker); batches are dealt to them in turn, so one worker's enumerate pass and host syncs overlap the "
                          "other's tile kernel.  Default 1: the HIP-event kernel times of the roofline object then measure execution "
                          "only (with several streams they include the wait behind the other stream's kernel)")
-    ap.add_argument("--async-gather", action="store_true", default=bool(os.environ.get("PLO_BENCH_ASYNC_GATHER")),
-                    help="N > 1: two contexts alternate and the record gather of batch i stays in flight while batch i+1 is "
-                         "computed (single thread per rank, same posting order on all ranks).  Opt-in: covered by the gloo "
-                         "tests, not yet exercised over RCCL on several GPUs")
     ap.add_argument("--overlap-workers", type=int, default=0,
                     help="after the timed region, repeat the same K steps with this many workers and report the rate as the "
                          "supplementary object `overlap` (N = 1 only; 0/1 = skip, the default: the extra launches would enter a "
@@ -107,10 +128,14 @@ def main():
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    # (several ranks on one GPU only happen in the single-GPU exercise of the distributed path, PLO_BENCH_SHARE_GPU=1)
+    dev_index = local_rank if not os.environ.get("PLO_BENCH_SHARE_GPU") else local_rank % max(1, n_dev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1 or os.environ.get("PLO_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
+    force_dist = bool(os.environ.get("PLO_BENCH_FORCE_DIST"))  # exercises the RCCL path with one rank on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -118,8 +143,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
+    strong = args.scaling == "strong"
 
-    over = {"seed": synth.config(args.workload).seed + 1000 * rank}
+    over = {"seed": synth.config(args.workload).seed + (0 if strong else 1000 * rank)}
     if args.reads:
         over["n_reads"] = args.reads
     cfg = synth.config(args.workload, **over)
@@ -131,13 +157,28 @@ def main():
         log(f"[bench] workload {cfg.name}: {w.n_reads} reads, {w.seg_read.numel()} read segments, {int(w.cigar.numel())} input ops, "
             f"{len(w.contig_len)} contigs / {len(w.seg_pos)} contig segments, generated on GPU in {t_gen:.1f}s")
 
-    index = api.Index(w.index_data_device(), device=local_rank)
+    index = api.Index(w.index_data_device(), device=dev_index)
     n_workers = max(1, args.workers)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
     engs = [api.Engine(index, stream=s.cuda_stream) for s in streams]
     eng = engs[0]
-    db = devbatch.DeviceBatch.from_workload(w)
+
+    # ---- this rank's batch ---------------------------------------------------------------------------------------------
+    shard_info = None
+    my_ranges = [(0, w.n_reads)]
+    deal = wins = None
+    if strong and dist is not None:
+        wins = shard.workload_windows(w)
+        deal = shard.deal_windows(wins, world)
+        my_ranges = shard.rank_read_ranges(wins, deal, rank)
+        loads = [sum(wins[i].weight for i in d) for d in deal]
+        shard_info = {"windows": len(wins), "segment_size": shard.SEGMENT_SIZE, "windows_per_rank": [len(d) for d in deal],
+                      "in_ops_per_rank": loads, "imbalance": (max(loads) / (sum(loads) / world)) if sum(loads) else 1.0}
+        db = devbatch.DeviceBatch.from_read_ranges(w, my_ranges)
+    else:
+        db = devbatch.DeviceBatch.from_workload(w)
     desc = db.desc()
+    my_reads = db.n_reads
     torch.cuda.synchronize()
 
     def barrier():
@@ -146,34 +187,37 @@ def main():
 
     gather_lock = threading.Lock()  # one exchange at a time per rank: the n-th exchange of every rank pairs up
     last_out = [None] * n_workers
+    last_gather = [None]
 
-    def step(k):
+    def step(k, gather=True):
         out = engs[k].liftover_batch_dev(desc)
-        if dist is not None:
-            engs[k].compact_output_dev(out)  # no slab gaps over xGMI
-            with gather_lock, torch.cuda.stream(streams[k]):
-                plo_gather.gather_results(out, dev, dist, rank, world)
+        if dist is not None and gather:
+            engs[k].compact_output_dev(out)  # no slab gaps over xGMI; completes on the engine's stream, not at return
+            with gather_lock, torch.cuda.stream(streams[k]):  # the exchange is ordered behind the engine's kernels
+                last_gather[0] = plo_gather.gather_results(out, dev, dist, rank, world)
         last_out[k] = out
         return out
 
-    lift_ms, enum_ms, big_ms, mid_ms, retry_ms = [], [], [], [], []
+    times = {k_: [] for k_ in ("lift", "enum", "big", "mid", "retry")}
 
-    def run_steps(n_steps, record):
+    def record(tm):
+        times["lift"].append(tm.lift_ms)
+        times["enum"].append(tm.enumerate_ms)
+        times["big"].append(tm.big_ms)
+        times["mid"].append(tm.mid_ms)
+        times["retry"].append(tm.retry_ms)
+
+    def run_steps(n_steps, rec, gather=True):
         """n_steps batches, dealt to the workers in turn; every worker drives its own context on its own stream"""
         errors = []
 
         def worker(k):
             try:
-                torch.cuda.set_device(local_rank)
+                torch.cuda.set_device(dev_index)
                 for _ in range(k, n_steps, n_workers):
-                    step(k)
-                    if record:
-                        tm = engs[k].timing()  # HIP events on the worker's stream (waits for the step)
-                        lift_ms.append(tm.lift_ms)
-                        enum_ms.append(tm.enumerate_ms)
-                        big_ms.append(tm.big_ms)
-                        mid_ms.append(tm.mid_ms)
-                        retry_ms.append(tm.retry_ms)
+                    step(k, gather)
+                    if rec:
+                        record(engs[k].timing())  # HIP events on the worker's stream (waits for the step)
             except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
                 errors.append(e)
 
@@ -188,70 +232,88 @@ def main():
         if errors:
             raise errors[0]
 
-    async_gather = bool(args.async_gather and dist is not None and n_workers == 1)
-    if async_gather:
-        engs.append(api.Engine(index, stream=torch.cuda.Stream(device=dev).cuda_stream))  # second set of output buffers
-
-        def run_steps(n_steps, record):  # noqa: F811 -- pipelined variant of the loop above
-            pending = [None, None]
-            for i in range(n_steps):
-                k = i & 1
-                if pending[k] is not None:  # the exchange that still reads context k's outputs
-                    pending[k].wait()
-                    pending[k] = None
-                out_k = engs[k].liftover_batch_dev(desc)
-                engs[k].compact_output_dev(out_k)
-                last_out[0] = out_k
-                pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
-                if record:
-                    tm = engs[k].timing()
-                    lift_ms.append(tm.lift_ms)
-                    enum_ms.append(tm.enumerate_ms)
-                    big_ms.append(tm.big_ms)
-                    mid_ms.append(tm.mid_ms)
-                    retry_ms.append(tm.retry_ms)
-            for p_ in pending:
-                if p_ is not None:
-                    p_.wait()
+    def timed(fn, n_steps):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n_steps)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps, True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = last_out[0]
+    dt = timed(lambda n: run_steps(n, True), args.steps)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        nr = torch.tensor([w.n_reads], dtype=torch.float64, device=dev)
+        nr = torch.tensor([my_reads], dtype=torch.float64, device=dev)
         dist.all_reduce(nr, op=dist.ReduceOp.SUM)
         total_reads = float(nr.item())
     else:
-        total_reads = float(w.n_reads)
+        total_reads = float(my_reads)
 
-    # SURVEY.md 8(e) "report both": the same K batches without the final record gather (every rank keeps / writes its own shard)
-    no_gather = None
+    # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
+    no_gather = async_gather = verify = None
     if dist is not None:
+        dt_ng = timed(lambda n: run_steps(n, False, gather=False), args.steps)
+        no_gather = {"value": total_reads * args.steps / dt_ng, "unit": "reads/s", "ms_per_step": dt_ng / args.steps * 1e3,
+                     "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
+        if n_workers == 1:
+            # the exchange of batch i stays in flight while batch i+1 is computed into a second context's buffers.  Both the
+            # posting and the wait happen under the owning engine's stream: RCCL then starts the sends behind the compaction
+            # kernel, and the engine's next kernels start behind the sends that still read its buffers.
+            s2 = torch.cuda.Stream(device=dev)
+            a_streams = [streams[0], s2]
+            a_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
+            a_engs[1].liftover_batch_dev(desc)  # sizes its buffers
+            a_engs[1].sync()
+
+            def run_async(n_steps):
+                pending = [None, None]
+                for i in range(n_steps):
+                    k = i & 1
+                    if pending[k] is not None:
+                        with torch.cuda.stream(a_streams[k]):
+                            pending[k].wait()
+                        pending[k] = None
+                    out_k = a_engs[k].liftover_batch_dev(desc)
+                    a_engs[k].compact_output_dev(out_k)
+                    with torch.cuda.stream(a_streams[k]):
+                        pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
+                for k, p_ in enumerate(pending):
+                    if p_ is not None:
+                        with torch.cuda.stream(a_streams[k]):
+                            p_.wait()
+
+            run_async(2)
+            dt_a = timed(run_async, args.steps)
+            async_gather = {"value": total_reads * args.steps / dt_a, "unit": "reads/s", "ms_per_step": dt_a / args.steps * 1e3,
+                            "note": "record gather of batch i overlapped with the compute of batch i+1 (two contexts alternate)"}
+            a_engs[1].close()
+        # one more synchronous step whose gathered records rank 0 compares with its own result of the WHOLE read set
+        step(0)
         torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            engs[0].liftover_batch_dev(desc)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        no_gather = {"value": total_reads * args.steps / float(t.item()), "unit": "reads/s", "ms_per_step": float(t.item()) / args.steps * 1e3,
-                     "note": "same K steps without the record gather (each rank keeps its shard); supplementary"}
-        out = last_out[0] = engs[0].liftover_batch_dev(desc)
+        if strong and not args.no_verify:
+            if rank == 0:
+                seg_maps = [plo_gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)) for r in range(world)]
+                got_all = plo_gather.combine(last_gather[0], seg_maps)
+                got_all = {k_: v.clone() for k_, v in got_all.items()}
+                whole_db = devbatch.DeviceBatch.from_workload(w)
+                whole_out = eng.liftover_batch_dev(whole_db.desc())
+                eng.sync()
+                whole = plo_gather.tensors_from_out(whole_out, dev)
+                same = plo_gather.same_records(got_all, whole)
+                verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
+                          "reads": int(w.n_reads)}
+                if not same:
+                    log("[bench] VERIFY FAILURE: gathered records differ from the single-GPU result")
+                step(0, gather=False)  # restore this rank's own result in the context (read by the roofline object below)
+            barrier()
 
     overlap = None
     if dist is None and n_workers == 1 and args.overlap_workers > 1:
@@ -278,9 +340,10 @@ def main():
                            "worker overlap the other's tile kernel; supplementary, the headline value is the single-worker rate"}
         for e in o_engs:
             e.close()
+
     tm = eng.timing()
-    kms = {"k_lift_mid": float(np.mean(mid_ms)), "k_lift_tiles": float(np.mean(lift_ms)), "k_lift_big": float(np.mean(big_ms)),
-           "k_lift_retry": float(np.mean(retry_ms))}
+    kms = {"k_lift_mid": float(np.mean(times["mid"])), "k_lift_tiles": float(np.mean(times["lift"])), "k_lift_big": float(np.mean(times["big"])),
+           "k_lift_retry": float(np.mean(times["retry"]))}
     dominant = max(kms, key=kms.get)
     dom_ms = kms[dominant]
     # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
@@ -305,28 +368,31 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": cfg.name, "reads_per_gpu": w.n_reads, "read_len_mean": cfg.read_len_mean,
+        "config": {"workload": cfg.name, "reads_total": int(total_reads), "reads_this_rank": my_reads, "read_len_mean": cfg.read_len_mean,
                    "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
-                   "large_items_per_gpu": int(tm.n_big_items), "mid_items_per_gpu": int(tm.n_mid_items), "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4", "parallelism": f"shard{world}", "host_workers_per_gpu": n_workers,
-                   "gather": ("rccl send/recv to rank 0" + (", overlapped with the next batch" if async_gather else "")) if world > 1 else "none"},
+                   "large_items_per_gpu": int(tm.n_big_items), "mid_items_per_gpu": int(tm.n_mid_items),
+                   "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4",
+                   "parallelism": (f"one read set, 20 Mb windows dealt to {world} ranks by input ops" if strong else f"{world} independent read sets"),
+                   "host_workers_per_gpu": n_workers,
+                   "gather": "rccl send/recv to rank 0" if dist is not None else "none"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
-                     "enumerate_ms": float(np.mean(enum_ms)), "lift_tiles_ms": float(np.mean(lift_ms)),
-                     "lift_big_ms": float(np.mean(big_ms)), "lift_mid_ms": float(np.mean(mid_ms)),
-                     "lift_retry_ms": float(np.mean(retry_ms))},
+                     "enumerate_ms": float(np.mean(times["enum"])), "lift_tiles_ms": kms["k_lift_tiles"],
+                     "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"]},
     }
-    if overlap is not None:
-        result["overlap"] = overlap
-    if no_gather is not None:
-        result["no_gather"] = no_gather
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    for name, obj in (("shard", shard_info), ("overlap", overlap), ("no_gather", no_gather), ("async_gather", async_gather),
+                      ("verify", verify)):
+        if obj is not None:
+            result[name] = obj
+    if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
         try:
-            cb, ok, n_checked = cpu_baseline(w, eng, db, out)
+            got = devbatch.download(eng, last_out[0])
+            cb, ok, n_checked = cpu_baseline(w, got)
             result["cpu_baseline"] = cb
             result["parity_sample_items"] = n_checked
             result["parity_sample_ok"] = bool(ok)

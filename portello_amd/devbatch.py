@@ -67,6 +67,31 @@ class DeviceBatch:
             seg_is_fwd_strand=w.seg_is_fwd_r[seg_lo:seg_hi].contiguous(),
             seg_cigar_off=(co - c0).to(torch.int32).contiguous(), cigar=w.cigar[c0:c1].to(torch.int32).contiguous())
 
+    @classmethod
+    def from_read_ranges(cls, w, ranges) -> "DeviceBatch":
+        """The reads of several ranges [lo, hi) of a workload as ONE batch (a rank's windows, portello_amd/shard.py):
+        the slices are concatenated, offsets re-based.  Read r of range k becomes read (reads of ranges < k) + r - lo."""
+        parts = [cls.from_workload(w, lo, hi) for lo, hi in ranges if hi > lo]
+        if not parts:
+            return cls.from_workload(w, 0, 0)
+        if len(parts) == 1:
+            return parts[0]
+        rb = cb = sb = 0
+        seg_read, coff, soff = [], [], []
+        for p_ in parts:
+            seg_read.append(p_.seg_read + rb)
+            coff.append(p_.seg_cigar_off[:-1] + cb)
+            soff.append(p_.read_seq_off + sb)
+            rb += p_.n_reads
+            cb += int(p_.cigar.numel())
+            sb += int(p_.seq.numel())
+        coff.append(torch.tensor([cb], dtype=torch.int32, device=parts[0].cigar.device))
+        cat = lambda name: torch.cat([getattr(p_, name) for p_ in parts]).contiguous()
+        return cls(read_is_reverse=cat("read_is_reverse"), read_seq_len=cat("read_seq_len"), read_seq_off=torch.cat(soff).contiguous(),
+                   seq=cat("seq"), seq_fmt=parts[0].seq_fmt, seg_read=torch.cat(seg_read).to(torch.int32).contiguous(),
+                   seg_contig=cat("seg_contig"), seg_pos=cat("seg_pos"), seg_is_fwd_strand=cat("seg_is_fwd_strand"),
+                   seg_cigar_off=torch.cat(coff).to(torch.int32).contiguous(), cigar=cat("cigar"))
+
     def desc(self) -> abi.PloBatchIn:
         b = abi.PloBatchIn()
         b.n_reads = self.n_reads

@@ -184,3 +184,70 @@ def to_result(t: Dict[str, torch.Tensor]) -> abi.BatchResult:
         return t[name].cpu().numpy().view(npdt).copy()
 
     return abi.BatchResult(**{name: np_(name, npdt) for name, npdt, _ in ITEM_FIELDS}, cigar=np_("cigar", np.uint32))
+
+
+# ---- order-independent comparison of gathered records with a single-rank result (bench.py --scaling strong, tests) --------
+
+def combine(parts: List[Dict[str, torch.Tensor]], seg_maps: Optional[List[Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
+    """One record set from the per-rank dicts of gather_payloads: item arrays concatenated, CIGAR offsets re-based onto the
+    concatenated CIGAR buffer, and -- with seg_maps[r] = global read-segment index of rank r's local segment -- item_seg mapped
+    back to the unsharded numbering."""
+    out: Dict[str, List[torch.Tensor]] = {name: [] for name, _, _ in ITEM_FIELDS}
+    cig, base = [], 0
+    for r, t in enumerate(parts):
+        for name, _, _ in ITEM_FIELDS:
+            v = t[name]
+            if name == "item_cigar_off":
+                v = v + base
+            elif name == "item_seg" and seg_maps is not None and seg_maps[r] is not None:
+                v = seg_maps[r][v.long()].to(torch.int32)
+            out[name].append(v)
+        cig.append(t["cigar"])
+        base += int(t["cigar"].numel())
+    res = {name: torch.cat(v) for name, v in out.items()}
+    res["cigar"] = torch.cat(cig)
+    return res
+
+
+def canonical_tensors(t: Dict[str, torch.Tensor]):
+    """records sorted by (read segment, contig segment): (keys, item fields in key order, CIGAR ops in key order)"""
+    key = (t["item_seg"].long() << 20) | t["item_cseg"].long()
+    order = torch.argsort(key)
+    lens = t["item_cigar_len"].long()[order]
+    offs = t["item_cigar_off"].long()[order]
+    emit = (t["item_status"][order] == abi.ITEM_LIFTED) | (t["item_status"][order] == abi.ITEM_LEN_MISMATCH)
+    lens = torch.where(emit, lens, torch.zeros_like(lens))
+    total = int(lens.sum().item())
+    starts = torch.cumsum(lens, 0) - lens
+    flat = torch.repeat_interleave(offs - starts, lens) + torch.arange(total, device=key.device)
+    fields = {name: t[name][order] for name, _, _ in ITEM_FIELDS if name not in ("item_cigar_off",)}
+    return key[order], fields, t["cigar"][flat] if total else t["cigar"][:0]
+
+
+def same_records(a: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor]) -> bool:
+    """bit-exact, order-independent equality of two record sets (status, flags, chromosome, position, CIGAR ops of every item)"""
+    ka, fa, ca = canonical_tensors(a)
+    kb, fb, cb = canonical_tensors(b)
+    if ka.numel() != kb.numel() or not torch.equal(ka, kb):
+        return False
+    lifted = (fa["item_status"] == abi.ITEM_LIFTED) | (fa["item_status"] == abi.ITEM_LEN_MISMATCH)
+    for name in fa:
+        x, y = fa[name], fb[name]
+        if name in ("item_ref_pos", "item_cigar_len"):  # defined for lifted records only
+            x, y = x[lifted], y[lifted]
+        if not torch.equal(x, y):
+            return False
+    return ca.numel() == cb.numel() and bool(torch.equal(ca, cb))
+
+
+def local_to_global_segments(w, read_ranges) -> torch.Tensor:
+    """global read-segment index of every local segment of DeviceBatch.from_read_ranges(w, read_ranges)"""
+    dev = w.seg_read.device
+    parts = []
+    for lo, hi in read_ranges:
+        if hi <= lo:
+            continue
+        s0 = int(torch.searchsorted(w.seg_read, torch.tensor(lo, device=dev)).item())
+        s1 = int(torch.searchsorted(w.seg_read, torch.tensor(hi, device=dev)).item())
+        parts.append(torch.arange(s0, s1, device=dev))
+    return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long, device=dev)

@@ -23,29 +23,41 @@ def _free_port():
 
 
 def _worker(rank, world, port, outdir):
+    """strong scaling as bench.py does it: one read set, the reference's windows dealt to the ranks by input ops, every rank
+    lifts its windows (several read ranges), records gathered to rank 0 and compared with the unsharded result"""
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import pyoracle
+    from portello_amd import shard
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    w = synth.generate(synth.config("tiny", n_reads=90, seed=301, split_read_frac=0.2))
+    w = synth.generate(synth.config("tiny", n_reads=120, seed=301, split_read_frac=0.2, sorted_reads=True))
     ix = w.index_data()
-    lo, hi = gather_shard(w.n_reads, rank, world)
-    res = pyoracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, 1)
-    got = gather.gather_payloads(gather.tensors_from_result(res), dist, rank, world)
+    wins = shard.workload_windows(w, segment_size=30_000)
+    deal = shard.deal_windows(wins, world)
+    assert len(wins) > 2 * world
+    ranges = shard.rank_read_ranges(wins, deal, rank)
+    # the rank's batch = its ranges one after the other; the oracle stands in for the engine, one call per range
+    parts, seg_base = [], 0
+    for lo, hi in ranges:
+        b = w.batch_data(lo, hi)
+        t = gather.tensors_from_result(pyoracle.liftover_batch(ix, b, abi.STAGES_ALL, 1))
+        t["item_seg"] = t["item_seg"] + seg_base
+        seg_base += b.n_segs
+        parts.append(t)
+    mine = gather.combine(parts)
+    got = gather.gather_payloads(mine, dist, rank, world)
     if rank == 0:
-        whole = pyoracle.liftover_batch(ix, w.batch_data(), abi.STAGES_ALL, 1)
-        rows = []
-        for r in range(world):
-            rlo, _ = gather_shard(w.n_reads, r, world)
-            seg_base = int(torch.searchsorted(w.seg_read, torch.tensor(rlo)).item())
-            part = gather.to_result(got[r])
-            part.item_seg = part.item_seg + np.uint32(seg_base)
-            rows += part.canonical()
-        assert rows == whole.canonical()
+        whole = gather.tensors_from_result(pyoracle.liftover_batch(ix, w.batch_data(), abi.STAGES_ALL, 1))
+        seg_maps = [gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)) for r in range(world)]
+        assert sum(int(m.numel()) for m in seg_maps) == int(w.seg_read.numel())
+        allr = gather.combine(got, seg_maps)
+        assert gather.same_records(allr, whole)
+        allr["item_ref_pos"][3] += 1  # and the comparison does notice a difference
+        assert not gather.same_records(allr, whole)
         open(os.path.join(outdir, "ok"), "w").write("ok")
     else:
         assert got is None
