@@ -1,0 +1,116 @@
+/*
+ * portello_bam.h -- host side of the liftover path: BAM/BGZF input, batch construction, BAM record bytes, output.
+ *
+ * These entry points surround plo_liftover_batch (portello_liftover.h) with what the reference does through
+ * rust-htslib (third party, not under /root/reference: rust-htslib 0.50.0 / htslib, Cargo.lock:740-742,1459-1461):
+ *
+ *   plo_bam_open / plo_bam_header / plo_bam_read_window
+ *        bam::IndexedReader + fetch + read loop of scan_chromosome_segment      src/read_alignment_scanner.rs:382-406
+ *        (records are taken in file order instead of per-window index fetches: the set of primary, mapped
+ *        records -- and therefore the output set -- is the same; output order is unspecified in the reference,
+ *        docs/user_guide.md:227-230) and of scan_unmapped_reads                  src/read_alignment_scanner.rs:537-559
+ *   plo_bam_window_batch
+ *        get_seq_order_read_split_segments for every primary record              lib/rust-vc-utils/src/bam_utils/split_read.rs:56-155
+ *        (SA:Z parsing: aux/sa_tag_parser.rs:25-59; clip positions: cigar/mod.rs:85-118), laid out as the
+ *        plo_batch_in of portello_liftover.h
+ *   plo_records_build
+ *        the record bytes of get_liftover_alignment_for_read_and_contig_segment  src/read_alignment_scanner.rs:245-284
+ *        (clone_record :105-118, PS/ZM tags :254-268, pos/cigar :270-271, reverse_alignment_seq_and_qual :125-133,
+ *        bin :278-279, supplementary :282) and finish_remapped_alignment_set      :310-366
+ *        (unmapped copy :317-335, primary selection :338-346, SA tags :348-364), serialised as htslib's bam_write1
+ *        does (BAM specification 4.2; CG:B,I for more than 65535 CIGAR ops)
+ *   plo_bam_output_header / plo_bam_writer_*
+ *        get_alignment_file_header :35-59, get_shared_bam_writer :61-78 (level 0 = uncompressed BGZF as for stdout)
+ *
+ * Parity: the aux / set() / bam_write1 byte semantics restate third-party code that is absent from the reference
+ * tree -- "parity unpinned by the reference's tests"; the SA / split-segment parsing is pinned by split_read.rs:198-232
+ * and sa_tag_parser.rs:66-77 (tests/golden/reference_vectors.json, "split_segments").
+ *
+ * Conventions as in portello_liftover.h: int status, no unwinding, plo_bam_last_error() for the message; objects are
+ * single-threaded (internally they use `n_threads` worker threads for (de)compression and record assembly).
+ */
+#ifndef PORTELLO_BAM_H
+#define PORTELLO_BAM_H
+
+#include "portello_liftover.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLO_ERR_IO 7   /* file cannot be opened / read / written, truncated or corrupt BGZF block           */
+#define PLO_ERR_DATA 8 /* a record the reference would panic on: SA segment without aligned bases, SA read
+                          length different from the primary's, unknown SA contig, empty split segment
+                          (split_read.rs:112-151), malformed SA text (sa_tag_parser.rs:27-31)               */
+
+typedef struct plo_bam_reader plo_bam_reader;
+typedef struct plo_bam_writer plo_bam_writer;
+typedef struct plo_bam_window plo_bam_window;
+
+plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out);
+void plo_bam_close(plo_bam_reader *r);
+/* header text and the @SQ list as stored in the BAM header (ChromList::from_bam_header, chrom_list.rs:27-37).
+   The pointers stay valid until plo_bam_close. */
+plo_status plo_bam_header(const plo_bam_reader *r, const char **text, uint32_t *l_text, uint32_t *n_ref,
+                          const char *const **ref_names, const uint32_t **ref_lens);
+
+/* Next window of the file: at most max_records primary records (fewer at the end of the file; 0 = end).
+ * Records are classified as the reference does:
+ *   unmapped flag set                     -> pass-through list (scan_unmapped_reads :551-555)
+ *   supplementary flag set                -> skipped (:404)
+ *   everything else                       -> a primary read of the batch
+ * The window owns copies of the record bytes. */
+plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_window **out);
+void plo_bam_window_free(plo_bam_window *w);
+uint32_t plo_bam_window_n_records(const plo_bam_window *w);
+/* unmapped records of the window's stretch of the file as BAM record bytes (block_size prefixed), ready for
+   plo_bam_write to the "unassembled" output */
+void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records);
+
+/* The window as a plo_batch_in (host arrays owned by the window, page-locked when a HIP device is usable):
+ * reads = the primary records, segments = get_seq_order_read_split_segments of each, read bases = the records' 4-bit
+ * packed sequences.  Also returns the qualities and flags that plo_finish_batch_dev takes (optional, may be NULL). */
+plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin);
+
+/* Output records of a window.  `lift` = host result of plo_liftover_batch on the window's batch (items ordered by read
+ * segment, contig segment).  For every read, in order: its lifted records (item order) with flags, bin, PS/ZM/SA tags as
+ * the reference writes them, or -- when nothing lifted and !is_target_region -- the unmapped copy.
+ * LEN_MISMATCH / PANIC items are the reference's aborts: the call fails with PLO_ERR_DATA. */
+typedef struct plo_records_params {
+    const plo_index_desc *index;        /* contig segments: is_fwd_strand for the PS tag, ordering                  */
+    const char *const *contig_names;    /* [n_contigs] labels of the read->contig BAM header (PS tag)               */
+    const char *const *ref_names;       /* [n_chroms] labels of the reference ChromList (SA tag)                    */
+    int32_t is_target_region;           /* src/read_alignment_scanner.rs:318-320                                    */
+    int32_t n_threads;
+} plo_records_params;
+
+typedef struct plo_record_buf {
+    const uint8_t *bytes;       /* BAM records, each prefixed by its block_size (what bam_write1 emits)             */
+    uint64_t n_bytes;
+    uint32_t n_records;
+    const uint64_t *record_off; /* [n_records + 1] */
+    uint32_t n_lifted, n_unmapped_copies;
+} plo_record_buf;
+
+plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *lift, const plo_records_params *params,
+                             plo_record_buf *out);
+
+/* Header of the output files (get_alignment_file_header :35-59): @HD VN:1.6 SO:unsorted, one @SQ per chromosome,
+   @PG PN/ID/VN/CL.  Returns a malloc'ed NUL-terminated text (free with plo_bam_free_text). */
+char *plo_bam_output_header(uint32_t n_ref, const char *const *ref_names, const uint32_t *ref_lens, const char *program_name,
+                            const char *program_version, const char *cmdline);
+void plo_bam_free_text(char *text);
+
+/* level 0: BGZF blocks with stored (uncompressed) deflate data, what the reference selects for stdout (:67-71);
+   1..9: zlib deflate levels */
+plo_status plo_bam_writer_open(const char *path, const char *header_text, uint32_t n_ref, const char *const *ref_names,
+                               const uint32_t *ref_lens, int level, int n_threads, plo_bam_writer **out);
+plo_status plo_bam_write(plo_bam_writer *w, const uint8_t *record_bytes, uint64_t n_bytes);
+plo_status plo_bam_writer_close(plo_bam_writer *w);
+
+const char *plo_bam_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORTELLO_BAM_H */

@@ -379,3 +379,30 @@ def result_from_out(out: PloBatchOut) -> BatchResult:
         item_cigar_len=cp(out.item_cigar_len, np.uint32, n),
         cigar=cp(out.cigar, np.uint32, nc),
     )
+
+
+def out_from_result(res: BatchResult):
+    """a plo_batch_out whose pointers view the numpy arrays of a BatchResult; returns (struct, keep-alive list)"""
+    o = PloBatchOut()
+    keep = []
+
+    def put(name, dt, ct):
+        a = np.ascontiguousarray(getattr(res, name), dtype=dt)
+        if a.size == 0:
+            a = np.zeros(1, dtype=dt)
+        keep.append(a)
+        setattr(o, name, a.ctypes.data_as(C.POINTER(ct)))
+
+    o.n_items = res.n_items
+    put("item_seg", np.uint32, C.c_uint32)
+    put("item_cseg", np.uint32, C.c_uint32)
+    put("item_status", np.uint8, C.c_uint8)
+    put("item_need_flipped", np.uint8, C.c_uint8)
+    put("item_mapq", np.uint8, C.c_uint8)
+    put("item_chrom_index", np.uint32, C.c_uint32)
+    put("item_ref_pos", np.int64, C.c_int64)
+    put("item_cigar_off", np.uint64, C.c_uint64)
+    put("item_cigar_len", np.uint32, C.c_uint32)
+    put("cigar", np.uint32, C.c_uint32)
+    o.n_cigar = len(res.cigar)
+    return o, keep

@@ -150,6 +150,13 @@ class Engine:
         self._check(self.lib.plo_liftover_batch(self.handle, C.byref(b), stages, C.byref(out)), "plo_liftover_batch")
         return abi.result_from_out(out)
 
+    def liftover_batch_host(self, desc: abi.PloBatchIn, stages: int = abi.STAGES_ALL) -> abi.PloBatchOut:
+        """plo_liftover_batch on a descriptor of host arrays (e.g. a BAM window's batch); the returned arrays are pinned host
+        memory owned by the context, valid until its next call."""
+        out = abi.PloBatchOut()
+        self._check(self.lib.plo_liftover_batch(self.handle, C.byref(desc), stages, C.byref(out)), "plo_liftover_batch")
+        return out
+
     def liftover_batch_dev(self, desc: abi.PloBatchIn, stages: int = abi.STAGES_ALL) -> abi.PloBatchOut:
         """Device pointers in, device pointers out (plo_liftover_batch_dev); asynchronous on the engine's stream."""
         out = abi.PloBatchOut()

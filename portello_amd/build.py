@@ -8,7 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libportello_liftover.so")
-SOURCES = ["engine.hip"]
+SOURCES = ["engine.hip", "bam_host.cpp"]
+LIBS = ["-lz"]
 HEADERS = ["plo_wave.hpp", "lift_core.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp"]
 
 
@@ -23,18 +24,19 @@ def build_timing() -> str:
     """instrumented variant (per-phase s_memtime accumulation) used by tools/tune.py only"""
     out = os.path.join(HERE, "libportello_liftover_timing.so")
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPLO_PHASE_TIMING", "-I" + CSRC, "-o", out,
-           os.path.join(CSRC, "engine.hip")]
+           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "bam_host.cpp")] + LIBS
     subprocess.check_call(cmd)
     return out
 
 
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "portello_liftover.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "portello_liftover.h"),
+                                                                os.path.join(HERE, "..", "include", "portello_bam.h")]
     stale = (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
     if not (force or stale):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + (extra or [])
+           "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + LIBS + (extra or [])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -18,14 +18,19 @@ def lib_path():
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "portello_liftover.h")).read()
-    return sorted(set(re.findall(r"^(?:plo_status|void|int|const char \*)\s*\*?(plo_[a-z0-9_]+)\(", text, flags=re.M)))
+    out = set()
+    for h in ("portello_liftover.h", "portello_bam.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        out |= set(re.findall(r"^(?:plo_status|void|int|uint32_t|char \*|const char \*)\s*\*?(plo_[a-z0-9_]+)\(", text, flags=re.M))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol(lib_path):
     L = C.CDLL(lib_path)
     syms = declared_symbols()
-    assert {"plo_index_create", "plo_ctx_create", "plo_liftover_batch", "plo_liftover_batch_dev", "plo_selftest"} <= set(syms)
+    assert {"plo_index_create", "plo_ctx_create", "plo_liftover_batch", "plo_liftover_batch_dev", "plo_selftest", "plo_bam_open",
+            "plo_bam_read_window", "plo_bam_window_batch", "plo_records_build", "plo_bam_writer_open", "plo_bam_output_header",
+            "plo_bam_window_n_records"} <= set(syms)
     for s in syms:
         assert hasattr(L, s), f"{s} declared in the header but not exported"
 

@@ -1,0 +1,358 @@
+"""BAM/BGZF input, batch construction from records, output record bytes (include/portello_bam.h) against
+ - the reference's own vectors for SA / split-segment parsing (split_read.rs:198-232, sa_tag_parser.rs:66-77),
+ - oracle/pyrecords.py, the pure-Python restatement of the record logic (byte for byte),
+ - tests/bamcheck.py, an independent reader of the files the BGZF writer produces.
+CPU tests use the C oracle for the lifted alignments; the GPU test runs the same window through the HIP engine."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import bamcheck
+from oracle import pyrecords as pr
+from portello_amd import abi, api, bam, bamsynth, synth
+from portello_amd import cigar as cg
+
+
+def _label_to_index(names):
+    return {n: i for i, n in enumerate(names)}
+
+
+def expected_records(rec_bytes, ix: abi.IndexData, contig_names, ref_names, res: abi.BatchResult, is_target_region=False):
+    """the reference's per-read loop (src/read_alignment_scanner.rs:393-488) in pure Python, lifted alignments taken from `res`;
+    also checks the item enumeration (a8) and need_flipped (a9) of `res` against the Python glue"""
+    l2i = _label_to_index(contig_names)
+    out, k, seg_global = [], 0, 0
+    for rb in rec_bytes:
+        rec = pr.record_from_bytes(rb)
+        segs = pr.get_seq_order_read_split_segments(l2i, rec)
+        remapped = []
+        for seg in segs:
+            c = seg.chrom_index
+            g0, g1 = int(ix.contig_seg_off[c]), int(ix.contig_seg_off[c + 1])
+            csegs = [(int(ix.seg_seq_order_start[g]), int(ix.seg_seq_order_end[g])) for g in range(g0, g1)]
+            for cseg in pr.get_contig_split_segments_from_read_mapping(seg, csegs):
+                g = g0 + cseg
+                assert int(res.item_seg[k]) == seg_global and int(res.item_cseg[k]) == cseg, (k, seg_global, cseg)
+                cfwd = bool(ix.seg_is_fwd_strand[g])
+                need_flipped, _, _ = pr.strand_glue(rec.is_reverse(), seg, cfwd, int(ix.contig_len[c]))
+                assert int(res.item_need_flipped[k]) == int(need_flipped)
+                if int(res.item_status[k]) == abi.ITEM_LIFTED:
+                    remapped.append(pr.lifted_record(rec, contig_names[c], cseg, cfwd, int(ix.seg_chrom_index[g]), int(ix.seg_mapq[g]),
+                                                     need_flipped, int(res.item_ref_pos[k]), [int(x) for x in res.item_cigar(k)]))
+                k += 1
+            seg_global += 1
+        out += pr.finish_remapped_alignment_set(ref_names, rec, remapped, is_target_region)
+    assert k == res.n_items
+    return [r.to_bytes() for r in out]
+
+
+def test_sa_parser_reference_vector():
+    """sa_tag_parser.rs:66-77"""
+    val = ("chr3,10001,+,5535S10=1D39=2X11438S,60,192;chr3,10001,+,3073S15=2D20=2X11=1X5=1I23=1X5=14798S,22,44;"
+           "chr4,106872270,-,23=1I226=1I195=1X147=1D1021=7362S,60,19;")
+    r = pr.parse_sa_aux_val(val)
+    assert len(r) == 3 and r[2]["rname"] == "chr4" and r[1]["pos"] == 10_000 and not r[2]["is_fwd_strand"]
+
+
+def _sam_record(tid, pos1, cigar_text, seq, qual, sa=None, flag=0):
+    cig = np.array(cg.encode(cigar_text), dtype=np.uint32)
+    lut = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    n4 = [lut[c] for c in seq] + ([0] if len(seq) & 1 else [])
+    sp = bytes((n4[i] << 4) | n4[i + 1] for i in range(0, len(n4), 2))
+    aux = (b"SAZ" + sa.encode() + b"\0") if sa else b""
+    return bamsynth.encode_record(tid, pos1 - 1, 60, flag, b"qname", cig, sp, len(seq), bytes(ord(c) - 33 for c in qual), aux)
+
+
+def test_split_segments_reference_vectors(tmp_path):
+    """split_read.rs:198-232 through both restatements: pyrecords and the engine's window builder (via a real BAM file)"""
+    names = ["chr0", "chr1", "chr2"]
+    seq, qual = "ACGCCGTATCGTCTCGAGGA", "DDDDDEEEEEDDDDDEEEEE"
+    r1 = _sam_record(2, 10, "10S5M5S", seq, qual)
+    r2 = _sam_record(2, 10, "10S5M5S", seq, qual, sa="chr0,20,-,5M15S,60,0;chr0,100,+,5S5M10S,60,0;chr1,200,-,15S5M,60,0;")
+    exp1 = [(10, 15, 2, 9, True, "10S5M5S", True)]
+    exp2 = [(0, 5, 1, 199, False, "15S5M", False), (5, 10, 0, 99, True, "5S5M10S", False), (10, 15, 2, 9, True, "10S5M5S", True),
+            (15, 20, 0, 19, False, "5M15S", False)]
+    l2i = _label_to_index(names)
+    for rb, exp in ((r1, exp1), (r2, exp2)):
+        got = pr.get_seq_order_read_split_segments(l2i, pr.record_from_bytes(rb))
+        assert [(s.seq_order_read_start, s.seq_order_read_end, s.chrom_index, s.pos, s.is_fwd_strand, pr.cigar_to_text(s.cigar),
+                 s.from_primary_bam_record) for s in got] == exp
+    path = str(tmp_path / "v.bam")
+    w = bam.BamWriter(path, "@HD\tVN:1.6\n", names, [1000] * 3, level=6)
+    w.write(r1 + r2)
+    w.close()
+    rd = bam.BamReader(path, 2)
+    assert rd.ref_names == names and rd.ref_lens == [1000] * 3
+    win = rd.read_window(10)
+    b = win.batch_data()
+    assert b.n_reads == 2 and b.n_segs == 5
+    exp = exp1 + exp2
+    assert list(b.seg_read) == [0, 1, 1, 1, 1]
+    assert [int(x) for x in b.seg_contig] == [e[2] for e in exp] and [int(x) for x in b.seg_pos] == [e[3] for e in exp]
+    assert [bool(x) for x in b.seg_is_fwd_strand] == [e[4] for e in exp]
+    for s, e in enumerate(exp):
+        assert cg.decode(b.cigar[int(b.seg_cigar_off[s]):int(b.seg_cigar_off[s + 1])]) == e[5]
+    assert rd.read_window(10) is None
+    win.close()
+    rd.close()
+
+
+@pytest.fixture(scope="module")
+def small_bam(tmp_path_factory):
+    d = tmp_path_factory.mktemp("bam")
+    w = synth.generate(synth.config("tiny", n_reads=300, seed=411, split_read_frac=0.3, sorted_reads=True))
+    path = str(d / "reads.bam")
+    meta = bamsynth.write_read_bam(w, path, level=6, n_unmapped=4)
+    return w, path, meta
+
+
+def test_writer_output_is_a_valid_bam_and_reader_round_trips(small_bam, tmp_path):
+    w, path, meta = small_bam
+    text, refs, recs = bamcheck.read_bam(path)
+    assert text == meta["header_text"] and [n for n, _ in refs] == meta["contig_names"]
+    blocks = bamcheck.bgzf_blocks(path)
+    assert blocks[-1] == (28, 0) and all(isz <= 0xff00 for _, isz in blocks)
+    flags = [struct.unpack_from("<H", r, 18)[0] for r in recs]
+    prim = [r for r, f in zip(recs, flags) if not (f & 0x804)]
+    assert len(prim) == w.n_reads and sum(1 for f in flags if f & 4) == 4 and any(f & 0x800 for f in flags)
+    # the engine's reader sees the same records, whatever the window size; level 0 (stored blocks) round-trips too
+    for max_rec in (7, 64, 10_000):
+        rd = bam.BamReader(path, 3)
+        got, unm, n_unm = [], b"", 0
+        while True:
+            win = rd.read_window(max_rec)
+            if win is None:
+                break
+            b = win.batch_data()
+            assert b.n_reads == win.n_records
+            got.append(b)
+            u, k = win.unmapped_bytes()
+            unm += u
+            n_unm += k
+            win.close()
+        rd.close()
+        assert sum(b.n_reads for b in got) == w.n_reads and n_unm == 4
+        assert unm == b"".join(meta["unmapped_records"])  # pass-through records are byte-identical (scan_unmapped_reads :551-555)
+    p0 = str(tmp_path / "stored.bam")
+    wr = bam.BamWriter(p0, text, [n for n, _ in refs], [l for _, l in refs], level=0)
+    wr.write(b"".join(recs))
+    wr.close()
+    assert bamcheck.read_bam(p0)[2] == recs
+
+
+def test_window_batch_matches_python_split_segments(small_bam):
+    w, path, meta = small_bam
+    _, _, recs = bamcheck.read_bam(path)
+    prim = [r for r in recs if not (struct.unpack_from("<H", r, 18)[0] & 0x804)]
+    rd = bam.BamReader(path, 2)
+    win = rd.read_window(100_000)
+    b = win.batch_data()
+    l2i = _label_to_index(meta["contig_names"])
+    s = 0
+    for r, rb in enumerate(prim):
+        rec = pr.record_from_bytes(rb)
+        assert int(b.read_is_reverse[r]) == int(rec.is_reverse()) and int(b.read_seq_len[r]) == rec.l_seq
+        o = int(b.read_seq_off[r])
+        assert b.seq[o:o + (rec.l_seq + 1) // 2].tobytes() == rec.seq4
+        for seg in pr.get_seq_order_read_split_segments(l2i, rec):
+            assert (int(b.seg_read[s]), int(b.seg_contig[s]), int(b.seg_pos[s]), bool(b.seg_is_fwd_strand[s])) == \
+                   (r, seg.chrom_index, seg.pos, seg.is_fwd_strand)
+            assert [int(x) for x in b.cigar[int(b.seg_cigar_off[s]):int(b.seg_cigar_off[s + 1])]] == seg.cigar
+            s += 1
+    assert s == b.n_segs
+    win.close()
+    rd.close()
+
+
+@pytest.mark.parametrize("is_target_region", [False, True])
+def test_record_bytes_match_python_restatement(small_bam, oracle, is_target_region):
+    """plo_records_build byte for byte against oracle/pyrecords.py (clone_record / PS / ZM / SA / flags / bin / reversed
+    seq+qual / unmapped copy), on lifted alignments from the C oracle"""
+    w, path, meta = small_bam
+    ix = w.index_data()
+    _, _, recs = bamcheck.read_bam(path)
+    prim = [r for r in recs if not (struct.unpack_from("<H", r, 18)[0] & 0x804)]
+    rd = bam.BamReader(path, 2)
+    win = rd.read_window(100_000)
+    b = win.batch_data()
+    res = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 2)
+    assert (res.item_status == abi.ITEM_NO_LIFTOVER).any() or True
+    o, keep = abi.out_from_result(res)
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    data, off, n_lift, n_unm = win.build_records(o, ix.to_desc(), cn, rn, is_target_region=is_target_region, n_threads=3)
+    exp = expected_records(prim, ix, cn, rn, res, is_target_region)
+    got = [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    assert len(got) == len(exp)
+    for i, (a, e) in enumerate(zip(got, exp)):
+        assert a == e, (i, pr.record_from_bytes(a), pr.record_from_bytes(e))
+    assert n_lift == int((res.item_status == abi.ITEM_LIFTED).sum())
+    if not is_target_region:
+        assert n_unm == len(exp) - n_lift
+    # the hand-checked ordering of the added tags on one split read: [kept tags] PS ZM SA, removed NM / old PS / old ZM / old SA
+    multi = [pr.record_from_bytes(e) for e in exp if pr.record_from_bytes(e).aux_get(b"SA") is not None]
+    assert multi, "workload has no read with two lifted records"
+    tags = [t for t, _ in multi[0].aux]
+    assert tags[-3:] == [b"PS", b"ZM", b"SA"] and b"NM" not in tags and tags.count(b"PS") == 1 and tags.count(b"ZM") == 1
+    win.close()
+    rd.close()
+
+
+def test_hand_checked_record(tmp_path):
+    """one read, two lifted records, every byte of the second written out by hand from the reference's statements"""
+    seq, qual = "ACGTTGCAAC", "ABCDEFGHIJ"
+    rb = bamsynth.encode_record(0, 99, 37, 0x10, b"r1", np.array(cg.encode("4S6M"), np.uint32), bytes([0x12, 0x48, 0x84, 0x21, 0x12]), 10,
+                                bytes(ord(c) - 33 for c in qual), b"NMC\x05" + b"XXZkeep\0" + b"SAZctg0,1,+,4M6S,60,0;\0")
+    path = str(tmp_path / "one.bam")
+    wr = bam.BamWriter(path, "@HD\tVN:1.6\n", ["ctg0"], [5000], level=0)
+    wr.write(rb)
+    wr.close()
+    rd = bam.BamReader(path, 1)
+    win = rd.read_window(10)
+    b = win.batch_data()
+    assert b.n_segs == 2
+    # a hand-made lift result: segment 0 (seq order) -> chr1:1001 6M4S mapq 20, not flipped; segment 1 -> chr2:501 flipped, mapq 50
+    res = abi.BatchResult(item_seg=np.array([0, 1], np.uint32), item_cseg=np.array([1, 0], np.uint32), item_status=np.zeros(2, np.uint8),
+                          item_need_flipped=np.array([0, 1], np.uint8), item_mapq=np.array([20, 50], np.uint8),
+                          item_chrom_index=np.array([0, 1], np.uint32), item_ref_pos=np.array([1000, 500], np.int64),
+                          item_cigar_off=np.array([0, 2], np.uint64), item_cigar_len=np.array([2, 4], np.uint32),
+                          cigar=np.array(list(cg.encode("6M4S")) + list(cg.encode("4S5M1D1M")), np.uint32))
+    ix = abi.IndexData(contig_len=np.array([5000]), contig_seg_off=np.array([0, 2], np.uint32), seg_chrom_index=np.array([0, 1], np.uint32),
+                       seg_pos=np.array([0, 0]), seg_is_fwd_strand=np.array([1, 0], np.uint8), seg_mapq=np.array([50, 20], np.uint8),
+                       seg_seq_order_start=np.array([0, 2500]), seg_seq_order_end=np.array([2500, 5000]), seg_cigar_off=np.array([0, 1, 2], np.uint32),
+                       seg_cigar=np.array(list(cg.encode("2500M")) * 2, np.uint32), chrom_seq=[np.zeros(4000, np.uint8)] * 2, rev_contig_seq=[None])
+    o, keep = abi.out_from_result(res)
+    data, off, n_lift, n_unm = win.build_records(o, ix.to_desc(), ["ctg0"], ["chr1", "chr2"])
+    assert (n_lift, n_unm, len(off) - 1) == (2, 0, 2)
+    second = data[int(off[1]):int(off[2])]
+    # record 2: flipped -> flag 0x10 ^ 0x10 = 0, primary (mapq 50 > 20) -> no 0x800; pos 500; end 500 + 6 = 506 -> bin 4681 + (500 >> 14)
+    # seq = revcomp("ACGTTGCAAC") = "GTTGCAACGT" -> nibbles 4 8 8 4 2 1 1 2 4 8; qual reversed
+    body = struct.pack("<iiBBHHHIiii", 1, 500, 3, 50, 4681, 4, 0, 10, -1, -1, 0) + b"r1\0" + \
+        np.array(cg.encode("4S5M1D1M"), "<u4").tobytes() + bytes([0x48, 0x84, 0x21, 0x12, 0x48]) + bytes(ord(c) - 33 for c in reversed(qual)) + \
+        b"XXZkeep\0" + b"PSZctg0_split0+\0" + b"ZMC\x25" + b"SAZchr1,1001,-,6M4S,20,0;\0"
+    assert second == struct.pack("<I", len(body)) + body
+    first = pr.record_from_bytes(data[:int(off[1])])
+    assert first.flag == 0x10 | 0x800 and first.aux[-1] == (b"SA", b"Zchr2,501,+,4S5M1D1M,50,0;\0") and first.aux[-3][1] == b"Zctg0_split1-\0"
+    win.close()
+    rd.close()
+
+
+def test_long_cigar_uses_the_cg_tag(tmp_path):
+    """more than 65535 CIGAR ops: bam_write1's <l_seq>S<ref_len>N placeholder + CG:B,I (both directions)"""
+    n = 70_000
+    l_seq = n  # alternating 1M 1I ... : read bases = n
+    cig = np.empty(n, np.uint32)
+    cig[0::2] = (1 << 4) | 0
+    cig[1::2] = (1 << 4) | 1
+    cig[-1] = (1 << 4) | 0
+    src = pr.Record(0, 10, 60, 0, 0, -1, -1, 0, b"long", [int(x) for x in cig], bytes((l_seq + 1) // 2), l_seq, bytes(l_seq), [(b"rq", b"f" + struct.pack("<f", 1.0))])
+    rb = src.to_bytes()
+    assert struct.unpack_from("<H", rb, 16)[0] == 2  # placeholder on disk
+    path = str(tmp_path / "long.bam")
+    wr = bam.BamWriter(path, "@HD\tVN:1.6\n", ["ctg0"], [500000], level=1)
+    wr.write(rb)
+    wr.close()
+    rd = bam.BamReader(path, 1)
+    win = rd.read_window(10)
+    b = win.batch_data()
+    assert int(b.seg_cigar_off[1]) == n and np.array_equal(b.cigar, cig)  # the real CIGAR reaches the batch
+    res = abi.BatchResult(item_seg=np.zeros(1, np.uint32), item_cseg=np.zeros(1, np.uint32), item_status=np.zeros(1, np.uint8),
+                          item_need_flipped=np.zeros(1, np.uint8), item_mapq=np.array([33], np.uint8), item_chrom_index=np.zeros(1, np.uint32),
+                          item_ref_pos=np.array([77], np.int64), item_cigar_off=np.zeros(1, np.uint64), item_cigar_len=np.array([n], np.uint32),
+                          cigar=cig)
+    ix = abi.IndexData(contig_len=np.array([500000]), contig_seg_off=np.array([0, 1], np.uint32), seg_chrom_index=np.zeros(1, np.uint32),
+                       seg_pos=np.zeros(1), seg_is_fwd_strand=np.ones(1, np.uint8), seg_mapq=np.array([33], np.uint8),
+                       seg_seq_order_start=np.zeros(1), seg_seq_order_end=np.array([500000]), seg_cigar_off=np.array([0, 1], np.uint32),
+                       seg_cigar=np.array(cg.encode("500000M"), np.uint32), chrom_seq=[np.zeros(10, np.uint8)], rev_contig_seq=[None])
+    o, keep = abi.out_from_result(res)
+    data, off, _, _ = win.build_records(o, ix.to_desc(), ["ctg0"], ["chr1"])
+    exp = pr.finish_remapped_alignment_set(["chr1"], src, [pr.lifted_record(pr.record_from_bytes(rb), "ctg0", 0, True, 0, 33, False, 77, [int(x) for x in cig])], False)
+    assert data == exp[0].to_bytes()
+    win.close()
+    rd.close()
+
+
+def test_corrupt_and_malformed_inputs(small_bam, tmp_path):
+    w, path, meta = small_bam
+    raw = bytearray(open(path, "rb").read())
+    bad = str(tmp_path / "crc.bam")
+    raw2 = bytearray(raw)
+    raw2[len(raw2) // 2] ^= 0x5A
+    open(bad, "wb").write(raw2)
+    with pytest.raises(api.PortelloError) as e:
+        rd = bam.BamReader(bad, 2)
+        while rd.read_window(50) is not None:
+            pass
+    assert e.value.status == bam.ERR_IO
+    trunc = str(tmp_path / "trunc.bam")
+    open(trunc, "wb").write(raw[: len(raw) // 3])
+    with pytest.raises(api.PortelloError) as e:
+        rd = bam.BamReader(trunc, 2)
+        while rd.read_window(50) is not None:
+            pass
+    assert e.value.status == bam.ERR_IO
+    with pytest.raises(api.PortelloError) as e:
+        bam.BamReader(str(tmp_path / "missing.bam"))
+    assert e.value.status == bam.ERR_IO
+    # records the reference panics on (split_read.rs:112-151, sa_tag_parser.rs:27-31) are reported as PLO_ERR_DATA
+    for sa in ("ctg0,1,+,10S,60,0;", "ctg0,1,+,5M,60,0;", "nosuch,1,+,5M5S,60,0;", "ctg0,1,+,5M5S,60;", "ctg0,x,+,5M5S,60,0;"):
+        p = str(tmp_path / "sa.bam")
+        wr = bam.BamWriter(p, "@HD\tVN:1.6\n", ["ctg0"], [1000], level=0)
+        wr.write(_sam_record(0, 5, "5S5M", "ACGTACGTAC", "IIIIIIIIII", sa=sa))
+        wr.close()
+        rd = bam.BamReader(p, 1)
+        win = rd.read_window(5)
+        with pytest.raises(api.PortelloError) as e:
+            win.batch_data()
+        assert e.value.status == bam.ERR_DATA, sa
+        with pytest.raises((AssertionError, KeyError, ValueError)):
+            pr.get_seq_order_read_split_segments({"ctg0": 0}, pr.record_from_bytes(_sam_record(0, 5, "5S5M", "ACGTACGTAC", "IIIIIIIIII", sa=sa)))
+        win.close()
+        rd.close()
+
+
+def test_output_header():
+    t = bam.output_header(["chr1", "chr2"], [1000, 2000], "portello", "0.6.1", "portello --ref x.fa")
+    assert t == "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000\n@SQ\tSN:chr2\tLN:2000\n@PG\tPN:portello\tID:portello-0.6.1\tVN:0.6.1\tCL:portello --ref x.fa\n"
+
+
+@pytest.mark.gpu
+def test_bam_to_bam_through_the_hip_engine(oracle, tmp_path):
+    """BAM file -> windows -> plo_liftover_batch (HIP) -> plo_records_build -> BGZF file; the output records are the
+    pure-Python expectation computed from the oracle's alignments, byte for byte, and the output file parses"""
+    w = synth.generate(synth.config("tiny", n_reads=2500, seed=412, split_read_frac=0.2, sorted_reads=True))
+    path = str(tmp_path / "reads.bam")
+    meta = bamsynth.write_read_bam(w, path, level=1)
+    ix = w.index_data()
+    index = api.Index(ix)
+    eng = api.Engine(index)
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    outp = str(tmp_path / "lifted.bam")
+    wr = bam.BamWriter(outp, bam.output_header(rn, [len(s) for s in ix.chrom_seq]), rn, [len(s) for s in ix.chrom_seq], level=0)
+    _, _, recs = bamcheck.read_bam(path)
+    prim = [r for r in recs if not (struct.unpack_from("<H", r, 18)[0] & 0x804)]
+    rd = bam.BamReader(path, 4)
+    ixd = ix.to_desc()
+    all_out, done = [], 0
+    while True:
+        win = rd.read_window(700)
+        if win is None:
+            break
+        if win.n_records:
+            desc = win.batch_desc()
+            lift = eng.liftover_batch_host(desc)
+            data, off, _, _ = win.build_records(lift, ixd, cn, rn, n_threads=4)
+            res = oracle.liftover_batch(ix, win.batch_data(), abi.STAGES_ALL, 4)
+            exp = expected_records(prim[done:done + win.n_records], ix, cn, rn, res)
+            assert [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)] == exp
+            all_out += exp
+            wr.write(data)
+            done += win.n_records
+        win.close()
+    wr.close()
+    assert done == w.n_reads
+    text, refs, out_recs = bamcheck.read_bam(outp)
+    assert out_recs == all_out and text.startswith("@HD\tVN:1.6\tSO:unsorted\n") and [n for n, _ in refs] == rn
+    eng.close()
+    index.close()
