@@ -47,7 +47,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(w, got, budget_s: float = 12.0):
+def cpu_baseline(w, got, budget_s: float = 12.0, ixd=None):
     """Times the oracle (CPU restatement of the reference algorithm: sorted-array block maps + bisection instead of the
     reference's BTreeMap, read segments split evenly over pthreads instead of rayon tasks per 20 Mb window) on a bounded sample
     of the same workload -- blocks of consecutive reads spread evenly over the whole coordinate-sorted read set -- and checks the
@@ -56,7 +56,7 @@ def cpu_baseline(w, got, budget_s: float = 12.0):
 
     pyoracle.build()
     cores = os.cpu_count() or 1
-    ixd = w.index_data()  # host copy of the index
+    ixd = w.index_data() if ixd is None else ixd  # host copy of the index
     n_reads = w.n_reads
     # calibrate on a small slice, then size the sample for ~budget_s of wall time on all cores
     probe = min(n_reads, 2000)
@@ -98,6 +98,82 @@ def cpu_baseline(w, got, budget_s: float = 12.0):
             "single_thread_value": rate1, "seconds": dt}, ok, n_items
 
 
+def pipeline_cpus() -> int:
+    from portello_amd import pipeline
+
+    return pipeline.effective_cpus()
+
+
+def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: int, io_threads: int):
+    """BAM file in -> lifted BAM file out on a bounded sample of the workload (a block of consecutive reads from the middle of
+    the coordinate-sorted read set, written as a real BGZF-compressed read->contig BAM first): BGZF inflate + record parsing +
+    batch construction -> page-locked H2D -> lift kernels -> D2H -> BAM record assembly (tags, flags, reversed seq/qual) ->
+    BGZF output (level 0, what the reference uses for stdout).  Also times the host-buffer entry point alone on the same
+    windows (`pcie_inclusive`: H2D + kernels + D2H, no BAM work)."""
+    import shutil
+    import tempfile
+
+    from portello_amd import bam, bamsynth, pipeline
+
+    n = min(sample_reads, w.n_reads)
+    lo = max(0, (w.n_reads - n) // 2)
+    d = tempfile.mkdtemp(prefix="plo_e2e_")
+    try:
+        inp, outp = os.path.join(d, "reads.bam"), os.path.join(d, "lifted.bam")
+        t0 = time.perf_counter()
+        meta = bamsynth.write_read_bam(w, inp, lo, lo + n, level=1, n_threads=io_threads)
+        t_write = time.perf_counter() - t0
+        cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+        rl = [int(s.numel()) for s in w.chrom_seq]
+        in_bytes = os.path.getsize(inp)
+        pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, window_reads=min(window_reads, 2000), n_workers=1, io_threads=io_threads)  # warm-up
+        st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, window_reads=window_reads, n_workers=n_workers, io_threads=io_threads,
+                                     unassembled_path=os.path.join(d, "unassembled.bam"))
+        e2e = {"value": st.reads / st.seconds, "unit": "reads/s", "reads": st.reads, "seconds": st.seconds, "windows": st.windows,
+               "window_reads": window_reads, "lift_workers": n_workers, "io_threads": io_threads, "host_cpus_reported": os.cpu_count(),
+               "host_cpus_effective": pipeline_cpus(), "records_out": st.records_out,
+               "lifted_records": st.lifted, "unmapped_copies": st.unmapped_copies, "unmapped_passed_through": st.unmapped_passed_through,
+               "input_bam_MB": in_bytes / 1e6, "output_MB": st.bytes_out / 1e6,
+               "stage_busy_s": {"decode+batch": st.read_s, "lift (H2D+kernels+D2H), summed over workers": st.lift_s,
+                                "record assembly, summed over workers": st.build_s, "bgzf write": st.write_s, "device (HIP events)": st.device_ms / 1e3},
+               "sample": f"reads [{lo}, {lo + n}) of the workload as a BGZF level-1 read->contig BAM (synthetic qualities / aux tags, "
+                         f"written in {t_write:.1f} s outside the timed run); output BGZF level 0",
+               "note": "supplementary: one GPU, one node's host cores; `value` of the bench line stays the HBM-resident kernel rate"}
+        # the host-buffer entry point alone on the same windows
+        rd = bam.BamReader(inp, io_threads)
+        eng = api.Engine(index)
+        wins = []
+        while len(wins) < 3:
+            win = rd.read_window(window_reads)
+            if win is None or not win.n_records:
+                break
+            wins.append((win, win.batch_desc()))
+        pcie = None
+        if wins:
+            for win, desc in wins:
+                eng.liftover_batch_host(desc)
+            t0 = time.perf_counter()
+            reads = 0
+            for _ in range(3):
+                for win, desc in wins:
+                    eng.liftover_batch_host(desc)
+                    reads += win.n_records
+            dt = time.perf_counter() - t0
+            b0 = wins[0][1]
+            h2d = int(b0.seq_bytes) + 4 * int(np.ctypeslib.as_array(b0.seg_cigar_off, shape=(int(b0.n_segs) + 1,))[-1]) + 25 * int(b0.n_segs) + 13 * int(b0.n_reads)
+            pcie = {"value": reads / dt, "unit": "reads/s", "reads_per_call": wins[0][0].n_records, "ms_per_call": dt / (3 * len(wins)) * 1e3,
+                    "h2d_MB_per_call": h2d / 1e6, "device_ms_per_call": eng.timing().total_ms,
+                    "note": "plo_liftover_batch on page-locked host arrays, one context, synchronous: H2D of packed bases + CIGARs, kernels, "
+                            "D2H of the dense result"}
+        for win, _ in wins:
+            win.close()
+        eng.close()
+        rd.close()
+        return e2e, pcie
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +185,10 @@ def main():
                     help="N > 1: strong = one read set sharded by windows over the ranks (BASELINE configs[3]); weak = every rank "
                          "its own read set of the full size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("PLO_BENCH_E2E_READS", "60000")),
+                    help="N = 1: size of the BAM-to-BAM end-to-end sample (0 = skip the end_to_end / pcie_inclusive objects)")
+    ap.add_argument("--e2e-window", type=int, default=15000, help="primary records per window of the end-to-end run")
+    ap.add_argument("--e2e-workers", type=int, default=2, help="lift worker threads (contexts) of the end-to-end run")
     ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip rank 0's comparison of the gathered records "
                                                              "with its own single-GPU result (after the timed region)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("PLO_BENCH_WORKERS", "1")),
@@ -389,10 +469,21 @@ def main():
                       ("verify", verify)):
         if obj is not None:
             result[name] = obj
+    ixd_host = None
+    if rank == 0 and world == 1 and dist is None and args.e2e_reads > 0:
+        try:
+            ixd_host = w.index_data()
+            e2e, pcie = end_to_end(w, index, ixd_host, args.e2e_reads, args.e2e_window, args.e2e_workers, max(2, min(64, pipeline_cpus())))
+            result["end_to_end"] = e2e
+            if pcie is not None:
+                result["pcie_inclusive"] = pcie
+        except Exception as e:  # supplementary objects must never hide the measurement
+            log(f"[bench] end_to_end failed: {e!r}")
+            result["end_to_end"] = None
     if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
         try:
             got = devbatch.download(eng, last_out[0])
-            cb, ok, n_checked = cpu_baseline(w, got)
+            cb, ok, n_checked = cpu_baseline(w, got, ixd=ixd_host)
             result["cpu_baseline"] = cb
             result["parity_sample_items"] = n_checked
             result["parity_sample_ok"] = bool(ok)

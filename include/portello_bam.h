@@ -38,10 +38,9 @@
 extern "C" {
 #endif
 
-#define PLO_ERR_IO 7   /* file cannot be opened / read / written, truncated or corrupt BGZF block           */
-#define PLO_ERR_DATA 8 /* a record the reference would panic on: SA segment without aligned bases, SA read
-                          length different from the primary's, unknown SA contig, empty split segment
-                          (split_read.rs:112-151), malformed SA text (sa_tag_parser.rs:27-31)               */
+/* status codes PLO_ERR_IO / PLO_ERR_DATA (portello_liftover.h): PLO_ERR_DATA marks records the reference would panic on --
+   SA segment without aligned bases, SA read length different from the primary's, unknown SA contig, empty split segment
+   (split_read.rs:112-151), malformed SA text (sa_tag_parser.rs:27-31) */
 
 typedef struct plo_bam_reader plo_bam_reader;
 typedef struct plo_bam_writer plo_bam_writer;

@@ -39,7 +39,11 @@ typedef enum plo_status {
     PLO_ERR_HIP = 3,
     PLO_ERR_OUT_OF_MEMORY = 4,
     PLO_ERR_RANGE = 5,    /* coordinate outside the 31-bit BAM range or invalid CIGAR op code            */
-    PLO_ERR_INTERNAL = 6  /* device-side capacity exceeded even in the large-item path                  */
+    PLO_ERR_INTERNAL = 6, /* device-side capacity exceeded even in the large-item path                  */
+    PLO_ERR_IO = 7,       /* portello_bam.h: file cannot be opened / read / written, truncated or corrupt BGZF   */
+    PLO_ERR_DATA = 8      /* input the reference aborts on: an item ended LEN_MISMATCH / PANIC when records are
+                             finished (src/read_alignment_scanner.rs:207-229), or a record whose SA tag it would
+                             panic on (portello_bam.h)                                                  */
 } plo_status;
 
 /* Per-item result status.  The reference expresses these as Option::None / panic!:
@@ -210,7 +214,10 @@ void plo_ctx_destroy(plo_ctx *ctx);
 /* Host buffers in, host (pinned, context-owned) buffers out; synchronous. */
 plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
 /* Device buffers in, device (context-owned) buffers out; returns after the result sizes are known, output is
-   complete on the context's stream (call plo_ctx_sync or synchronise the stream before reading it). */
+   complete on the context's stream (call plo_ctx_sync or synchronise the stream before reading it).
+   The batch is checked on the device before any lift kernel runs: an index outside its array -> PLO_ERR_INVALID_ARG;
+   a coordinate outside the 31-bit BAM range, an op code above 8, a CIGAR spanning more than 2^30 bases or more than
+   2^31 - 1 ops / item weights in the batch -> PLO_ERR_RANGE. */
 plo_status plo_liftover_batch_dev(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -283,10 +290,15 @@ typedef struct plo_sa_out {
 
 plo_status plo_sa_segments_dev(plo_ctx *ctx, const plo_sa_in *in, plo_sa_out *out);
 
-/* Packs the output CIGARs of the last plo_liftover_batch_dev result densely (items in order, no gaps): the kernels
+/* (plo_finish_batch_dev returns PLO_ERR_DATA when an item of the batch ended LEN_MISMATCH or PANIC -- the reference aborts
+   there, :207-229 -- and leaves is_target_region handling (:318-320: no unmapped copy) to the caller.)
+
+   Packs the output CIGARs of the last plo_liftover_batch_dev result densely (items in order, no gaps): the kernels
    allocate them in per-wave slabs, so plo_batch_out.cigar spans up to 16 Ki unused ops per resident wave.  Rewrites
    item_cigar_off, cigar and n_cigar of `out` (and what plo_finish_batch_dev / plo_sa_segments_dev will read).  Worth it
    before the arrays leave the device (plo_liftover_batch does it itself before its device-to-host copy). */
+/* Like the kernels of plo_liftover_batch_dev it completes on the context's stream, not at return: order consumers on that
+   stream (or call plo_ctx_sync). */
 plo_status plo_compact_output_dev(plo_ctx *ctx, plo_batch_out *out);
 
 /* Page-locked host memory for the arrays handed to plo_liftover_batch: copies from such buffers are direct DMA transfers

@@ -17,6 +17,8 @@ PLO_ERR_HIP = 3
 PLO_ERR_OUT_OF_MEMORY = 4
 PLO_ERR_RANGE = 5
 PLO_ERR_INTERNAL = 6
+PLO_ERR_IO = 7
+PLO_ERR_DATA = 8
 
 ITEM_LIFTED = 0
 ITEM_NO_LIFTOVER = 1

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libportello_liftover.so")
 SOURCES = ["engine.hip", "bam_host.cpp"]
-LIBS = ["-lz"]
+LIBS = ["-lz", "-ldl"]
 HEADERS = ["plo_wave.hpp", "lift_core.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp"]
 
 

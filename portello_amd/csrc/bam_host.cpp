@@ -2,6 +2,7 @@
 // (get_seq_order_read_split_segments), BAM record bytes of the lifted alignments, BGZF output.  Plain C++17 + zlib;
 // no GPU code.  Citations are relative to /root/reference; rust-htslib / htslib semantics are restated from their
 // published behaviour (third party, absent from the reference tree).
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -67,6 +69,32 @@ void parallel_ranges(size_t n, int threads, F fn) {
     for (auto &t : th) t.join();
 }
 
+// growable byte buffer that does not zero what it allocates (the inflated stream and the output records are written once, in
+// parallel, right after the allocation)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    bool resize(size_t want) {  // keeps the first min(n, want) bytes
+        if (want > cap) {
+            size_t nc = std::max(want, cap + cap / 2);
+            uint8_t *q = (uint8_t *)realloc(p, nc ? nc : 1);
+            if (!q) return false;
+            p = q;
+            cap = nc;
+        }
+        n = want;
+        return true;
+    }
+};
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads);
+
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
@@ -81,6 +109,43 @@ inline void wr32(uint8_t *p, uint32_t v) {
     p[3] = (uint8_t)(v >> 24);
 }
 
+// DEFLATE engine: zlib always works; libdeflate (whole-buffer API, 2-3x faster inflate, CRC with carry-less multiplies) is
+// used when its shared library is on the machine.  Only the runtime is present in this image (no header), so the five entry
+// points are bound by name -- their signatures are libdeflate's stable public API.
+struct LibDeflate {
+    void *(*alloc_decompressor)() = nullptr;
+    int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_decompressor)(void *) = nullptr;
+    void *(*alloc_compressor)(int) = nullptr;
+    size_t (*deflate_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*free_compressor)(void *) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("PLO_NO_LIBDEFLATE")) return;
+        void *h = nullptr;
+        for (const char *n : {"libdeflate.so.0", "libdeflate.so", "libdeflate.so.1"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        alloc_decompressor = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        deflate_decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        free_decompressor = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        alloc_compressor = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        deflate_compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        free_compressor = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        crc32 = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc_decompressor && deflate_decompress && free_decompressor && alloc_compressor && deflate_compress && free_compressor && crc32;
+    }
+};
+const LibDeflate &libdeflate() {
+    static const LibDeflate *l = new LibDeflate();
+    return *l;
+}
+inline uint32_t fast_crc32(const uint8_t *p, size_t n) {
+    const LibDeflate &ld = libdeflate();
+    return ld.ok ? ld.crc32(0, p, n) : (uint32_t)crc32(0L, p, (uInt)n);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // BGZF input: the file is mapped; blocks are located by their BSIZE fields and inflated in parallel, a chunk at a time
 // ---------------------------------------------------------------------------------------------------------------------
@@ -88,11 +153,11 @@ struct BgzfIn {
     int fd = -1;
     const uint8_t *map = nullptr;
     size_t size = 0, cpos = 0;
-    std::vector<uint8_t> buf;  // inflated bytes not yet consumed: [bpos, buf.size())
+    RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
     size_t bpos = 0;
     int threads = 1;
     bool eof = false;
-    static constexpr size_t CHUNK = 64u << 20;
+    static constexpr size_t CHUNK = 256u << 20;
 
     struct Blk {
         size_t coff, clen, uoff, ulen;
@@ -102,13 +167,13 @@ struct BgzfIn {
     plo_status open(const char *path, int nt) {
         threads = std::max(1, nt);
         fd = ::open(path, O_RDONLY);
-        if (fd < 0) return fail((plo_status)PLO_ERR_IO, std::string("cannot open ") + path);
+        if (fd < 0) return fail(PLO_ERR_IO, std::string("cannot open ") + path);
         struct stat st;
-        if (fstat(fd, &st) != 0) return fail((plo_status)PLO_ERR_IO, "fstat failed");
+        if (fstat(fd, &st) != 0) return fail(PLO_ERR_IO, "fstat failed");
         size = (size_t)st.st_size;
         if (size) {
             void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (p == MAP_FAILED) return fail((plo_status)PLO_ERR_IO, "mmap failed");
+            if (p == MAP_FAILED) return fail(PLO_ERR_IO, "mmap failed");
             map = (const uint8_t *)p;
             madvise(p, size, MADV_SEQUENTIAL);
         }
@@ -130,37 +195,56 @@ struct BgzfIn {
             buf.resize(buf.size() - bpos);
             bpos = 0;
         }
+        const size_t cpos0 = cpos;
         std::vector<Blk> blks;
         size_t u = buf.size();
         const size_t target = std::max(want, CHUNK);
         while (cpos < size && u < target) {
-            if (size - cpos < 28) return fail((plo_status)PLO_ERR_IO, "truncated BGZF block header");
+            if (size - cpos < 28) return fail(PLO_ERR_IO, "truncated BGZF block header");
             const uint8_t *h = map + cpos;
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail((plo_status)PLO_ERR_IO, "not a BGZF block");
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(PLO_ERR_IO, "not a BGZF block");
             uint32_t xlen = rd16(h + 10), bsize = 0;
-            if (12 + (size_t)xlen > size - cpos) return fail((plo_status)PLO_ERR_IO, "truncated BGZF extra field");
+            if (12 + (size_t)xlen > size - cpos) return fail(PLO_ERR_IO, "truncated BGZF extra field");
             for (uint32_t x = 0; x + 4 <= xlen;) {
                 const uint8_t *e = h + 12 + x;
                 uint32_t slen = rd16(e + 2);
                 if (e[0] == 'B' && e[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint32_t)rd16(e + 4) + 1;
                 x += 4 + slen;
             }
-            if (bsize < 12 + xlen + 8 || bsize > size - cpos) return fail((plo_status)PLO_ERR_IO, "corrupt or truncated BGZF block");
+            if (bsize < 12 + xlen + 8 || bsize > size - cpos) return fail(PLO_ERR_IO, "corrupt or truncated BGZF block");
             Blk b;
             b.coff = cpos + 12 + xlen;
             b.clen = bsize - 12 - xlen - 8;
             b.crc = rd32(h + bsize - 8);
             b.ulen = rd32(h + bsize - 4);
             b.uoff = u;
-            if (b.ulen > 65536) return fail((plo_status)PLO_ERR_IO, "BGZF block larger than 64 KiB");
+            if (b.ulen > 65536) return fail(PLO_ERR_IO, "BGZF block larger than 64 KiB");
             u += b.ulen;
             cpos += bsize;
             blks.push_back(b);
         }
         if (cpos >= size) eof = true;
-        buf.resize(u);
+        if (cpos > cpos0) madvise((void *)(map + (cpos0 & ~(size_t)4095)), cpos - (cpos0 & ~(size_t)4095), MADV_WILLNEED);
+        if (!buf.resize(u)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the inflated BAM stream");
         std::atomic<int> bad{0};
         parallel_ranges(blks.size(), threads, [&](size_t lo, size_t hi) {
+            const LibDeflate &ld = libdeflate();
+            if (ld.ok) {
+                void *d = ld.alloc_decompressor();
+                if (!d) {
+                    bad = 1;
+                    return;
+                }
+                for (size_t i = lo; i < hi; ++i) {
+                    const Blk &b = blks[i];
+                    if (b.ulen == 0) continue;
+                    size_t got = 0;
+                    int rc = ld.deflate_decompress(d, map + b.coff, b.clen, buf.data() + b.uoff, b.ulen, &got);
+                    if (rc != 0 || got != b.ulen || ld.crc32(0, buf.data() + b.uoff, b.ulen) != b.crc) bad = 1;
+                }
+                ld.free_decompressor(d);
+                return;
+            }
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit2(&zs, -15) != Z_OK) {
@@ -180,20 +264,64 @@ struct BgzfIn {
             }
             inflateEnd(&zs);
         });
-        if (bad) return fail((plo_status)PLO_ERR_IO, "BGZF block failed to inflate (corrupt data or CRC mismatch)");
+        if (bad) return fail(PLO_ERR_IO, "BGZF block failed to inflate (corrupt data or CRC mismatch)");
         return PLO_OK;
     }
     plo_status read(void *dst, size_t n) {
         plo_status st = fill(n);
         if (st != PLO_OK) return st;
-        if (avail() < n) return fail((plo_status)PLO_ERR_IO, "unexpected end of BAM stream");
+        if (avail() < n) return fail(PLO_ERR_IO, "unexpected end of BAM stream");
         memcpy(dst, buf.data() + bpos, n);
         bpos += n;
         return PLO_OK;
     }
 };
 
-// page-locked when the engine's allocator has a device, plain memory otherwise
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads) {
+    const size_t piece = 4u << 20;
+    const size_t np = (n + piece - 1) / piece;
+    parallel_for(np, std::min<int>(threads, 16), [&](size_t i) {
+        size_t o = i * piece;
+        memcpy(dst + o, src + o, std::min(piece, n - o));
+    });
+}
+
+// Page-locked when the engine's allocator has a device, plain memory otherwise.  Pinning costs far more than the copy it
+// speeds up, so page-locked blocks go back to a process-wide pool when a window is freed and the next window reuses them.
+struct PinPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> blocks;
+    void *take(size_t want, size_t &cap) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].second >= want && blocks[i].second <= 4 * want + (1u << 20) && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void *p = blocks[best].first;
+        cap = blocks[best].second;
+        blocks.erase(blocks.begin() + (ptrdiff_t)best);
+        return p;
+    }
+    void give(void *p, size_t cap) {
+        std::lock_guard<std::mutex> g(mu);
+        if (blocks.size() >= 256) {  // bounded: drop the smallest
+            size_t k = 0;
+            for (size_t i = 1; i < blocks.size(); ++i)
+                if (blocks[i].second < blocks[k].second) k = i;
+            if (blocks[k].second >= cap) {
+                plo_host_free(p);
+                return;
+            }
+            plo_host_free(blocks[k].first);
+            blocks.erase(blocks.begin() + (ptrdiff_t)k);
+        }
+        blocks.emplace_back(p, cap);
+    }
+};
+PinPool &pin_pool() {
+    static PinPool *p = new PinPool();  // never destroyed: the HIP runtime may be gone by the time static destructors run
+    return *p;
+}
 struct HostBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -202,8 +330,12 @@ struct HostBuf {
         if (bytes <= cap) return p;
         release();
         size_t want = bytes + bytes / 8 + 64;
-        void *q = nullptr;
-        if (plo_host_alloc(want, &q) == PLO_OK && q) {
+        size_t got = 0;
+        void *q = pin_pool().take(want, got);
+        if (q) {
+            pinned = true;
+            want = got;
+        } else if (plo_host_alloc(want, &q) == PLO_OK && q) {
             pinned = true;
         } else {
             q = malloc(want);
@@ -215,7 +347,7 @@ struct HostBuf {
     }
     void release() {
         if (p) {
-            if (pinned) plo_host_free(p);
+            if (pinned) pin_pool().give(p, cap);
             else free(p);
         }
         p = nullptr;
@@ -390,18 +522,21 @@ struct plo_bam_reader {
 struct plo_bam_window {
     const plo_bam_reader *reader = nullptr;
     int threads = 1;
-    std::vector<uint8_t> rec;       // primary records, block_size prefixed
-    std::vector<uint64_t> rec_off;  // [n + 1]
+    RawBuf raw;                     // the window's stretch of the BAM stream (all records)
+    std::vector<uint64_t> rec_at;   // [n] offset (of the block_size word) of every primary record inside raw
     std::vector<uint8_t> unmapped;
     uint32_t n_unmapped = 0;
     // batch (plo_batch_in) arrays
     HostBuf b_rev, b_len, b_soff, b_seq, b_seg_read, b_seg_contig, b_seg_pos, b_seg_fwd, b_coff, b_cigar, b_flags, b_qual, b_qoff;
     std::vector<uint32_t> read_seg_off;  // [n + 1] first segment of every read
     // output records
-    std::vector<uint8_t> out;
+    RawBuf out;
     std::vector<uint64_t> out_off;
-    uint32_t n_records() const { return (uint32_t)(rec_off.empty() ? 0 : rec_off.size() - 1); }
-    Rec record(uint32_t i) const { return Rec{rec.data() + rec_off[i] + 4, (uint32_t)(rec_off[i + 1] - rec_off[i] - 4)}; }
+    uint32_t n_records() const { return (uint32_t)rec_at.size(); }
+    Rec record(uint32_t i) const {
+        const uint8_t *p = raw.data() + rec_at[i];
+        return Rec{p + 4, rd32(p)};
+    }
 };
 
 extern "C" {
@@ -422,7 +557,7 @@ plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out) {
     if (st != PLO_OK) return bail(st);
     uint8_t hd[8];
     if ((st = r->in.read(hd, 8)) != PLO_OK) return bail(st);
-    if (memcmp(hd, "BAM\1", 4) != 0) return bail(fail((plo_status)PLO_ERR_IO, "not a BAM file (bad magic)"));
+    if (memcmp(hd, "BAM\1", 4) != 0) return bail(fail(PLO_ERR_IO, "not a BAM file (bad magic)"));
     uint32_t l_text = rd32(hd + 4);
     r->text.resize(l_text);
     if (l_text && (st = r->in.read(&r->text[0], l_text)) != PLO_OK) return bail(st);
@@ -436,7 +571,7 @@ plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out) {
         if (l_name && (st = r->in.read(&name[0], l_name)) != PLO_OK) return bail(st);
         while (!name.empty() && name.back() == '\0') name.pop_back();
         if ((st = r->in.read(w, 4)) != PLO_OK) return bail(st);
-        if (r->label_to_index.count(name)) return bail(fail((plo_status)PLO_ERR_DATA, "duplicate reference name in BAM header: " + name));  // chrom_list.rs:47
+        if (r->label_to_index.count(name)) return bail(fail(PLO_ERR_DATA, "duplicate reference name in BAM header: " + name));  // chrom_list.rs:47
         r->label_to_index[name] = i;
         r->names.push_back(name);
         r->lens.push_back(rd32(w));
@@ -469,44 +604,49 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     plo_bam_window *w = new plo_bam_window();
     w->reader = r;
     w->threads = r->threads;
-    w->rec_off.push_back(0);
     plo_status st = PLO_OK;
-    while (w->n_records() < max_records) {
-        if ((st = r->in.fill(4)) != PLO_OK) break;
-        if (r->in.avail() == 0) break;  // end of file
-        if (r->in.avail() < 4) {
-            st = fail((plo_status)PLO_ERR_IO, "truncated BAM record");
+    // walk the records of the inflated stream (no copies), then take the whole stretch with one parallel copy
+    size_t at = 0;  // offset from r->in.bpos
+    std::vector<uint64_t> unm_at;
+    while (w->rec_at.size() < max_records) {
+        if (r->in.avail() < at + 4 && (st = r->in.fill(at + 4)) != PLO_OK) break;
+        if (r->in.avail() == at) break;  // end of file
+        if (r->in.avail() < at + 4) {
+            st = fail(PLO_ERR_IO, "truncated BAM record");
             break;
         }
-        uint32_t bs = rd32(r->in.buf.data() + r->in.bpos);
+        uint32_t bs = rd32(r->in.buf.data() + r->in.bpos + at);
         if (bs < 32) {
-            st = fail((plo_status)PLO_ERR_IO, "BAM record shorter than its fixed fields");
+            st = fail(PLO_ERR_IO, "BAM record shorter than its fixed fields");
             break;
         }
-        if ((st = r->in.fill(4 + (size_t)bs)) != PLO_OK) break;
-        if (r->in.avail() < 4 + (size_t)bs) {
-            st = fail((plo_status)PLO_ERR_IO, "truncated BAM record");
+        if (r->in.avail() < at + 4 + (size_t)bs && (st = r->in.fill(at + 4 + (size_t)bs)) != PLO_OK) break;
+        if (r->in.avail() < at + 4 + (size_t)bs) {
+            st = fail(PLO_ERR_IO, "truncated BAM record");
             break;
         }
-        const uint8_t *p = r->in.buf.data() + r->in.bpos;
+        const uint8_t *p = r->in.buf.data() + r->in.bpos + at;
         Rec rec{p + 4, bs};
         if (!rec.layout_ok()) {
-            st = fail((plo_status)PLO_ERR_IO, "BAM record fields exceed its block_size");
+            st = fail(PLO_ERR_IO, "BAM record fields exceed its block_size");
             break;
         }
         uint16_t flag = rec.flag();
-        if (flag & 0x4) {  // scan_unmapped_reads :551-555
-            w->unmapped.insert(w->unmapped.end(), p, p + 4 + bs);
-            ++w->n_unmapped;
-        } else if (!(flag & 0x800)) {  // :404 supplementary records are reached through the primary's SA tag
-            w->rec.insert(w->rec.end(), p, p + 4 + bs);
-            w->rec_off.push_back(w->rec.size());
-        }
-        r->in.bpos += 4 + (size_t)bs;
+        if (flag & 0x4) unm_at.push_back(at);                 // scan_unmapped_reads :551-555
+        else if (!(flag & 0x800)) w->rec_at.push_back(at);    // :404 supplementary records are reached through the primary's SA tag
+        at += 4 + (size_t)bs;
     }
+    if (st == PLO_OK && !w->raw.resize(at)) st = fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for a window of records");
     if (st != PLO_OK) {
         delete w;
         return st;
+    }
+    parallel_copy(w->raw.data(), r->in.buf.data() + r->in.bpos, at, r->threads);
+    r->in.bpos += at;
+    for (uint64_t u : unm_at) {
+        const uint8_t *p = w->raw.data() + u;
+        w->unmapped.insert(w->unmapped.end(), p, p + 4 + rd32(p));
+        ++w->n_unmapped;
     }
     *out = w;
     return PLO_OK;
@@ -558,7 +698,7 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
     if (sa) {
         if (sa[2] != 'Z') {
             err = "SA aux tag is not a string";  // unexpected_aux_val_err (aux/mod.rs:80-82)
-            return (plo_status)PLO_ERR_DATA;
+            return PLO_ERR_DATA;
         }
         const char *s = (const char *)sa + 3, *e = (const char *)sa + fl - 1;
         uint32_t seg_index = 0;
@@ -587,7 +727,7 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
             }
             if (too_many || nf != 6) {
                 err = "Unexpected segment in bam SA tag: " + std::string(s, se);
-                return (plo_status)PLO_ERR_DATA;
+                return PLO_ERR_DATA;
             }
             SaSeg g;
             std::string rname(f[0], fe[0]);
@@ -596,7 +736,7 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
             if (!parse_int(f[1], fe[1], pos1) || !parse_cigar_text(f[3], fe[3], g.cigar) || !parse_uint(f[4], fe[4], mq) || mq > 255 ||
                 !parse_int(f[5], fe[5], nm) || nm < INT32_MIN || nm > INT32_MAX) {
                 err = "malformed SA segment: " + std::string(s, se);
-                return (plo_status)PLO_ERR_DATA;
+                return PLO_ERR_DATA;
             }
             g.pos = pos1 - 1;
             g.fwd = (fe[2] - f[2] == 1 && f[2][0] == '+');
@@ -606,13 +746,13 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
             for (uint32_t c : g.cigar) aligned |= op_is_match(c);
             if (!aligned) {  // :112-115
                 err = "Bam record split segment id unaligned in read " + std::string((const char *)rec.qname());
-                return (plo_status)PLO_ERR_DATA;
+                return PLO_ERR_DATA;
             }
             uint64_t s0, e0, sz;
             read_clip_positions(g.cigar.data(), g.cigar.size(), s0, e0, sz);
             if (sz != rsize) {  // assert_eq!(primary_read_size, read_size) :118
                 err = "SA segment read length differs from the primary record's in read " + std::string((const char *)rec.qname());
-                return (plo_status)PLO_ERR_DATA;
+                return PLO_ERR_DATA;
             }
             g.so_start = g.fwd ? s0 : sz - e0;
             g.so_end = g.fwd ? e0 : sz - s0;
@@ -620,7 +760,7 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
             if (it == rd->label_to_index.end()) {  // :121-130
                 err = "In read '" + std::string((const char *)rec.qname()) + "', the SA aux tag describes a split read mapped to " + rname +
                       ", which is not found in the input header";
-                return (plo_status)PLO_ERR_DATA;
+                return PLO_ERR_DATA;
             }
             g.contig = it->second;
             out.push_back(std::move(g));
@@ -633,7 +773,7 @@ plo_status split_segments(const plo_bam_reader *rd, const Rec &rec, std::vector<
     for (const SaSeg &g : out)
         if (g.so_start >= g.so_end) {  // :146-152
             err = "Can't parse consistent split read information from SA tag format in read: " + std::string((const char *)rec.qname());
-            return (plo_status)PLO_ERR_DATA;
+            return PLO_ERR_DATA;
         }
     return PLO_OK;
 }
@@ -672,7 +812,7 @@ extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batc
         n_seqb[i + 1] = (rec.l_seq() + 1) / 2;
         n_qual[i + 1] = rec.l_seq();
     });
-    if (bad) return fail((plo_status)PLO_ERR_DATA, errs[err_rec.load()]);
+    if (bad) return fail(PLO_ERR_DATA, errs[err_rec.load()]);
     for (uint32_t i = 0; i < n; ++i) {
         n_seg[i + 1] += n_seg[i];
         n_ops[i + 1] += n_ops[i];
@@ -788,14 +928,31 @@ uint8_t *put_decimal(uint8_t *p, uint64_t v) {
 // every other code (=, IUPAC ambiguity) becomes N; an odd length leaves the last low nibble 0
 void revcomp_packed(const uint8_t *src, uint32_t n, uint8_t *dst) {
     static const uint8_t comp[16] = {15, 8, 4, 15, 2, 15, 15, 15, 1, 15, 15, 15, 15, 15, 15, 15};
-    auto get = [&](uint32_t j) -> uint8_t { return (j & 1) ? (src[j >> 1] & 15) : (src[j >> 1] >> 4); };
+    struct Tables {
+        uint8_t swap[256];  // both nibbles complemented and exchanged (even length: byte k of the output = swap[byte nb-1-k])
+        uint8_t hi[256];    // complemented high nibble, in the high position
+        uint8_t lo[256];    // complemented low nibble, in the low position
+        Tables() {
+            for (int x = 0; x < 256; ++x) {
+                swap[x] = (uint8_t)((comp[x & 15] << 4) | comp[x >> 4]);
+                hi[x] = (uint8_t)(comp[x >> 4] << 4);
+                lo[x] = comp[x & 15];
+            }
+        }
+    };
+    static const Tables T;
     const uint32_t nb = (n + 1) / 2;
-    for (uint32_t b = 0; b < nb; ++b) {
-        uint32_t i0 = 2 * b, i1 = 2 * b + 1;
-        uint8_t hi = comp[get(n - 1 - i0)];
-        uint8_t lo = i1 < n ? comp[get(n - 1 - i1)] : 0;
-        dst[b] = (uint8_t)((hi << 4) | lo);
+    if (!(n & 1)) {
+        for (uint32_t b = 0; b < nb; ++b) dst[b] = T.swap[src[nb - 1 - b]];
+        return;
     }
+    // odd length: output byte b = comp(high nibble of source byte m) | comp(low nibble of source byte m - 1), m = nb - 1 - b;
+    // the last output byte keeps a zero low nibble
+    for (uint32_t b = 0; b + 1 < nb; ++b) {
+        const uint32_t m = nb - 1 - b;
+        dst[b] = (uint8_t)(T.hi[src[m]] | T.lo[src[m - 1]]);
+    }
+    dst[nb - 1] = T.hi[src[0]];
 }
 
 struct AuxPlan {  // aux bytes of the clone after remove_aux_if_found NM, SA, PS, ZM (first occurrence of each, :105-118)
@@ -899,7 +1056,7 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
     }
     for (uint32_t i = 0; i < ni; ++i)
         if (lift->item_status[i] == PLO_ITEM_LEN_MISMATCH || lift->item_status[i] == PLO_ITEM_PANIC)
-            return fail((plo_status)PLO_ERR_DATA, "an item ended LEN_MISMATCH / PANIC: the reference aborts here (src/read_alignment_scanner.rs:207-229)");
+            return fail(PLO_ERR_DATA, "an item ended LEN_MISMATCH / PANIC: the reference aborts here (src/read_alignment_scanner.rs:207-229)");
 
     struct ItemInfo {
         uint32_t flag;
@@ -969,7 +1126,7 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
         read_bytes[r + 1] += read_bytes[r];
         read_nrec[r + 1] += read_nrec[r];
     }
-    w->out.resize(read_bytes[n]);
+    if (!w->out.resize(read_bytes[n])) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the output records");
     w->out_off.assign((size_t)read_nrec[n] + 1, 0);
     std::atomic<uint32_t> n_lifted{0}, n_unm{0};
     // pass 2: bytes
@@ -984,8 +1141,7 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
             if (flip) {
                 revcomp_packed(rec.seq(), l_seq, q);
                 q += seqb;
-                const uint8_t *ql = rec.qual();
-                for (uint32_t j = 0; j < l_seq; ++j) q[j] = ql[l_seq - 1 - j];
+                std::reverse_copy(rec.qual(), rec.qual() + l_seq, q);
                 return q + l_seq;
             }
             memcpy(q, rec.seq(), (size_t)seqb + l_seq);
@@ -1135,68 +1291,136 @@ extern "C" void plo_bam_free_text(char *text) { free(text); }
 struct plo_bam_writer {
     int fd = -1;
     int level = 0, threads = 1;
-    std::vector<uint8_t> pend;  // bytes not yet cut into blocks
+    bool seekable = false;
+    uint64_t file_off = 0;
+    std::vector<uint8_t> pend;  // tail of the stream that does not fill a block yet (< BLOCK bytes)
+    RawBuf scratch;
     static constexpr size_t BLOCK = 0xff00;  // htslib's BGZF_BLOCK_SIZE
-    plo_status flush(bool all);
+    plo_status emit(const uint8_t *src, size_t n);  // n bytes -> ceil(n / BLOCK) BGZF blocks, written out
+    plo_status put(const uint8_t *src, size_t n);
 };
 
-plo_status plo_bam_writer::flush(bool all) {
-    size_t nblk = pend.size() / BLOCK + ((all && pend.size() % BLOCK) ? 1 : 0);
+// Blocks are built in parallel, each in its own slot of a scratch buffer, and written with positional writes from several
+// threads when the output is a regular file (page-cache copies scale with the writers), in order otherwise (pipe / stdout).
+plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
+    const size_t nblk = (n + BLOCK - 1) / BLOCK;
     if (!nblk) return PLO_OK;
-    const size_t slot = 18 + BLOCK + 1024 + 8;  // stored deflate: 5 bytes per 64 KiB; compressed: bound below 64 KiB + slack
-    std::vector<uint8_t> outb(nblk * slot);
+    const size_t slot = level == 0 ? 18 + 5 + BLOCK + 8 : 18 + BLOCK + 1024 + 8;
+    if (!scratch.resize(nblk * slot)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for BGZF output blocks");
     std::vector<uint32_t> olen(nblk, 0);
     std::atomic<int> bad{0};
-    parallel_for(nblk, threads, [&](size_t b) {
-        const uint8_t *src = pend.data() + b * BLOCK;
-        size_t n = std::min(BLOCK, pend.size() - b * BLOCK);
-        uint8_t *o = outb.data() + b * slot;
-        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        memcpy(o, hdr, 16);
-        size_t clen = 0;
-        if (level == 0) {
-            o[18] = 1;  // final stored block
-            wr16(o + 19, (uint16_t)n);
-            wr16(o + 21, (uint16_t)~n);
-            memcpy(o + 23, src, n);
-            clen = 5 + n;
-        } else {
-            z_stream zs;
-            memset(&zs, 0, sizeof(zs));
-            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-                bad = 1;
-                return;
-            }
-            zs.next_in = (Bytef *)src;
-            zs.avail_in = (uInt)n;
-            zs.next_out = o + 18;
-            zs.avail_out = (uInt)(slot - 18 - 8);
-            int rc = deflate(&zs, Z_FINISH);
-            clen = zs.total_out;
-            deflateEnd(&zs);
-            if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) {
-                bad = 1;
-                return;
-            }
+    uint8_t *outb = scratch.data();
+    parallel_ranges(nblk, threads, [&](size_t lo, size_t hi) {
+        const LibDeflate &ld = libdeflate();
+        void *lc = (level > 0 && ld.ok) ? ld.alloc_compressor(level) : nullptr;
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (level > 0 && !lc && deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            bad = 1;
+            return;
         }
-        wr16(o + 16, (uint16_t)(18 + clen + 8 - 1));
-        wr32(o + 18 + clen, (uint32_t)crc32(0L, src, (uInt)n));
-        wr32(o + 18 + clen + 4, (uint32_t)n);
-        olen[b] = (uint32_t)(18 + clen + 8);
+        for (size_t b = lo; b < hi; ++b) {
+            const uint8_t *in = src + b * BLOCK;
+            const size_t len = std::min(BLOCK, n - b * BLOCK);
+            uint8_t *o = outb + b * slot;
+            static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            memcpy(o, hdr, 16);
+            size_t clen = 0;
+            if (level == 0) {
+                o[18] = 1;  // final stored block
+                wr16(o + 19, (uint16_t)len);
+                wr16(o + 21, (uint16_t)~len);
+                memcpy(o + 23, in, len);
+                clen = 5 + len;
+            } else if (lc) {
+                clen = ld.deflate_compress(lc, in, len, o + 18, slot - 18 - 8);
+                if (clen == 0 || 18 + clen + 8 > 65536) {
+                    bad = 1;
+                    break;
+                }
+            } else {
+                deflateReset(&zs);
+                zs.next_in = (Bytef *)in;
+                zs.avail_in = (uInt)len;
+                zs.next_out = o + 18;
+                zs.avail_out = (uInt)(slot - 18 - 8);
+                int rc = deflate(&zs, Z_FINISH);
+                clen = zs.total_out;
+                if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) {
+                    bad = 1;
+                    break;
+                }
+            }
+            wr16(o + 16, (uint16_t)(18 + clen + 8 - 1));
+            wr32(o + 18 + clen, fast_crc32(in, len));
+            wr32(o + 18 + clen + 4, (uint32_t)len);
+            olen[b] = (uint32_t)(18 + clen + 8);
+        }
+        if (lc) ld.free_compressor(lc);
+        else if (level > 0) deflateEnd(&zs);
     });
-    if (bad) return fail((plo_status)PLO_ERR_IO, "BGZF block compression failed");
-    for (size_t b = 0; b < nblk; ++b) {
-        const uint8_t *o = outb.data() + b * slot;
-        size_t left = olen[b];
-        while (left) {
-            ssize_t wr = ::write(fd, o, left);
-            if (wr <= 0) return fail((plo_status)PLO_ERR_IO, "write failed");
-            o += wr;
-            left -= (size_t)wr;
+    if (bad) return fail(PLO_ERR_IO, "BGZF block compression failed");
+    std::vector<uint64_t> at(nblk + 1, 0);
+    for (size_t b = 0; b < nblk; ++b) at[b + 1] = at[b] + olen[b];
+    if (seekable) {
+        // runs of blocks that are contiguous in the scratch buffer (level 0: all full blocks) go out with one pwrite each
+        const size_t group = 128;
+        const size_t ng = (nblk + group - 1) / group;
+        parallel_for(ng, std::min(threads, 16), [&](size_t g) {
+            size_t b = g * group, e = std::min(nblk, b + group);
+            while (b < e) {
+                size_t r = b + 1;
+                while (r < e && olen[r - 1] == slot) ++r;  // block r starts right behind block r - 1
+                const uint8_t *p = outb + b * slot;
+                size_t left = (size_t)(at[r] - at[b]);
+                uint64_t off = file_off + at[b];
+                while (left) {
+                    ssize_t k = pwrite(fd, p, left, (off_t)off);
+                    if (k <= 0) {
+                        bad = 1;
+                        return;
+                    }
+                    p += k;
+                    off += (uint64_t)k;
+                    left -= (size_t)k;
+                }
+                b = r;
+            }
+        });
+        if (bad) return fail(PLO_ERR_IO, "write failed");
+    } else {
+        for (size_t b = 0; b < nblk; ++b) {
+            const uint8_t *p = outb + b * slot;
+            size_t left = olen[b];
+            while (left) {
+                ssize_t k = ::write(fd, p, left);
+                if (k <= 0) return fail(PLO_ERR_IO, "write failed");
+                p += k;
+                left -= (size_t)k;
+            }
         }
     }
-    size_t used = std::min(pend.size(), nblk * BLOCK);
-    pend.erase(pend.begin(), pend.begin() + (ptrdiff_t)used);
+    file_off += at[nblk];
+    return PLO_OK;
+}
+
+plo_status plo_bam_writer::put(const uint8_t *src, size_t n) {
+    if (!pend.empty()) {  // complete the open block first
+        size_t take = std::min(n, BLOCK - pend.size());
+        pend.insert(pend.end(), src, src + take);
+        src += take;
+        n -= take;
+        if (pend.size() < BLOCK) return PLO_OK;
+        plo_status st = emit(pend.data(), pend.size());
+        pend.clear();
+        if (st != PLO_OK) return st;
+    }
+    const size_t full = n / BLOCK * BLOCK;
+    if (full) {
+        plo_status st = emit(src, full);  // straight from the caller's bytes
+        if (st != PLO_OK) return st;
+    }
+    pend.insert(pend.end(), src + full, src + n);
     return PLO_OK;
 }
 
@@ -1210,10 +1434,11 @@ extern "C" plo_status plo_bam_writer_open(const char *path, const char *header_t
     w->fd = strcmp(path, "-") == 0 ? dup(1) : ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (w->fd < 0) {
         delete w;
-        return fail((plo_status)PLO_ERR_IO, std::string("cannot create ") + path);
+        return fail(PLO_ERR_IO, std::string("cannot create ") + path);
     }
+    w->seekable = lseek(w->fd, 0, SEEK_CUR) != (off_t)-1 && strcmp(path, "-") != 0;
     size_t lt = header_text ? strlen(header_text) : 0;
-    std::vector<uint8_t> &p = w->pend;
+    std::vector<uint8_t> p;
     p.insert(p.end(), {'B', 'A', 'M', 1});
     uint8_t b4[4];
     wr32(b4, (uint32_t)lt);
@@ -1229,7 +1454,7 @@ extern "C" plo_status plo_bam_writer_open(const char *path, const char *header_t
         wr32(b4, ref_lens[i]);
         p.insert(p.end(), b4, b4 + 4);
     }
-    plo_status st = w->flush(true);  // the header ends its own block(s), as htslib's bam_hdr_write + bgzf_flush do
+    plo_status st = w->emit(p.data(), p.size());  // the header ends its own block(s), as htslib's bam_hdr_write + bgzf_flush do
     if (st != PLO_OK) {
         ::close(w->fd);
         delete w;
@@ -1241,16 +1466,17 @@ extern "C" plo_status plo_bam_writer_open(const char *path, const char *header_t
 
 extern "C" plo_status plo_bam_write(plo_bam_writer *w, const uint8_t *bytes, uint64_t n) {
     if (!w || (n && !bytes)) return PLO_ERR_INVALID_ARG;
-    w->pend.insert(w->pend.end(), bytes, bytes + n);
-    if (w->pend.size() >= plo_bam_writer::BLOCK * 64) return w->flush(false);
-    return PLO_OK;
+    return w->put(bytes, (size_t)n);
 }
 
 extern "C" plo_status plo_bam_writer_close(plo_bam_writer *w) {
     if (!w) return PLO_ERR_INVALID_ARG;
-    plo_status st = w->flush(true);
+    plo_status st = w->pend.empty() ? PLO_OK : w->emit(w->pend.data(), w->pend.size());
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (st == PLO_OK && ::write(w->fd, eof_block, 28) != 28) st = fail((plo_status)PLO_ERR_IO, "write failed");
+    if (st == PLO_OK) {
+        ssize_t k = w->seekable ? pwrite(w->fd, eof_block, 28, (off_t)w->file_off) : ::write(w->fd, eof_block, 28);
+        if (k != 28) st = fail(PLO_ERR_IO, "write failed");
+    }
     ::close(w->fd);
     delete w;
     return st;

@@ -46,10 +46,15 @@ using namespace plo;
 #define PLO_SEG_LANES 8  // measured on MI355X (wgs30x enumerate pass): 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms
 #endif
 constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 2 : 32 / SEG_LANES;
-__global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen) {
+// It is also the boundary check of the device path (the kernels index with what the batch says): bit 0 of *err = an index
+// outside its array (PLO_ERR_INVALID_ARG), bit 1 = a coordinate outside the 31-bit BAM range, an op code above 8 or a CIGAR
+// spanning more than 2^30 bases (PLO_ERR_RANGE) -- what the reference's types rule out by construction.
+enum { VERR_INDEX = 1u, VERR_RANGE = 2u };
+__global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen, uint32_t *err) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = t / SEG_LANES, sub = t % SEG_LANES;
     const bool live = s < bt.n_segs;
+    uint32_t bad = 0;
     // Two dependent chains, issued side by side so that the kernel is three memory round trips deep instead of five:
     //   CIGAR offsets -> ops (reference span)   and   contig -> its segment range -> segment intervals (overlap test,
     //   one contig segment per lane of the group)
@@ -60,6 +65,23 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
         c1 = bt.seg_cigar_off[s + 1];
         contig = bt.seg_contig[s];
         r_start = (long long)bt.seg_pos[s];
+        if (c1 < c0 || c1 > 0x7fffffffu) {  // (ops are indexed with int: more than 2^31 - 1 of them cannot be addressed)
+            bad |= c1 < c0 ? VERR_INDEX : VERR_RANGE;
+            c1 = c0;
+        }
+        if (r_start < 0 || r_start > 0x7ffffff0LL) bad |= VERR_RANGE;
+        if (contig >= ix.n_contigs) bad |= VERR_INDEX;
+        if (sub == 0) {
+            const uint32_t rd = bt.seg_read[s];
+            if (rd >= bt.n_reads) {
+                bad |= VERR_INDEX;
+            } else {
+                const unsigned long long len = bt.read_seq_len[rd];
+                const unsigned long long need = bt.seq_fmt == PLO_SEQ_BAM4 ? (len + 1) / 2 : len;
+                const unsigned long long off = bt.read_seq_off[rd];
+                if (off > bt.seq_bytes || need > bt.seq_bytes - off) bad |= VERR_INDEX;
+            }
+        }
     }
     uint32_t g0 = 0, g1 = 0;
     if (live && contig < ix.n_contigs) {
@@ -72,8 +94,10 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
 #pragma unroll
         for (uint32_t u = 0; u < SEG_UNROLL; ++u) c[u] = (i + SEG_LANES * u < c1) ? bt.cigar[i + SEG_LANES * u] : 0u;  // 0 = M of length 0
 #pragma unroll
-        for (uint32_t u = 0; u < SEG_UNROLL; ++u)
+        for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
             if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
+            if ((c[u] & 15u) > 8u) bad |= VERR_RANGE;
+        }
     }
     // the first interval of every lane is fetched before the reduction needs the ops
     const uint32_t gl = g0 + sub;
@@ -84,6 +108,8 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     }
 #pragma unroll
     for (uint32_t d = 1; d < SEG_LANES; d <<= 1) part += __shfl_xor(part, (int)d, 64);
+    if (part > 0x3fffffffLL) bad |= VERR_RANGE;
+    if (bad) atomicOr(err, bad);
     const long long r_end = r_start + part;
     // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end (int_range.rs:56-58)
     uint32_t n = (gl < g1 && r_end >= cs && r_start < ce) ? 1u : 0u;
@@ -117,10 +143,24 @@ __global__ void k_map_build(const uint32_t *seg_cigar, const uint32_t *seg_cigar
 }
 
 // explicit item list: thread per item
-__global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *in_seg, const uint32_t *in_cseg) {
+__global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *in_seg, const uint32_t *in_cseg,
+                            uint32_t *err) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= wk.n_items) return;
     uint32_t seg = in_seg[i];
+    {   // the pair must exist: a read segment of the batch and a contig segment of ITS contig
+        bool ok = seg < bt.n_segs;
+        if (ok) {
+            uint32_t contig = bt.seg_contig[seg];
+            ok = contig < ix.n_contigs && in_cseg[i] < ix.contig_seg_off[contig + 1] - ix.contig_seg_off[contig];
+        }
+        if (!ok) {  // the host discards the batch before any lift kernel runs; the scans in between only need a class and a weight
+            atomicOr(err, (uint32_t)VERR_INDEX);
+            wk.item_cls[i] = 2u;
+            wk.item_nin[i] = 0u;
+            return;
+        }
+    }
     build_item_desc(ix, bt, wk, stages, i, seg, in_cseg[i], segment_ref_len(bt, seg));
 }
 
@@ -534,7 +574,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo;
+    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len;
     // outputs (device)
@@ -545,6 +585,7 @@ struct plo_ctx {
     HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_big = false, ev_mid = false;
+    uint64_t dense_total = 0;
     plo_timing timing{};
     unsigned long long phase_cycles[12] = {0};
     // tuning
@@ -800,7 +841,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
                       &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
-                      &c->counters, &c->big_list, &c->huge_list, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
+                      &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
@@ -888,23 +929,33 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     // ---- items: count -> scan -> resolve descriptors -> scan op counts -> tile bounds ----
     uint32_t n_items = 0;
-    HIP_TRY(c, c->h_counters.ensure(64 * 8 + CNT_N * 8));
+    HIP_TRY(c, c->h_counters.ensure(64 * 8 + CNT_N * 8 + 64));
     uint32_t ns = in->n_segs;
-    if (in->item_seg) {
-        n_items = in->n_items;
-    } else {
+    HIP_TRY(c, c->verr.ensure(16));
+    HIP_TRY(c, hipMemsetAsync(c->verr.p, 0, 16, st));
+    auto verr_status = [&](uint32_t flags) -> plo_status {
+        if (flags & VERR_INDEX) {
+            c->err = "plo_batch_in: an index points outside its array (seg_read / seg_contig / seg_cigar_off / read_seq_off / item_seg / item_cseg)";
+            return PLO_ERR_INVALID_ARG;
+        }
+        c->err = "plo_batch_in: coordinate outside the 31-bit BAM range, CIGAR op code above 8, or a CIGAR spanning more than 2^30 bases";
+        return PLO_ERR_RANGE;
+    };
+    {   // k_seg_count always runs: it is the boundary check of the batch (and counts the items unless the caller lists them)
         HIP_TRY(c, c->seg_cnt.ensure((size_t)std::max(1u, ns) * 4));
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
         if (ns)
             hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt,
-                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>());
+                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>(), c->verr.as<uint32_t>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
         uint32_t *h = c->h_counters.as<uint32_t>();
         HIP_TRY(c, hipMemcpyAsync(h, c->seg_off.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h + 1, c->verr.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        n_items = h[0];
+        if (h[1]) return verr_status(h[1]);
+        n_items = in->item_seg ? in->n_items : h[0];
     }
     size_t ni = std::max(1u, n_items);
     HIP_TRY(c, c->item_seg.ensure(ni * 4));
@@ -994,7 +1045,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     if (n_items) {
         if (in->item_seg)
             hipLaunchKernelGGL(k_item_desc, dim3((n_items + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages, in->item_seg,
-                               in->item_cseg);
+                               in->item_cseg, c->verr.as<uint32_t>());
         else
             hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages,
                                (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>());
@@ -1038,7 +1089,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         // one copy: [0] max weight, [2..3] weight sum, [4] tiled weight, [5..6] class-0/1 counts, [8..] weight histogram
         uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;  // clear of h[0..47] below
         HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, (WHIST_AT + WHIST_BINS) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(m_ + WHIST_AT + WHIST_BINS, c->verr.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        if (m_[WHIST_AT + WHIST_BINS]) return verr_status(m_[WHIST_AT + WHIST_BINS]);
         uint32_t *h = c->h_counters.as<uint32_t>();
         h[0] = n_items ? m_[4] : 0;
         h[1] = m_[0];
@@ -1051,8 +1104,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         max_nin = h[1];
         n_small = n_items ? h[2] + h[3] : 0;
         all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
-        if (all_ops > 0xf0000000ull) {  // the tiling prefix is 32-bit
-            c->err = "batch too large: the item weights (CIGAR ops + 2 x block-map entries) sum to more than 2^32; split the batch";
+        if (all_ops > 0x7fffffffull) {  // op indices are int: the weights bound the ops of every stage, output included
+            c->err = "batch too large: the item weights (CIGAR ops + 2 x block-map entries) sum to more than 2^31; split the batch";
             return PLO_ERR_RANGE;
         }
         if (c->adaptive && n_items) {
@@ -1295,6 +1348,9 @@ plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_fi
     f.fflag = c->f_fflag.as<uint32_t>();
     f.frank = c->f_frank.as<uint32_t>();
     f.flist = c->f_flist.as<uint32_t>();
+    HIP_TRY(c, c->verr.ensure(16));
+    HIP_TRY(c, hipMemsetAsync(c->verr.p, 0, 16, st));
+    f.n_fault = c->verr.as<unsigned>() + 2;
     HIP_TRY(c, hipEventRecord(c->fev[0], st));
     if (n) hipLaunchKernelGGL(k_finish_items, dim3((n + 255) / 256), dim3(256), 0, st, bt, wk, f);
     if (nr) hipLaunchKernelGGL(k_finish_reads, dim3((nr + 255) / 256), dim3(256), 0, st, bt, wk, f);
@@ -1309,8 +1365,13 @@ plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_fi
     uint32_t *h = c->h_counters.as<uint32_t>();
     HIP_TRY(c, hipMemcpyAsync(h, c->f_soff.as<uint32_t>() + ne, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(h + 1, c->f_qoff.as<uint32_t>() + ne, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h + 2, c->verr.as<unsigned>() + 2, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->fev[1], st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    if (h[2]) {
+        c->err = "plo_finish_batch_dev: " + std::to_string(h[2]) + " item(s) ended LEN_MISMATCH / PANIC; the reference aborts here (src/read_alignment_scanner.rs:207-229)";
+        return PLO_ERR_DATA;
+    }
     uint64_t sb = (uint64_t)h[0] * 16u, qb = (uint64_t)h[1] * 16u;
     HIP_TRY(c, c->f_rseq.ensure(std::max<uint64_t>(sb, 16)));
     HIP_TRY(c, c->f_rqual.ensure(std::max<uint64_t>(qb, 16)));
@@ -1403,7 +1464,11 @@ plo_status plo_compact_output_dev(plo_ctx *c, plo_batch_out *out) {
         c->err = "plo_compact_output_dev: `out` is not the result of the context's last plo_liftover_batch_dev";
         return PLO_ERR_INVALID_ARG;
     }
-    if (c->last_wk.out_cigar == c->o_cigar_dense.as<uint32_t>()) return PLO_OK;  // already dense
+    if (c->last_wk.out_cigar == c->o_cigar_dense.as<uint32_t>()) {  // already dense
+        out->cigar = c->o_cigar_dense.as<uint32_t>();
+        out->n_cigar = c->dense_total;
+        return PLO_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->ix->device));
     hipStream_t st = c->stream;
     const uint32_t n = out->n_items;
@@ -1424,6 +1489,7 @@ plo_status plo_compact_output_dev(plo_ctx *c, plo_batch_out *out) {
     c->last_wk.out_cigar = c->o_cigar_dense.as<uint32_t>();
     out->cigar = c->o_cigar_dense.as<uint32_t>();
     out->n_cigar = total;
+    c->dense_total = total;
     return PLO_OK;
 }
 
@@ -1469,50 +1535,28 @@ plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stage
     HIP_TRY(c, hipSetDevice(c->ix->device));
     hipStream_t st = c->stream;
     uint32_t nr = in->n_reads, ns = in->n_segs;
-    // host-side validation (the device path trusts its inputs)
+    // NULL arrays are refused here; everything else about the batch (index ranges, 31-bit coordinates, op codes) is checked on
+    // the device by the enumerate kernels of plo_liftover_batch_dev
+    if (ns && (!in->seg_read || !in->seg_contig || !in->seg_pos || !in->seg_is_fwd_strand || !in->seg_cigar_off) ) {
+        c->err = "plo_batch_in: NULL segment array";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (nr && (!in->read_is_reverse || !in->read_seq_len || !in->read_seq_off)) {
+        c->err = "plo_batch_in: NULL read array";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (in->item_seg && !in->item_cseg) {
+        c->err = "plo_batch_in: item_seg without item_cseg";
+        return PLO_ERR_INVALID_ARG;
+    }
     uint32_t n_cigar = ns ? in->seg_cigar_off[ns] : 0;
-    for (uint32_t s = 0; s < ns; ++s) {
-        if (in->seg_read[s] >= nr || in->seg_contig[s] >= c->ix->d.n_contigs || in->seg_cigar_off[s + 1] < in->seg_cigar_off[s]) {
-            c->err = "plo_batch_in: segment index out of range";
-            return PLO_ERR_INVALID_ARG;
-        }
-        if (!fits31(in->seg_pos[s])) {
-            c->err = "plo_batch_in: seg_pos outside the 31-bit BAM range";
-            return PLO_ERR_RANGE;
-        }
-        unsigned long long span = 0;
-        for (uint32_t i = in->seg_cigar_off[s]; i < in->seg_cigar_off[s + 1]; ++i) {
-            if ((in->cigar[i] & 15u) > 8u) {
-                c->err = "plo_batch_in: invalid CIGAR op code";
-                return PLO_ERR_RANGE;
-            }
-            span += in->cigar[i] >> 4;
-        }
-        if (span > 0x3fffffffull) {
-            c->err = "plo_batch_in: CIGAR spans more than 2^30 bases";
-            return PLO_ERR_RANGE;
-        }
+    if ((n_cigar && !in->cigar) || (in->seq_bytes && !in->seq)) {
+        c->err = "plo_batch_in: NULL cigar / seq array";
+        return PLO_ERR_INVALID_ARG;
     }
-    for (uint32_t r = 0; r < nr; ++r) {
-        unsigned long long need = in->seq_fmt == PLO_SEQ_BAM4 ? ((unsigned long long)in->read_seq_len[r] + 1) / 2 : in->read_seq_len[r];
-        if (in->read_seq_off[r] + need > in->seq_bytes) {
-            c->err = "plo_batch_in: read sequence outside seq buffer";
-            return PLO_ERR_INVALID_ARG;
-        }
-    }
-    if (in->item_seg) {
-        for (uint32_t i = 0; i < in->n_items; ++i) {
-            uint32_t s = in->item_seg[i];
-            if (s >= ns) {
-                c->err = "plo_batch_in: item_seg out of range";
-                return PLO_ERR_INVALID_ARG;
-            }
-            uint32_t ctg = in->seg_contig[s];
-            if (in->item_cseg[i] >= c->ix->host.contig_seg_off[ctg + 1] - c->ix->host.contig_seg_off[ctg]) {
-                c->err = "plo_batch_in: item_cseg out of range";
-                return PLO_ERR_INVALID_ARG;
-            }
-        }
+    if (n_cigar > 0x7fffffffu) {
+        c->err = "plo_batch_in: more than 2^31 - 1 CIGAR ops in one batch; split the batch";
+        return PLO_ERR_RANGE;
     }
 #define UP(buf, src, bytes)                                                                          \
     do {                                                                                             \

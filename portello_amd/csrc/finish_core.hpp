@@ -33,6 +33,7 @@ struct DevFinish {
     const uint32_t *frank;
     uint32_t *flist;         // compact list of those entries
     uint8_t *rev_seq, *rev_qual;
+    unsigned *n_fault;       // items that ended LEN_MISMATCH / PANIC (the reference aborts: the batch must not be written)
 };
 
 // hts_reg2bin / bam_reg2bin (lib/rust-vc-utils/src/bam_utils/util.rs:10-35)
@@ -166,6 +167,7 @@ PLO_DEV void finish_read(const DevBatch &bt, const DevWork &wk, const DevFinish 
     uint32_t i0 = u32_lower_bound(f.item_read, n, r), i1 = u32_lower_bound(f.item_read, n, r + 1);
     uint32_t nl = 0, best = 0xffffffffu;
     for (uint32_t i = i0; i < i1; ++i) {
+        if (wk.status[i] == PLO_ITEM_LEN_MISMATCH || wk.status[i] == PLO_ITEM_PANIC) wv::atomic_add_global(f.n_fault, 1u);
         if (wk.status[i] != PLO_ITEM_LIFTED) continue;
         ++nl;
         if (best == 0xffffffffu || wk.mapq[best] < wk.mapq[i]) best = i;

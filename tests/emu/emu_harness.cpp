@@ -350,6 +350,8 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
     o->frank.assign(e + 1, 0); o->flist.assign(e, 0);
     DevFinish f;
     memset(&f, 0, sizeof(f));
+    unsigned n_fault = 0;
+    f.n_fault = &n_fault;
     f.read_flags = fin->read_flags; f.qual = fin->qual; f.read_qual_off = fin->read_qual_off; f.qual_bytes = fin->qual_bytes;
     f.seq_bytes = in->seq_bytes;
     f.item_flag = o->flag.data(); f.item_bin = o->bin.data(); f.item_ref_end = o->rend.data(); f.item_is_primary = o->prim.data();

@@ -410,3 +410,49 @@ def test_compact_output(oracle):
     assert np.array_equal(got["item_bin"][lifted], ref["item_bin"][lifted])
     eng.close()
     index.close()
+
+
+def test_device_entry_point_checks_its_batch():
+    """plo_liftover_batch_dev validates on the device what the reference's types rule out: index ranges, 31-bit coordinates,
+    op codes -- before any lift kernel indexes with them"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("tiny", n_reads=64, seed=209), device="cuda")
+    index = api.Index(w.index_data_device())
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    good = devbatch.DeviceBatch.from_workload(w)
+
+    def run(mutate):
+        import dataclasses
+
+        db = devbatch.DeviceBatch.from_workload(w)
+        # (slices of the whole workload share its storage: mutate copies)
+        db = dataclasses.replace(db, **{f.name: getattr(db, f.name).clone() for f in dataclasses.fields(db) if f.name != "seq_fmt"})
+        mutate(db)
+        torch.cuda.synchronize()
+        with pytest.raises(api.PortelloError) as e:
+            eng.liftover_batch_dev(db.desc())
+        return e.value.status
+
+    def set_(name, idx, val):
+        def f(db):
+            getattr(db, name)[idx] = val
+        return f
+
+    assert run(set_("seg_contig", 0, 1_000_000)) == abi.PLO_ERR_INVALID_ARG
+    assert run(set_("seg_read", 3, 10_000_000)) == abi.PLO_ERR_INVALID_ARG
+    assert run(set_("seg_pos", 1, 2**31 + 7)) == abi.PLO_ERR_RANGE
+    assert run(set_("seg_pos", 1, -4)) == abi.PLO_ERR_RANGE
+    assert run(set_("cigar", 5, (7 << 4) | 12)) == abi.PLO_ERR_RANGE
+    assert run(set_("read_seq_off", 2, 2**40)) == abi.PLO_ERR_INVALID_ARG
+
+    def swap_offsets(db):
+        db.seg_cigar_off[4] = db.seg_cigar_off[5] + 3
+
+    assert run(swap_offsets) == abi.PLO_ERR_INVALID_ARG
+    # and the context is usable afterwards
+    assert int(eng.liftover_batch_dev(good.desc()).n_items) > 0
+    eng.close()
+    index.close()
