@@ -107,6 +107,35 @@ plo_status plo_bam_writer_open(const char *path, const char *header_text, uint32
 plo_status plo_bam_write(plo_bam_writer *w, const uint8_t *record_bytes, uint64_t n_bytes);
 plo_status plo_bam_writer_close(plo_bam_writer *w);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Phase 1: the contig->reference index from the assembly->reference BAM (scan_contig_bam,
+ * src/contig_alignment_scanner/mod.rs:290-459): primary records -> sequencing-order split segments (:91-133), exact CIGARs
+ * of the supplementary records matched by (chrom, pos, strand, leading clip, trailing clip) (:135-183, :371-416), optional
+ * target-region filter (non_targeted_segment_filter.rs:7-39), clip_repeated_contig_matches (gap-compressed identity, then
+ * MAPQ; contig_repeated_match_trimmer.rs:214-303), join_colinear_contig_segments (same chromosome / strand / MAPQ,
+ * reference gap 0..1000; contig_colinear_segment_joiner.rs:124-186), and the reverse-complemented contig sequence of every
+ * contig with a reverse-mapped segment (:113-125).  The result is handed to plo_index_create as a plo_index_desc (which
+ * builds the block maps on the device); the caller adds the reference sequences (chrom_len / chrom_seq).
+ * Pinned by the reference's vectors of contig_repeated_match_trimmer.rs:311-397 and clip_alignment.rs:188-248.
+ * Inputs the reference panics on (missing supplementary record in a whole-genome run, ambiguous supplementary key, M ops in
+ * an overlap that needs the identity, unknown contig name) return PLO_ERR_DATA.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct plo_phase1 plo_phase1;
+typedef struct plo_target_region {  /* GenomeSegment of --target-region (debug option, src/cli.rs:24-75) */
+    uint32_t chrom_index;
+    int64_t start, end;
+} plo_target_region;
+
+/* contig_names / contig_lens: the @SQ list of the read->contig BAM (ChromList of the assembly contigs) */
+plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const char *const *contig_names, const int64_t *contig_lens,
+                           const plo_target_region *target_region /* NULL = whole genome */, int n_threads, plo_phase1 **out);
+/* every array of the descriptor except chrom_len / chrom_seq (pointers owned by the plo_phase1 object) */
+plo_status plo_phase1_index_desc(const plo_phase1 *ph, plo_index_desc *desc);
+/* reference ChromList of the assembly->reference BAM header + the counters the reference logs (trimmer.rs:302, joiner.rs:185) */
+plo_status plo_phase1_info(const plo_phase1 *ph, uint32_t *n_ref, const char *const **ref_names, const uint32_t **ref_lens,
+                           uint32_t *segments_clipped, uint32_t *segments_joined, uint32_t *n_records);
+void plo_phase1_free(plo_phase1 *ph);
+
 const char *plo_bam_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,351 @@
+"""oracle/pyphase1.py -- pure-Python restatement of the reference's phase 1 (index construction).
+
+TEST INFRASTRUCTURE ONLY.  Written from the Rust sources, function by function; shares no code with
+portello_amd/csrc/phase1.cpp.  Pinned by the reference's vectors (tests/test_phase1.py):
+contig_repeated_match_trimmer.rs:311-397, clip_alignment.rs:188-248, score_alignment.rs:68-74.
+
+  clip_alignment_read_start / _read_edges      lib/rust-vc-utils/src/bam_utils/cigar/clip_alignment.rs:113-181
+  clip_alignment_ref_start / _ref_edges        .../clip_alignment.rs:15-95 (not on portello's path; restated for its vectors)
+  compress_cigar, strip_*_clip                 lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:204-228, 300-327
+  get_gap_compressed_identity_no_align_match   .../score_alignment.rs:138-165
+  clip_seg_isec_range, get_seg_clip_info, clip_repeated_contig_matches    src/contig_alignment_scanner/contig_repeated_match_trimmer.rs
+  are_segments_joinable, join_segments, join_colinear_contig_segments     src/contig_alignment_scanner/contig_colinear_segment_joiner.rs
+  scan_contig_bam (record handling, supplementary CIGAR matching)         src/contig_alignment_scanner/mod.rs:91-183, 290-459
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from . import pyrecords as pr
+from .pyrecords import D, EQ, H, I, M, N, P, S, X
+
+
+def mk(t: int, length: int) -> int:
+    return (length << 4) | t
+
+
+def compress_cigar(cigar: Sequence[int]) -> List[int]:  # cigar/mod.rs:204-228
+    out: List[int] = []
+    for c in cigar:
+        t, l = c & 15, c >> 4
+        if l == 0:
+            continue
+        if out and (out[-1] & 15) == t:
+            if t != P:  # Pad is missing from the summing pattern (:210-212)
+                out[-1] = mk(t, (out[-1] >> 4) + l)
+        else:
+            out.append(c)
+    return out
+
+
+def clip_alignment_read_start(cigar_in: Sequence[int], min_left_clip: int) -> Tuple[List[int], int]:  # clip_alignment.rs:113-163
+    read_pos = 0
+    out: List[int] = []
+    left_ref_clip_shift = 0
+    for c in cigar_in:
+        t, l = c & 15, c >> 4
+        if t in (D, N):
+            if read_pos <= min_left_clip:
+                left_ref_clip_shift += l
+            else:
+                out.append(c)
+        elif t == I:
+            out.append(mk(S, l) if read_pos < min_left_clip else c)
+        elif t in (M, X, EQ):
+            if read_pos < min_left_clip:
+                remaining_clip = min_left_clip - read_pos
+                match_size = max(l - remaining_clip, 0)
+                clip_size = l - match_size
+                out.append(mk(S, clip_size))
+                if match_size > 0:
+                    out.append(mk(t, match_size))
+                left_ref_clip_shift += clip_size
+            else:
+                out.append(c)
+        else:
+            out.append(c)
+        read_pos += pr.cigarseg_read_offset(c, False)
+    return out, left_ref_clip_shift
+
+
+def clip_alignment_read_edges(cigar_in: Sequence[int], min_left_clip: int, min_right_clip: int) -> Tuple[List[int], int]:  # :166-181
+    right, _ = clip_alignment_read_start(list(reversed(cigar_in)), min_right_clip)
+    right.reverse()
+    clipped, ref_shift = clip_alignment_read_start(right, min_left_clip)
+    return compress_cigar(clipped), ref_shift
+
+
+def clip_alignment_ref_start(cigar_in: Sequence[int], min_left_ref_clip: int) -> Tuple[List[int], int]:  # :15-67
+    ref_pos = 0
+    out: List[int] = []
+    shift = 0
+    for c in cigar_in:
+        t, l = c & 15, c >> 4
+        if t in (D, N):
+            if ref_pos <= min_left_ref_clip:
+                shift += l
+            else:
+                out.append(c)
+        elif t == I:
+            out.append(mk(S, l) if ref_pos < min_left_ref_clip else c)
+        elif t in (M, X, EQ):
+            if ref_pos < min_left_ref_clip:
+                remaining = min_left_ref_clip - shift
+                match_size = max(l - remaining, 0)
+                clip_size = l - match_size
+                out.append(mk(S, clip_size))
+                if match_size > 0:
+                    out.append(mk(t, match_size))
+                shift += clip_size
+            else:
+                out.append(c)
+        else:
+            out.append(c)
+        ref_pos += pr.cigarseg_ref_offset(c)
+    return out, shift
+
+
+def clip_alignment_ref_edges(cigar_in: Sequence[int], min_left: int, min_right: int) -> Tuple[List[int], int]:  # :78-95
+    right, _ = clip_alignment_ref_start(list(reversed(cigar_in)), min_right)
+    right.reverse()
+    clipped, shift = clip_alignment_ref_start(right, min_left)
+    return compress_cigar(clipped), shift
+
+
+def gap_compressed_identity_no_align_match(cigar: Sequence[int]) -> float:  # score_alignment.rs:138-165, :68-74
+    mismatch_events = match_bases = 0
+    for c in cigar:
+        t, l = c & 15, c >> 4
+        if t in (I, D, N):
+            mismatch_events += 1
+        elif t == X:
+            mismatch_events += l
+        elif t == EQ:
+            match_bases += l
+        elif t == M:
+            raise ValueError("Method assumes alignment CIGAR strings use seq match/mismatch (=/X) instead of alignment match (M)")
+    if match_bases + mismatch_events == 0:
+        return 1.0
+    return match_bases / (match_bases + mismatch_events)
+
+
+@dataclass
+class Seg:  # SeqOrderSplitReadSegment (split_read.rs:15-32)
+    seq_order_read_start: int
+    seq_order_read_end: int
+    chrom_index: int
+    pos: int
+    is_fwd_strand: bool
+    cigar: List[int]
+    mapq: int
+    from_primary_bam_record: bool
+
+
+def _reverse_range(r: Tuple[int, int], size: int) -> Tuple[int, int]:  # int_range.rs:89-94
+    return size - r[1], size - r[0]
+
+
+def get_seg_gap_compressed_identity(seg: Seg, isec_so: Tuple[int, int]) -> float:  # trimmer.rs:18-50
+    read_len = sum(pr.cigarseg_read_offset(c, False) for c in seg.cigar)
+    r = isec_so if seg.is_fwd_strand else _reverse_range(isec_so, read_len)
+    clipped, _ = clip_alignment_read_edges(seg.cigar, r[0], read_len - r[1])
+    return gap_compressed_identity_no_align_match(clipped)
+
+
+def clip_seg_isec_range(seg: Seg, isec_so: Tuple[int, int]) -> bool:  # :55-115
+    is_clipping_seq_order_prefix = isec_so[0] == seg.seq_order_read_start
+    is_clipping_prefix = is_clipping_seq_order_prefix ^ (not seg.is_fwd_strand)
+    read_len = sum(pr.cigarseg_read_offset(c, False) for c in seg.cigar)
+    r = list(isec_so if seg.is_fwd_strand else _reverse_range(isec_so, read_len))
+    min_left, min_right = (r[1], 0) if is_clipping_prefix else (0, read_len - r[0])
+    shifted, ref_pos_shift = clip_alignment_read_edges(seg.cigar, min_left, min_right)
+    seg.cigar = shifted
+    seg.pos += ref_pos_shift
+    left_read_pos, right_read_pos, _ = pr.get_read_clip_positions(seg.cigar, False)
+    if left_read_pos >= right_read_pos:
+        return True
+    if is_clipping_prefix:
+        r[1] = left_read_pos
+    else:
+        r[0] = right_read_pos
+    so = tuple(r) if seg.is_fwd_strand else _reverse_range((r[0], r[1]), read_len)
+    if is_clipping_seq_order_prefix:
+        seg.seq_order_read_start = so[1]
+    else:
+        seg.seq_order_read_end = so[0]
+    return False
+
+
+def clip_repeated_contig_matches(contigs: List[List[Seg]]) -> int:  # :214-303
+    clipped = 0
+    for segs in contigs:
+        if not segs:
+            continue
+        n = len(segs)
+        eliminated = [False] * n
+        for i1 in range(n):
+            for i2 in range(i1 + 1, n):
+                if eliminated[i1] or eliminated[i2]:
+                    continue
+                s1, s2 = segs[i1], segs[i2]
+                if s1.seq_order_read_end <= s2.seq_order_read_start:  # get_seg_clip_info -> None -> break
+                    break
+                isec = (s2.seq_order_read_start, s1.seq_order_read_end)
+                g1 = get_seg_gap_compressed_identity(s1, isec)
+                g2 = get_seg_gap_compressed_identity(s2, isec)
+                clip_seg1 = g2 > g1 or (g2 == g1 and s2.mapq > s1.mapq)  # partial_cmp(...).then(mapq cmp) == Greater
+                ci = i1 if clip_seg1 else i2
+                if clip_seg_isec_range(segs[ci], isec):
+                    eliminated[ci] = True
+                clipped += 1
+        segs[:] = [s for s, e in zip(segs, eliminated) if not e]
+    return clipped
+
+
+def get_seg_ref_gap(s1: Seg, s2: Seg) -> int:  # joiner.rs:14-22
+    if s1.is_fwd_strand:
+        return s2.pos - (s1.pos + pr.cigar_ref_offset(s1.cigar))
+    return s1.pos - (s2.pos + pr.cigar_ref_offset(s2.cigar))
+
+
+def are_segments_joinable(s1: Seg, s2: Seg) -> bool:  # :26-50
+    if s1.chrom_index != s2.chrom_index or s1.is_fwd_strand != s2.is_fwd_strand:
+        return False
+    gap = get_seg_ref_gap(s1, s2)
+    if gap < 0 or gap > 1000:
+        return False
+    return s1.mapq == s2.mapq
+
+
+def _is_clip(c: int) -> bool:
+    return (c & 15) in (S, H)
+
+
+def strip_trailing_clip(cigar: List[int]):  # cigar/mod.rs:315-327
+    out, non_clip_found = [], False
+    for c in cigar:
+        if non_clip_found:
+            if not _is_clip(c):
+                out.append(c)
+        else:
+            if not _is_clip(c):
+                non_clip_found = True
+            out.append(c)
+    cigar[:] = out
+
+
+def strip_leading_clip(cigar: List[int]):  # :300-312
+    out, non_clip_found = [], False
+    for c in cigar:
+        if non_clip_found:
+            out.append(c)
+        elif not _is_clip(c):
+            non_clip_found = True
+            out.append(c)
+    cigar[:] = out
+
+
+def join_segments(s1: Seg, s2: Seg):  # :59-122
+    join_del_size = get_seg_ref_gap(s1, s2)
+    assert join_del_size >= 0
+    assert s2.seq_order_read_start >= s1.seq_order_read_end
+    join_ins_size = s2.seq_order_read_start - s1.seq_order_read_end
+
+    def join_cigars(a: List[int], b: List[int]):
+        strip_trailing_clip(a)
+        if join_ins_size > 0:
+            a.append(mk(I, join_ins_size))
+        if join_del_size > 0:
+            a.append(mk(D, join_del_size))
+        strip_leading_clip(b)
+        a.extend(b)
+        b.clear()
+
+    if s1.is_fwd_strand:
+        join_cigars(s1.cigar, s2.cigar)
+    else:
+        join_cigars(s2.cigar, s1.cigar)
+        s1.cigar, s2.cigar = s2.cigar, s1.cigar
+        s1.pos = s2.pos
+    s1.seq_order_read_end = s2.seq_order_read_end
+
+
+def join_colinear_contig_segments(contigs: List[List[Seg]]) -> int:  # :124-186
+    joined = 0
+    for segs in contigs:
+        if not segs:
+            continue
+        old = list(segs)
+        segs.clear()
+        for seg in old:
+            if not segs:
+                segs.append(seg)
+                continue
+            last = segs[-1]
+            assert seg.seq_order_read_start >= last.seq_order_read_end, "Incomplete repeat trimming"
+            if are_segments_joinable(last, seg):
+                join_segments(last, seg)
+                joined += 1
+            else:
+                segs.append(seg)
+    return joined
+
+
+@dataclass
+class Phase1Result:
+    contigs: List[List[Seg]]
+    rev_contig_seq: List[Optional[bytes]]
+    segments_clipped: int = 0
+    segments_joined: int = 0
+
+
+def scan_contig_bam(records: Sequence[bytes], ref_names: Sequence[str], contig_names: Sequence[str],
+                    target_region: Optional[Tuple[int, int, int]] = None) -> Phase1Result:
+    """records: the BAM records of the assembly->reference file (block_size prefixed), in any order"""
+    ref_index = {n: i for i, n in enumerate(ref_names)}
+    contig_index = {n: i for i, n in enumerate(contig_names)}
+    n = len(contig_names)
+    contigs: List[List[Seg]] = [[] for _ in range(n)]
+    revs: List[Optional[bytes]] = [None] * n
+    supp: List[Dict[tuple, List[int]]] = [dict() for _ in range(n)]
+
+    def key(chrom, pos, fwd, cigar):
+        rs, re_, size = pr.get_read_clip_positions(cigar, False)
+        return (chrom, pos, fwd, rs, size - re_)
+
+    for rb in records:
+        rec = pr.record_from_bytes(rb)
+        if rec.flag & 0x4 or rec.flag & 0x100:
+            continue
+        cid = contig_index[rec.qname.decode()]
+        if not (rec.flag & 0x800):  # add_primary_read (mod.rs:91-133)
+            segs = pr.get_seq_order_read_split_segments(ref_index, rec)
+            contigs[cid] = [Seg(s.seq_order_read_start, s.seq_order_read_end, s.chrom_index, s.pos, s.is_fwd_strand, list(s.cigar), s.mapq,
+                                s.from_primary_bam_record) for s in segs]
+            if any(not s.is_fwd_strand for s in segs):
+                seq = rec.seq_as_bytes()
+                revs[cid] = seq if rec.is_reverse() else pr.rev_comp(seq)
+            else:
+                revs[cid] = None
+        else:  # add_split_read_cigar_to_supp_cigar_set (:135-183)
+            k = key(rec.tid, rec.pos, not rec.is_reverse(), rec.cigar)
+            assert k not in supp[cid], "Can't uniquely identify split read alignment info"
+            supp[cid][k] = list(rec.cigar)
+    for cid in range(n):  # :371-416
+        for s in contigs[cid]:
+            if s.from_primary_bam_record:
+                continue
+            k = key(s.chrom_index, s.pos, s.is_fwd_strand, s.cigar)
+            if k in supp[cid]:
+                s.cigar = list(supp[cid][k])
+            else:
+                assert target_region is not None, "Can't find supplementary alignment record corresponding to segment reported in SA tag"
+    if target_region is not None:  # filter_non_targeted_segments
+        tc, ts, te = target_region
+        for cid in range(n):
+            contigs[cid] = [s for s in contigs[cid] if s.chrom_index == tc and s.pos + 1 >= ts and s.pos < te]
+    res = Phase1Result(contigs, revs)
+    res.segments_clipped = clip_repeated_contig_matches(contigs)
+    res.segments_joined = join_colinear_contig_segments(contigs)
+    return res

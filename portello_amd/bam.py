@@ -219,3 +219,71 @@ class BamWriter:
             self.close()
         except Exception:
             pass
+
+
+# ---- phase 1 (index construction) ----------------------------------------------------------------------------------------------
+class PloTargetRegion(C.Structure):
+    _fields_ = [("chrom_index", C.c_uint32), ("start", C.c_int64), ("end", C.c_int64)]
+
+
+class Phase1:
+    """plo_phase1_scan: the contig->reference index built from the assembly->reference BAM (scan_contig_bam,
+    src/contig_alignment_scanner/mod.rs:290-459)"""
+
+    def __init__(self, asm_to_ref_bam: str, contig_names: Sequence[str], contig_lens: Sequence[int], target_region=None, n_threads: int = 4):
+        L = lib()
+        L.plo_phase1_scan.restype = C.c_int
+        L.plo_phase1_scan.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(PloTargetRegion), C.c_int,
+                                      C.POINTER(C.c_void_p)]
+        L.plo_phase1_index_desc.restype = C.c_int
+        L.plo_phase1_index_desc.argtypes = [C.c_void_p, C.POINTER(abi.PloIndexDesc)]
+        L.plo_phase1_info.restype = C.c_int
+        L.plo_phase1_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint32)),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.plo_phase1_free.restype = None
+        L.plo_phase1_free.argtypes = [C.c_void_p]
+        cn = _names(contig_names)
+        cl = (C.c_int64 * max(1, len(contig_lens)))(*[int(x) for x in contig_lens])
+        tr = PloTargetRegion(*target_region) if target_region is not None else None
+        h = C.c_void_p()
+        _check(L.plo_phase1_scan(asm_to_ref_bam.encode(), len(contig_names), cn, cl, C.byref(tr) if tr is not None else None, n_threads,
+                                 C.byref(h)), "plo_phase1_scan")
+        self.handle = h
+        n, names, lens = C.c_uint32(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint32)()
+        a, b, r = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(L.plo_phase1_info(h, C.byref(n), C.byref(names), C.byref(lens), C.byref(a), C.byref(b), C.byref(r)), "plo_phase1_info")
+        self.ref_names = [names[i].decode() for i in range(n.value)]
+        self.ref_lens = [int(lens[i]) for i in range(n.value)]
+        self.segments_clipped, self.segments_joined, self.n_records = int(a.value), int(b.value), int(r.value)
+
+    def index_data(self, chrom_seq) -> abi.IndexData:
+        """numpy copy of the index description; chrom_seq = the reference sequences (ASCII arrays or device pointers)"""
+        d = abi.PloIndexDesc()
+        _check(lib().plo_phase1_index_desc(self.handle, C.byref(d)), "plo_phase1_index_desc")
+        nc, ns = int(d.n_contigs), int(d.n_segments)
+
+        def cp(p, dt, cnt):
+            return np.ctypeslib.as_array(p, shape=(cnt,)).astype(dt, copy=True) if cnt else np.zeros(0, dt)
+
+        coff = cp(d.seg_cigar_off, np.uint32, ns + 1) if ns else np.zeros(1, np.uint32)
+        clen = cp(d.contig_len, np.int64, nc)
+        revs = []
+        for c in range(nc):
+            p = d.rev_contig_seq[c]
+            revs.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(clen[c]),)).copy() if p else None)
+        return abi.IndexData(contig_len=clen, contig_seg_off=cp(d.contig_seg_off, np.uint32, nc + 1), seg_chrom_index=cp(d.seg_chrom_index, np.uint32, ns),
+                             seg_pos=cp(d.seg_pos, np.int64, ns), seg_is_fwd_strand=cp(d.seg_is_fwd_strand, np.uint8, ns),
+                             seg_mapq=cp(d.seg_mapq, np.uint8, ns), seg_seq_order_start=cp(d.seg_seq_order_start, np.int64, ns),
+                             seg_seq_order_end=cp(d.seg_seq_order_end, np.int64, ns), seg_cigar_off=coff,
+                             seg_cigar=cp(d.seg_cigar, np.uint32, int(coff[-1])), chrom_seq=list(chrom_seq), rev_contig_seq=revs)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().plo_phase1_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -137,3 +137,115 @@ def write_read_bam(w, path: str, lo: int = 0, hi: Optional[int] = None, level: i
     meta["contig_names"] = cn
     meta["header_text"] = text
     return meta
+
+
+# ---- assembly -> reference BAM (input of phase 1) ---------------------------------------------------------------------------
+
+def _read_len(ops) -> int:
+    return int(sum(int(c) >> 4 for c in ops if (0x1B3 >> (int(c) & 15)) & 1))
+
+
+def _ref_len(ops) -> int:
+    return int(sum(int(c) >> 4 for c in ops if (0x18D >> (int(c) & 15)) & 1))
+
+
+def raw_contig_pieces(w, seed: int = 5, perturb: bool = True):
+    """The workload's post-phase-1 contig segments taken apart again into what an aligner would have reported: per contig a
+    list of pieces (chrom, pos, fwd, mapq, lead clip, aligned ops, trail clip) -- some segments cut in two at a match boundary,
+    at an insertion or at a deletion (colinear pieces the joiner must re-join), some cut with an overlap (a repeated match
+    the trimmer must clip first)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for c in range(len(w.contig_len)):
+        pieces = []
+        for g in range(int(w.contig_seg_off[c]), int(w.contig_seg_off[c + 1])):
+            ops = [int(x) for x in w.seg_cigar[int(w.seg_cigar_off[g]): int(w.seg_cigar_off[g + 1])]]
+            lead = ops[0] >> 4 if (ops[0] & 15) in (4, 5) else 0
+            trail = ops[-1] >> 4 if (ops[-1] & 15) in (4, 5) and len(ops) > 1 else 0
+            core = ops[(1 if lead else 0): (len(ops) - 1 if trail else len(ops))]
+            base = dict(chrom=int(w.seg_chrom_index[g]), pos=int(w.seg_pos[g]), fwd=bool(w.seg_is_fwd[g]), mapq=int(w.seg_mapq[g]))
+            mode = int(rng.integers(0, 4)) if (perturb and len(core) > 12) else 0
+            eq = [k for k in range(3, len(core) - 3) if (core[k] & 15) == 7 and (core[k - 1] & 15) != 7]
+            if mode == 1 and eq:  # cut at a match boundary
+                k = int(rng.choice(eq))
+                cuts = [(0, k), (k, len(core))]
+            elif mode == 2:  # cut at an indel: the op itself belongs to neither piece
+                ind = [k for k in range(3, len(core) - 3) if (core[k] & 15) in (1, 2) and (core[k] >> 4) <= 900 and (core[k - 1] & 15) in (7, 8)
+                       and (core[k + 1] & 15) in (7, 8)]
+                if ind:
+                    k = int(rng.choice(ind))
+                    cuts = [(0, k), (k + 1, len(core))]
+                else:
+                    cuts = [(0, len(core))]
+            elif mode == 3 and len(eq) >= 2:  # overlap: ops [k1, k2) reported by both pieces (a repeated match)
+                k1, k2 = sorted(int(x) for x in rng.choice(eq, 2, replace=False))
+                cuts = [(0, k2), (k1, len(core))] if k2 - k1 < 40 else [(0, len(core))]
+            else:
+                cuts = [(0, len(core))]
+            for a, b in cuts:
+                p = dict(base)
+                p["pos"] = base["pos"] + _ref_len(core[:a])
+                p["lead"] = lead + _read_len(core[:a])
+                p["trail"] = trail + _read_len(core[b:])
+                p["ops"] = core[a:b]
+                pieces.append(p)
+        out.append(pieces)
+    return out
+
+
+def write_contig_bam(w, path: str, seed: int = 5, perturb: bool = True, level: int = 1) -> dict:
+    """assembly->reference BAM of the workload: per contig one primary record (soft clips, full contig sequence, SA tag listing
+    the other pieces with approximate CIGARs as minimap2 writes them) and one supplementary record per other piece (hard clips,
+    exact CIGAR)."""
+    rng = np.random.default_rng(seed + 1)
+    rn, cn = ref_names(w), contig_names(w)
+    rl = [int(s.numel()) for s in w.chrom_seq]
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(rn, rl)) + "@PG\tID:minimap2\tPN:minimap2\n"
+    pieces = raw_contig_pieces(w, seed, perturb)
+    lut = np.full(256, 15, dtype=np.uint8)
+    for i_, c_ in enumerate("=ACMGRSVTWYHKDBN"):
+        lut[ord(c_)] = i_
+    recs = []
+    for c, ps in enumerate(pieces):
+        if not ps:
+            continue
+        prim = int(rng.integers(0, len(ps)))
+        for k, p in enumerate(ps):
+            clip = 4 if k == prim else 5
+            cig = ([(p["lead"] << 4) | clip] if p["lead"] else []) + p["ops"] + ([(p["trail"] << 4) | clip] if p["trail"] else [])
+            flag = (0 if p["fwd"] else 0x10) | (0 if k == prim else 0x800)
+            if k == prim:
+                # SEQ of the primary record = the contig in the orientation of that alignment.  The workload keeps only the reverse
+                # complement, and only for contigs with a reverse-mapped segment; where it is missing nobody reads the bases
+                rcs = w.rev_contig_seq[c]
+                if rcs is None:
+                    assert p["fwd"], "reverse-mapped primary without rev_contig_seq"
+                    seq_ascii = np.full(int(w.contig_len[c]), ord("N"), dtype=np.uint8)
+                elif p["fwd"]:
+                    from . import synth as _synth
+
+                    seq_ascii = _synth.revcomp(rcs).cpu().numpy()
+                else:
+                    seq_ascii = rcs.cpu().numpy()
+                n4 = lut[seq_ascii]
+                if len(n4) & 1:
+                    n4 = np.concatenate([n4, np.zeros(1, np.uint8)])
+                sp = ((n4[0::2] << 4) | n4[1::2]).astype(np.uint8).tobytes()
+                l_seq = len(seq_ascii)
+                qual = b"\xff" * l_seq
+                sa = ""
+                for j, q in enumerate(ps):
+                    if j == prim:
+                        continue
+                    approx = (f"{q['lead']}S" if q["lead"] else "") + f"{_read_len(q['ops'])}M" + (f"{q['trail']}S" if q["trail"] else "")
+                    sa += f"{rn[q['chrom']]},{q['pos'] + 1},{'+' if q['fwd'] else '-'},{approx},{q['mapq']},{int(rng.integers(0, 99))};"
+                aux = b"NMi" + struct.pack("<i", 12) + ((b"SAZ" + sa.encode() + b"\0") if sa else b"")
+            else:
+                sp, l_seq, qual, aux = b"", 0, b"", b"NMi" + struct.pack("<i", 3)
+            recs.append((p["chrom"], p["pos"], encode_record(p["chrom"], p["pos"], p["mapq"], flag, cn[c].encode(), np.array(cig, np.uint32), sp, l_seq,
+                                                             qual, aux)))
+    recs.sort(key=lambda t: (t[0], t[1]))
+    wr = bam.BamWriter(path, text, rn, rl, level=level)
+    wr.write(b"".join(r[2] for r in recs))
+    wr.close()
+    return {"ref_names": rn, "contig_names": cn, "pieces": pieces, "n_records": len(recs), "records": [r[2] for r in recs]}

@@ -1,0 +1,621 @@
+// bam_internal.hpp -- shared internals of the host-side BAM code (bam_host.cpp, phase1.cpp): BGZF input, record access, aux
+// walking, CIGAR helpers.  Everything sits in an unnamed namespace (one private copy per translation unit).
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/portello_bam.h"
+
+void plo_bam_set_error(const std::string &msg);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
+
+namespace {
+
+plo_status fail(plo_status st, const std::string &msg) {
+    plo_bam_set_error(msg);
+    return st;
+}
+
+// fork-join over [0, n): `threads` workers take indices from a shared counter
+template <class F>
+void parallel_for(size_t n, int threads, F fn) {
+    if (threads <= 1 || n <= 1) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto body = [&]() {
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    size_t nt = std::min<size_t>((size_t)threads, n);
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+}
+// the same over contiguous ranges (per-thread state: one z_stream per range)
+template <class F>
+void parallel_ranges(size_t n, int threads, F fn) {
+    size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), n));
+    if (nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) {
+        size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        if (t + 1 < nt) th.emplace_back(fn, lo, hi);
+        else fn(lo, hi);
+    }
+    for (auto &t : th) t.join();
+}
+
+// growable byte buffer that does not zero what it allocates (the inflated stream and the output records are written once, in
+// parallel, right after the allocation)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    bool resize(size_t want) {  // keeps the first min(n, want) bytes
+        if (want > cap) {
+            size_t nc = std::max(want, cap + cap / 2);
+            uint8_t *q = (uint8_t *)realloc(p, nc ? nc : 1);
+            if (!q) return false;
+            p = q;
+            cap = nc;
+        }
+        n = want;
+        return true;
+    }
+};
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads);
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
+inline void wr16(uint8_t *p, uint16_t v) {
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+}
+inline void wr32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+// DEFLATE engine: zlib always works; libdeflate (whole-buffer API, 2-3x faster inflate, CRC with carry-less multiplies) is
+// used when its shared library is on the machine.  Only the runtime is present in this image (no header), so the five entry
+// points are bound by name -- their signatures are libdeflate's stable public API.
+struct LibDeflate {
+    void *(*alloc_decompressor)() = nullptr;
+    int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_decompressor)(void *) = nullptr;
+    void *(*alloc_compressor)(int) = nullptr;
+    size_t (*deflate_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*free_compressor)(void *) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("PLO_NO_LIBDEFLATE")) return;
+        void *h = nullptr;
+        for (const char *n : {"libdeflate.so.0", "libdeflate.so", "libdeflate.so.1"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        alloc_decompressor = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        deflate_decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        free_decompressor = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        alloc_compressor = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        deflate_compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        free_compressor = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        crc32 = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc_decompressor && deflate_decompress && free_decompressor && alloc_compressor && deflate_compress && free_compressor && crc32;
+    }
+};
+const LibDeflate &libdeflate() {
+    static const LibDeflate *l = new LibDeflate();
+    return *l;
+}
+inline uint32_t fast_crc32(const uint8_t *p, size_t n) {
+    const LibDeflate &ld = libdeflate();
+    return ld.ok ? ld.crc32(0, p, n) : (uint32_t)crc32(0L, p, (uInt)n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BGZF input: the file is mapped; blocks are located by their BSIZE fields and inflated in parallel, a chunk at a time
+// ---------------------------------------------------------------------------------------------------------------------
+struct BgzfIn {
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t size = 0, cpos = 0;
+    RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
+    size_t bpos = 0;
+    int threads = 1;
+    bool eof = false;
+    static constexpr size_t CHUNK = 256u << 20;
+
+    struct Blk {
+        size_t coff, clen, uoff, ulen;
+        uint32_t crc;
+    };
+
+    plo_status open(const char *path, int nt) {
+        threads = std::max(1, nt);
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(PLO_ERR_IO, std::string("cannot open ") + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) return fail(PLO_ERR_IO, "fstat failed");
+        size = (size_t)st.st_size;
+        if (size) {
+            void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) return fail(PLO_ERR_IO, "mmap failed");
+            map = (const uint8_t *)p;
+            madvise(p, size, MADV_SEQUENTIAL);
+        }
+        return PLO_OK;
+    }
+    void close() {
+        if (map) munmap((void *)map, size);
+        if (fd >= 0) ::close(fd);
+        map = nullptr;
+        fd = -1;
+    }
+    size_t avail() const { return buf.size() - bpos; }
+
+    // makes at least `want` bytes available (fewer only at the end of the file)
+    plo_status fill(size_t want) {
+        if (avail() >= want || eof) return PLO_OK;
+        if (bpos) {
+            memmove(buf.data(), buf.data() + bpos, buf.size() - bpos);
+            buf.resize(buf.size() - bpos);
+            bpos = 0;
+        }
+        const size_t cpos0 = cpos;
+        std::vector<Blk> blks;
+        size_t u = buf.size();
+        const size_t target = std::max(want, CHUNK);
+        while (cpos < size && u < target) {
+            if (size - cpos < 28) return fail(PLO_ERR_IO, "truncated BGZF block header");
+            const uint8_t *h = map + cpos;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(PLO_ERR_IO, "not a BGZF block");
+            uint32_t xlen = rd16(h + 10), bsize = 0;
+            if (12 + (size_t)xlen > size - cpos) return fail(PLO_ERR_IO, "truncated BGZF extra field");
+            for (uint32_t x = 0; x + 4 <= xlen;) {
+                const uint8_t *e = h + 12 + x;
+                uint32_t slen = rd16(e + 2);
+                if (e[0] == 'B' && e[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint32_t)rd16(e + 4) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || bsize > size - cpos) return fail(PLO_ERR_IO, "corrupt or truncated BGZF block");
+            Blk b;
+            b.coff = cpos + 12 + xlen;
+            b.clen = bsize - 12 - xlen - 8;
+            b.crc = rd32(h + bsize - 8);
+            b.ulen = rd32(h + bsize - 4);
+            b.uoff = u;
+            if (b.ulen > 65536) return fail(PLO_ERR_IO, "BGZF block larger than 64 KiB");
+            u += b.ulen;
+            cpos += bsize;
+            blks.push_back(b);
+        }
+        if (cpos >= size) eof = true;
+        if (cpos > cpos0) madvise((void *)(map + (cpos0 & ~(size_t)4095)), cpos - (cpos0 & ~(size_t)4095), MADV_WILLNEED);
+        if (!buf.resize(u)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the inflated BAM stream");
+        std::atomic<int> bad{0};
+        parallel_ranges(blks.size(), threads, [&](size_t lo, size_t hi) {
+            const LibDeflate &ld = libdeflate();
+            if (ld.ok) {
+                void *d = ld.alloc_decompressor();
+                if (!d) {
+                    bad = 1;
+                    return;
+                }
+                for (size_t i = lo; i < hi; ++i) {
+                    const Blk &b = blks[i];
+                    if (b.ulen == 0) continue;
+                    size_t got = 0;
+                    int rc = ld.deflate_decompress(d, map + b.coff, b.clen, buf.data() + b.uoff, b.ulen, &got);
+                    if (rc != 0 || got != b.ulen || ld.crc32(0, buf.data() + b.uoff, b.ulen) != b.crc) bad = 1;
+                }
+                ld.free_decompressor(d);
+                return;
+            }
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) {
+                bad = 1;
+                return;
+            }
+            for (size_t i = lo; i < hi; ++i) {
+                const Blk &b = blks[i];
+                if (b.ulen == 0) continue;
+                inflateReset(&zs);
+                zs.next_in = (Bytef *)(map + b.coff);
+                zs.avail_in = (uInt)b.clen;
+                zs.next_out = buf.data() + b.uoff;
+                zs.avail_out = (uInt)b.ulen;
+                int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(0L, buf.data() + b.uoff, (uInt)b.ulen) != b.crc) bad = 1;
+            }
+            inflateEnd(&zs);
+        });
+        if (bad) return fail(PLO_ERR_IO, "BGZF block failed to inflate (corrupt data or CRC mismatch)");
+        return PLO_OK;
+    }
+    plo_status read(void *dst, size_t n) {
+        plo_status st = fill(n);
+        if (st != PLO_OK) return st;
+        if (avail() < n) return fail(PLO_ERR_IO, "unexpected end of BAM stream");
+        memcpy(dst, buf.data() + bpos, n);
+        bpos += n;
+        return PLO_OK;
+    }
+};
+
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads) {
+    const size_t piece = 4u << 20;
+    const size_t np = (n + piece - 1) / piece;
+    parallel_for(np, std::min<int>(threads, 16), [&](size_t i) {
+        size_t o = i * piece;
+        memcpy(dst + o, src + o, std::min(piece, n - o));
+    });
+}
+
+// Page-locked when the engine's allocator has a device, plain memory otherwise.  Pinning costs far more than the copy it
+// speeds up, so page-locked blocks go back to a process-wide pool when a window is freed and the next window reuses them.
+struct PinPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> blocks;
+    void *take(size_t want, size_t &cap) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].second >= want && blocks[i].second <= 4 * want + (1u << 20) && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void *p = blocks[best].first;
+        cap = blocks[best].second;
+        blocks.erase(blocks.begin() + (ptrdiff_t)best);
+        return p;
+    }
+    void give(void *p, size_t cap) {
+        std::lock_guard<std::mutex> g(mu);
+        if (blocks.size() >= 256) {  // bounded: drop the smallest
+            size_t k = 0;
+            for (size_t i = 1; i < blocks.size(); ++i)
+                if (blocks[i].second < blocks[k].second) k = i;
+            if (blocks[k].second >= cap) {
+                plo_host_free(p);
+                return;
+            }
+            plo_host_free(blocks[k].first);
+            blocks.erase(blocks.begin() + (ptrdiff_t)k);
+        }
+        blocks.emplace_back(p, cap);
+    }
+};
+PinPool &pin_pool() {
+    static PinPool *p = new PinPool();  // never destroyed: the HIP runtime may be gone by the time static destructors run
+    return *p;
+}
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    void *ensure(size_t bytes) {
+        if (bytes <= cap) return p;
+        release();
+        size_t want = bytes + bytes / 8 + 64;
+        size_t got = 0;
+        void *q = pin_pool().take(want, got);
+        if (q) {
+            pinned = true;
+            want = got;
+        } else if (plo_host_alloc(want, &q) == PLO_OK && q) {
+            pinned = true;
+        } else {
+            q = malloc(want);
+            pinned = false;
+        }
+        p = q;
+        cap = q ? want : 0;
+        return p;
+    }
+    void release() {
+        if (p) {
+            if (pinned) pin_pool().give(p, cap);
+            else free(p);
+        }
+        p = nullptr;
+        cap = 0;
+    }
+    ~HostBuf() { release(); }
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
+// ---- record access (BAM specification 4.2; all offsets after the block_size word) ------------------------------------
+struct Rec {
+    const uint8_t *p;  // first byte after block_size
+    uint32_t len;      // block_size
+    int32_t tid() const { return rdi32(p); }
+    int32_t pos() const { return rdi32(p + 4); }
+    uint32_t l_qname() const { return p[8]; }
+    uint8_t mapq() const { return p[9]; }
+    uint16_t bin() const { return rd16(p + 10); }
+    uint32_t n_cigar() const { return rd16(p + 12); }
+    uint16_t flag() const { return rd16(p + 14); }
+    uint32_t l_seq() const { return rd32(p + 16); }
+    const uint8_t *qname() const { return p + 32; }
+    const uint8_t *cigar() const { return qname() + l_qname(); }
+    const uint8_t *seq() const { return cigar() + 4 * (size_t)n_cigar(); }
+    const uint8_t *qual() const { return seq() + (l_seq() + 1) / 2; }
+    const uint8_t *aux() const { return qual() + l_seq(); }
+    const uint8_t *end() const { return p + len; }
+    bool layout_ok() const { return len >= 32 && (size_t)(aux() - p) <= len; }
+};
+
+// length of the aux field starting at a (tag, type, value), 0 if malformed / beyond e
+size_t aux_field_len(const uint8_t *a, const uint8_t *e) {
+    if (e - a < 3) return 0;
+    size_t n = 0;
+    switch (a[2]) {
+        case 'A': case 'c': case 'C': n = 1; break;
+        case 's': case 'S': n = 2; break;
+        case 'i': case 'I': case 'f': n = 4; break;
+        case 'd': n = 8; break;
+        case 'Z': case 'H': {
+            const uint8_t *z = (const uint8_t *)memchr(a + 3, 0, (size_t)(e - a - 3));
+            if (!z) return 0;
+            n = (size_t)(z - (a + 3)) + 1;
+            break;
+        }
+        case 'B': {
+            if (e - a < 8) return 0;
+            size_t es;
+            switch (a[3]) {
+                case 'c': case 'C': es = 1; break;
+                case 's': case 'S': es = 2; break;
+                case 'i': case 'I': case 'f': es = 4; break;
+                default: return 0;
+            }
+            n = 5 + es * (size_t)rd32(a + 4);
+            break;
+        }
+        default: return 0;
+    }
+    return (3 + n <= (size_t)(e - a)) ? 3 + n : 0;
+}
+// first field with the given tag (bam_aux_get), nullptr if absent
+const uint8_t *aux_find(const uint8_t *a, const uint8_t *e, const char tag[2], size_t *flen) {
+    while (a < e) {
+        size_t n = aux_field_len(a, e);
+        if (!n) return nullptr;
+        if (a[0] == (uint8_t)tag[0] && a[1] == (uint8_t)tag[1]) {
+            if (flen) *flen = n;
+            return a;
+        }
+        a += n;
+    }
+    return nullptr;
+}
+
+// ---- CIGAR helpers (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs) --------------------------------------------------------
+inline bool op_is_match(uint32_t c) {  // :22-24
+    uint32_t t = c & 15u;
+    return t == 0 || t == 7 || t == 8;
+}
+inline uint64_t op_read_len(uint32_t c) {  // get_cigarseg_read_offset, ignore_hard_clip = false (:26-39)
+    return ((0x1B3u >> (c & 15u)) & 1u) ? (uint64_t)(c >> 4) : 0;  // M I S H = X
+}
+inline int64_t op_ref_len(uint32_t c) {  // :41-47
+    return ((0x18Du >> (c & 15u)) & 1u) ? (int64_t)(c >> 4) : 0;  // M D N = X
+}
+// get_read_clip_positions(cigar, false) (:85-118)
+void read_clip_positions(const uint32_t *cig, size_t n, uint64_t &start, uint64_t &end, uint64_t &size) {
+    uint64_t left = 0, right = 0, read_pos = 0;
+    bool left_clip = true;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t t = cig[i] & 15u;
+        if (t == 4 || t == 5) {
+            if (left_clip) left += cig[i] >> 4;
+            else right += cig[i] >> 4;
+        } else {
+            left_clip = false;
+        }
+        read_pos += op_read_len(cig[i]);
+    }
+    start = left;
+    end = read_pos - right;
+    size = read_pos;
+}
+
+struct SaSeg {
+    uint32_t contig;
+    int64_t pos;
+    bool fwd;
+    uint8_t mapq;
+    std::vector<uint32_t> cigar;
+    uint64_t so_start, so_end;
+    bool primary;
+};
+
+bool parse_uint(const char *s, const char *e, uint64_t &v) {
+    if (s == e) return false;
+    v = 0;
+    for (; s < e; ++s) {
+        if (*s < '0' || *s > '9') return false;
+        v = v * 10 + (uint64_t)(*s - '0');
+        if (v > (1ull << 62)) return false;
+    }
+    return true;
+}
+bool parse_int(const char *s, const char *e, int64_t &v) {  // Rust's str::parse::<i64>: optional sign, digits
+    bool neg = false;
+    if (s < e && (*s == '-' || *s == '+')) {
+        neg = *s == '-';
+        ++s;
+    }
+    uint64_t u;
+    if (!parse_uint(s, e, u)) return false;
+    v = neg ? -(int64_t)u : (int64_t)u;
+    return true;
+}
+// CigarString::try_from(&[u8]) of rust-htslib: <digits><op> repeated, ops MIDNSHP=X
+bool parse_cigar_text(const char *s, const char *e, std::vector<uint32_t> &out) {
+    out.clear();
+    while (s < e) {
+        const char *d = s;
+        while (d < e && *d >= '0' && *d <= '9') ++d;
+        uint64_t len;
+        if (d == s || d == e || !parse_uint(s, d, len) || len > 0x0fffffffull) return false;
+        const char *ops = "MIDNSHP=X";
+        const char *o = strchr(ops, *d);
+        if (!o || !*d) return false;
+        out.push_back((uint32_t)(len << 4) | (uint32_t)(o - ops));
+        s = d + 1;
+    }
+    return true;
+}
+
+// get_seq_order_read_split_segments (split_read.rs:56-155) of one primary record.  Long CIGARs stored in the CG tag
+// (more than 65535 ops) are what htslib hands to the reference after bam_read1: the real CIGAR.
+plo_status split_segments(const std::unordered_map<std::string, uint32_t> &label_to_index, const Rec &rec, std::vector<SaSeg> &out, std::vector<uint32_t> &primary_cigar,
+                          std::string &err) {
+    out.clear();
+    const uint32_t nc = rec.n_cigar();
+    primary_cigar.resize(nc);
+    for (uint32_t i = 0; i < nc; ++i) primary_cigar[i] = rd32(rec.cigar() + 4 * (size_t)i);
+    if (nc == 2 && (primary_cigar[0] & 15u) == 4 && (primary_cigar[0] >> 4) == rec.l_seq() && (primary_cigar[1] & 15u) == 3) {
+        size_t fl = 0;
+        const uint8_t *cg = aux_find(rec.aux(), rec.end(), "CG", &fl);
+        if (cg && cg[2] == 'B' && cg[3] == 'I') {
+            uint32_t n = rd32(cg + 4);
+            primary_cigar.resize(n);
+            for (uint32_t i = 0; i < n; ++i) primary_cigar[i] = rd32(cg + 8 + 4 * (size_t)i);
+        }
+    }
+    const bool fwd = !(rec.flag() & 0x10);
+    uint64_t rs, re, rsize;
+    read_clip_positions(primary_cigar.data(), primary_cigar.size(), rs, re, rsize);
+    SaSeg p;
+    p.contig = (uint32_t)rec.tid();
+    p.pos = rec.pos();
+    p.fwd = fwd;
+    p.mapq = rec.mapq();
+    p.primary = true;
+    p.so_start = fwd ? rs : rsize - re;  // get_seq_order_read_pos :78-89
+    p.so_end = fwd ? re : rsize - rs;
+    out.push_back(std::move(p));
+    size_t fl = 0;
+    const uint8_t *sa = aux_find(rec.aux(), rec.end(), "SA", &fl);
+    if (sa) {
+        if (sa[2] != 'Z') {
+            err = "SA aux tag is not a string";  // unexpected_aux_val_err (aux/mod.rs:80-82)
+            return PLO_ERR_DATA;
+        }
+        const char *s = (const char *)sa + 3, *e = (const char *)sa + fl - 1;
+        uint32_t seg_index = 0;
+        while (s < e) {  // split_terminator(';') (sa_tag_parser.rs:55-59)
+            const char *q = (const char *)memchr(s, ';', (size_t)(e - s));
+            const char *se = q ? q : e;
+            // split_terminator(',') (:26): fields between commas, a trailing empty field dropped; exactly six (:27-31)
+            const char *f[6], *fe[6];
+            int nf = 0;
+            bool too_many = false;
+            for (const char *c = s, *start = s;; ++c) {
+                if (c == se || *c == ',') {
+                    if (!(c == se && start == se && se > s)) {  // not the empty field after a trailing comma
+                        if (c == se && start == se && se == s) break;  // empty segment: no fields at all
+                        if (nf == 6) {
+                            too_many = true;
+                            break;
+                        }
+                        f[nf] = start;
+                        fe[nf] = c;
+                        ++nf;
+                    }
+                    if (c == se) break;
+                    start = c + 1;
+                }
+            }
+            if (too_many || nf != 6) {
+                err = "Unexpected segment in bam SA tag: " + std::string(s, se);
+                return PLO_ERR_DATA;
+            }
+            SaSeg g;
+            std::string rname(f[0], fe[0]);
+            int64_t pos1, nm;
+            uint64_t mq;
+            if (!parse_int(f[1], fe[1], pos1) || !parse_cigar_text(f[3], fe[3], g.cigar) || !parse_uint(f[4], fe[4], mq) || mq > 255 ||
+                !parse_int(f[5], fe[5], nm) || nm < INT32_MIN || nm > INT32_MAX) {
+                err = "malformed SA segment: " + std::string(s, se);
+                return PLO_ERR_DATA;
+            }
+            g.pos = pos1 - 1;
+            g.fwd = (fe[2] - f[2] == 1 && f[2][0] == '+');
+            g.mapq = (uint8_t)mq;
+            g.primary = false;
+            bool aligned = false;
+            for (uint32_t c : g.cigar) aligned |= op_is_match(c);
+            if (!aligned) {  // :112-115
+                err = "Bam record split segment id unaligned in read " + std::string((const char *)rec.qname());
+                return PLO_ERR_DATA;
+            }
+            uint64_t s0, e0, sz;
+            read_clip_positions(g.cigar.data(), g.cigar.size(), s0, e0, sz);
+            if (sz != rsize) {  // assert_eq!(primary_read_size, read_size) :118
+                err = "SA segment read length differs from the primary record's in read " + std::string((const char *)rec.qname());
+                return PLO_ERR_DATA;
+            }
+            g.so_start = g.fwd ? s0 : sz - e0;
+            g.so_end = g.fwd ? e0 : sz - s0;
+            auto it = label_to_index.find(rname);
+            if (it == label_to_index.end()) {  // :121-130
+                err = "In read '" + std::string((const char *)rec.qname()) + "', the SA aux tag describes a split read mapped to " + rname +
+                      ", which is not found in the input header";
+                return PLO_ERR_DATA;
+            }
+            g.contig = it->second;
+            out.push_back(std::move(g));
+            ++seg_index;
+            s = q ? q + 1 : e;
+        }
+        (void)seg_index;
+        std::stable_sort(out.begin(), out.end(), [](const SaSeg &a, const SaSeg &b) { return a.so_start < b.so_start; });  // :141
+    }
+    for (const SaSeg &g : out)
+        if (g.so_start >= g.so_end) {  // :146-152
+            err = "Can't parse consistent split read information from SA tag format in read: " + std::string((const char *)rec.qname());
+            return PLO_ERR_DATA;
+        }
+    return PLO_OK;
+}
+
+
+}  // namespace
