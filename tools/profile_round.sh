@@ -1,11 +1,25 @@
+#!/bin/bash
+# usage (GPU box): tools/profile_round.sh <version tag>  -- bench line, rocprofv3 kernel stats of the same command, PMC passes
+# (one counter group per pass, --pmc never combined with trace domains other than the kernel trace); then the stress workload.
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/v11
-python bench.py > gpurun_out/v11/bench.json 2>/dev/null
-rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline > gpurun_out/v11/bench_under_rocprof.json 2>/dev/null
-f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/v11/kernel_stats.csv
-tools/pmc_pass.sh "FETCH_SIZE" "k_lift" > gpurun_out/v11/pmc_fetch.csv 2>&1
-tools/pmc_pass.sh "WRITE_SIZE" "k_lift" > gpurun_out/v11/pmc_write.csv 2>&1
-tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" > gpurun_out/v11/pmc_sq1.csv 2>&1
-tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" > gpurun_out/v11/pmc_sq2.csv 2>&1
-head -c 600 gpurun_out/v11/bench.json; echo; head -8 gpurun_out/v11/kernel_stats.csv; cat gpurun_out/v11/pmc_*.csv
+v=${1:-v1}
+o=gpurun_out/$v
+mkdir -p $o
+python bench.py > $o/bench.json 2>/dev/null
+rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --e2e-reads 0 > $o/bench_under_rocprof.json 2>/dev/null
+f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/kernel_stats.csv
+PMC_EXTRA="--e2e-reads 0"
+tools/pmc_pass.sh "FETCH_SIZE" "k_lift" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
+tools/pmc_pass.sh "WRITE_SIZE" "k_lift" $PMC_EXTRA > $o/pmc_write.csv 2>&1
+tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "k_lift_tiles" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
+tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "k_lift_tiles" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
+# stress: the workgroup-per-item kernel
+S="--workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0"
+python bench.py $S > $o/stress_bench.json 2>/dev/null
+rm -rf /tmp/kt2; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 bench.py $S --no-cpu-baseline > $o/stress_bench_under_rocprof.json 2>/dev/null
+f=$(find /tmp/kt2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/stress_kernel_stats.csv
+tools/pmc_pass.sh "FETCH_SIZE" "k_lift_mid" $S > $o/stress_pmc_fetch.csv 2>&1
+tools/pmc_pass.sh "WRITE_SIZE" "k_lift_mid" $S > $o/stress_pmc_write.csv 2>&1
+tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "k_lift_mid" $S > $o/stress_pmc_sq1.csv 2>&1
+head -c 400 $o/bench.json; echo; grep "k_lift" $o/kernel_stats.csv | head -5; grep "k_lift" $o/stress_kernel_stats.csv | head -5; cat $o/pmc_*.csv $o/stress_pmc_*.csv

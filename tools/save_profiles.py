@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ver = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = f"gpurun_out/{ver}"
 pre = f"profiles/{rnd}_{ver}_wgs30x"
 rows = list(csv.reader(open(f"{src}/kernel_stats.csv")))
@@ -16,7 +16,7 @@ hdr, body = rows[0], rows[1:]
 tot = sum(int(r[2]) for r in body)
 eng = [r for r in body if r[0].startswith("k_")]
 with open(f"{pre}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (default workload wgs30x, 10 steps + 2 warm-up)\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --e2e-reads 0   (default workload wgs30x, 10 steps + 2 warm-up)\n")
     f.write(f"# rows of the engine kernels only (the other {len(body) - len(eng)} rows are torch kernels of the synthetic generator); total traced kernel time {tot} ns\n")
     w = csv.writer(f)
     w.writerow(hdr)
@@ -32,7 +32,7 @@ def rd(p):
 
 fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
 with open(f"{pre}_pmc_summary.csv", "w") as f:
-    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_tiles --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_tiles --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0\n")
     f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of k_lift_tiles; FETCH_SIZE / WRITE_SIZE in KiB\n")
     f.write("counter,mean_per_launch,launches\n")
     for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
@@ -49,3 +49,34 @@ print(json.dumps(b["roofline"]))
 print(b["value"], b["ms_per_step"], b["cpu_baseline"]["value"])
 for r in eng[:4]:
     print(r[0][:40], r[1], r[3])
+
+# ---- stress workload: the workgroup-per-item kernel --------------------------------------------------------------------------
+if os.path.exists(f"{src}/stress_kernel_stats.csv"):
+    pre = f"profiles/{rnd}_{ver}_stress"
+    rows = list(csv.reader(open(f"{src}/stress_kernel_stats.csv")))
+    eng = [r for r in rows[1:] if r[0].startswith("k_") or "k_lift" in r[0]]
+    with open(f"{pre}_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0 --no-cpu-baseline\n")
+        f.write("# rows of the engine kernels only\n")
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in eng:
+            w.writerow(r)
+    shutil.copy(f"{src}/stress_bench.json", f"{pre}_bench.json")
+    shutil.copy(f"{src}/stress_bench_under_rocprof.json", f"{pre}_bench_under_rocprof.json")
+    sfe, swr = rd(f"{src}/stress_pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/stress_pmc_write.csv")["WRITE_SIZE"]
+    with open(f"{pre}_pmc_summary.csv", "w") as f:
+        f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_mid --output-format csv -- python3 bench.py --workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0 --no-cpu-baseline\n")
+        f.write("# one pass per counter group; value = mean over the launches of k_lift_mid; FETCH_SIZE / WRITE_SIZE in KiB\n")
+        f.write("counter,mean_per_launch,launches\n")
+        for p in ["stress_pmc_fetch", "stress_pmc_write", "stress_pmc_sq1"]:
+            for l in open(f"{src}/{p}.csv"):
+                if "," in l:
+                    f.write(l)
+    sb = json.load(open(f"{src}/stress_bench.json"))
+    h["stress"] = {"k_lift_mid": int((2 * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr,
+                   "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"]}
+    json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
+    print(h["stress"])
+    print(json.dumps(sb["roofline"]))
+    print(sb["value"], sb["ms_per_step"])
