@@ -130,6 +130,10 @@ class Engine:
     (src/worker_thread_data.rs:8-18)."""
 
     def __init__(self, index: Index, stream: Optional[int] = None):
+        """stream: a hipStream_t handle to run on, or None / 0 for a private (non-blocking) stream of the context.  torch's
+        *default* stream is the NULL handle, i.e. 0: a context created with `torch.cuda.current_stream().cuda_stream` while the
+        default stream is current gets a private stream and is NOT ordered behind torch work -- synchronise before handing it
+        tensors torch has just written (devbatch.run_and_download does), or run under a `torch.cuda.Stream` of your own."""
         self.lib = index.lib
         self.index = index
         h = C.c_void_p()

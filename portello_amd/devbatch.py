@@ -68,6 +68,16 @@ class DeviceBatch:
             seg_cigar_off=(co - c0).to(torch.int32).contiguous(), cigar=w.cigar[c0:c1].to(torch.int32).contiguous())
 
     @classmethod
+    def from_batch_data(cls, b: abi.BatchData, device="cuda") -> "DeviceBatch":
+        """upload of a host-side batch (numpy arrays) as it is"""
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.itemsize == np.dtype(dt).itemsize else
+                                           np.ascontiguousarray(a).astype(dt)).to(device)
+        return cls(read_is_reverse=t(b.read_is_reverse, np.uint8), read_seq_len=t(b.read_seq_len, np.int32), read_seq_off=t(b.read_seq_off, np.int64),
+                   seq=t(b.seq if len(b.seq) else np.zeros(1, np.uint8), np.uint8), seq_fmt=b.seq_fmt, seg_read=t(b.seg_read, np.int32),
+                   seg_contig=t(b.seg_contig, np.int32), seg_pos=t(b.seg_pos, np.int64), seg_is_fwd_strand=t(b.seg_is_fwd_strand, np.uint8),
+                   seg_cigar_off=t(b.seg_cigar_off, np.int32), cigar=t(b.cigar if len(b.cigar) else np.zeros(1, np.uint32), np.int32))
+
+    @classmethod
     def from_read_ranges(cls, w, ranges) -> "DeviceBatch":
         """The reads of several ranges [lo, hi) of a workload as ONE batch (a rank's windows, portello_amd/shard.py):
         the slices are concatenated, offsets re-based.  Read r of range k becomes read (reads of ranges < k) + r - lo."""

@@ -17,6 +17,8 @@ from portello_amd import abi, api, devbatch, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=200000)
 ap.add_argument("--cases", default="1e-4:0.5:1,1e-3:0.5:2,2e-3:0.3:3,5e-4:1.0:4,3e-3:0.5:5")
+ap.add_argument("--workload", default="chr20", help="chr20 (default) or stress_small: the heavy items of the latter all take the "
+                                                     "workgroup-per-item kernel (vary PLO_MID_WAVES / PLO_MID_CAP in the environment)")
 args = ap.parse_args()
 pyoracle.build()
 dev = torch.device("cuda", 0)
@@ -25,11 +27,13 @@ bad = 0
 for case in args.cases.split(","):
     rate, rev, seed = case.split(":")
     cr = synth.EditRates(mismatch=1e-3, ins=float(rate), dele=float(rate), hpol_frac=0.3, big_indel_prob=0.02)
-    cfg = synth.config("chr20", n_reads=args.reads, rev_contig_frac=float(rev), contig_rates=cr, seed=synth.config("chr20").seed + int(seed))
+    cfg = synth.config(args.workload, n_reads=args.reads, rev_contig_frac=float(rev), contig_rates=cr, seed=synth.config(args.workload).seed + int(seed))
     w = synth.generate(cfg, device=dev)
     index = api.Index(w.index_data_device(), 0)
     eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
     db = devbatch.DeviceBatch.from_workload(w)
+    torch.cuda.synchronize()  # torch's default stream is the NULL handle, for which the engine creates a private stream: the batch's
+    # tensors must be complete before the engine's stream reads them
     out = eng.liftover_batch_dev(db.desc())
     t = eng.timing()
     got = devbatch.download(eng, out)
@@ -39,8 +43,8 @@ for case in args.cases.split(","):
     a, b = got.canonical(), ref.canonical()
     same = a == b
     bad += 0 if same else 1
-    print(f"case contig-indel {rate} rev {rev} seed {seed}: {t.n_items} items, {t.n_big_items} large, {t.n_retry_items} retried, "
-          f"tiles {t.lift_ms:.3f} ms, oracle {dt:.1f} s -> {'IDENTICAL' if same else 'MISMATCH'}", flush=True)
+    print(f"case contig-indel {rate} rev {rev} seed {seed}: {t.n_items} items, {t.n_mid_items} workgroup-per-item ({t.mid_ms:.2f} ms), {t.n_big_items} large, "
+          f"{t.n_retry_items} retried, tiles {t.lift_ms:.3f} ms, oracle {dt:.1f} s -> {'IDENTICAL' if same else 'MISMATCH'}", flush=True)
     eng.close()
     index.close()
 sys.exit(1 if bad else 0)
