@@ -21,7 +21,9 @@
 
 #include "../../include/portello_bam.h"
 
-void plo_bam_set_error(const std::string &msg);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
+void plo_bam_set_error(const std::string &msg);
+// engine.hip: all BGZF blocks of a chunk inflated on the device (one thread per block); < 0 = not done, inflate on the host
+extern "C" int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
 
 namespace {
 
@@ -73,19 +75,31 @@ void parallel_ranges(size_t n, int threads, F fn) {
 struct RawBuf {
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
+    bool pinned = false;  // page-locked (plo_host_alloc): the destination of device-to-host copies
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    ~RawBuf() {
+        if (pinned) plo_host_free(p);
+        else free(p);
+    }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
     bool resize(size_t want) {  // keeps the first min(n, want) bytes
         if (want > cap) {
             size_t nc = std::max(want, cap + cap / 2);
-            uint8_t *q = (uint8_t *)realloc(p, nc ? nc : 1);
-            if (!q) return false;
-            p = q;
+            if (pinned) {
+                void *q = nullptr;
+                if (plo_host_alloc(nc ? nc : 1, &q) != PLO_OK || !q) return false;
+                if (n) memcpy(q, p, std::min(n, want));
+                plo_host_free(p);
+                p = (uint8_t *)q;
+            } else {
+                uint8_t *q = (uint8_t *)realloc(p, nc ? nc : 1);
+                if (!q) return false;
+                p = q;
+            }
             cap = nc;
         }
         n = want;
@@ -153,10 +167,16 @@ struct BgzfIn {
     const uint8_t *map = nullptr;
     size_t size = 0, cpos = 0;
     RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
+    RawBuf cstage;  // device inflate: page-locked copy of a chunk's compressed bytes
     size_t bpos = 0;
     int threads = 1;
     bool eof = false;
+    int device = -1;  // -1 undecided, 0 host inflate, 1 blocks of a chunk are inflated on the GPU (PLO_BGZF_DEVICE=1 switches it on)
     static constexpr size_t CHUNK = 256u << 20;
+    struct DevBlk {  // engine.hip's BgzfBlk
+        unsigned long long coff, uoff;
+        uint32_t clen, ulen;
+    };
 
     struct Blk {
         size_t coff, clen, uoff, ulen;
@@ -195,9 +215,28 @@ struct BgzfIn {
             bpos = 0;
         }
         const size_t cpos0 = cpos;
+        if (device < 0) {
+            // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 5.6 GB/s (23 ms per 64 KiB block, 4 096 blocks in
+            // flight; input bytes and match sources come from global memory one round trip at a time), which with the transfers
+            // is no faster than 16 host cores of libdeflate (3.4 GB/s) -- see DESIGN.md for what it needs to get ahead
+            const char *e = getenv("PLO_BGZF_DEVICE");
+            device = (e && atoi(e) != 0) ? 1 : 0;
+            if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays
+                void *q = nullptr;
+                if (buf.p == nullptr && plo_host_alloc(CHUNK + CHUNK / 2, &q) == PLO_OK && q) {
+                    buf.p = (uint8_t *)q;
+                    buf.cap = CHUNK + CHUNK / 2;
+                    buf.pinned = true;
+                } else {
+                    device = 0;
+                }
+            }
+        }
         std::vector<Blk> blks;
         size_t u = buf.size();
-        const size_t target = std::max(want, CHUNK);
+        // always a whole chunk of NEW data: a window larger than one chunk must not degenerate into one small refill (thread
+        // start-up, or a device round trip) per record
+        const size_t target = std::max(want, u + CHUNK);
         while (cpos < size && u < target) {
             if (size - cpos < 28) return fail(PLO_ERR_IO, "truncated BGZF block header");
             const uint8_t *h = map + cpos;
@@ -226,6 +265,31 @@ struct BgzfIn {
         if (cpos > cpos0) madvise((void *)(map + (cpos0 & ~(size_t)4095)), cpos - (cpos0 & ~(size_t)4095), MADV_WILLNEED);
         if (!buf.resize(u)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the inflated BAM stream");
         std::atomic<int> bad{0};
+        if (device == 1 && !blks.empty()) {
+            // the whole chunk on the GPU; CRCs on the host afterwards (libdeflate's CRC runs at memory speed)
+            std::vector<DevBlk> db(blks.size());
+            const size_t c0 = blks.front().coff, u0 = blks.front().uoff;
+            for (size_t i = 0; i < blks.size(); ++i) db[i] = DevBlk{blks[i].coff - c0, blks[i].uoff - u0, (uint32_t)blks[i].clen, (uint32_t)blks[i].ulen};
+            const size_t cbytes = blks.back().coff + blks.back().clen - c0, ubytes = u - u0;
+            // the compressed bytes go through a page-locked staging buffer: a large host-to-device copy straight from the file
+            // mapping makes the runtime pin file-backed pages, which is far slower than this parallel copy
+            int rc = -101;
+            cstage.pinned = true;
+            if (cstage.resize(cbytes + 16)) {
+                parallel_copy(cstage.data(), map + c0, cbytes, threads);
+                rc = plo_internal_bgzf_inflate(cstage.data(), cbytes, db.data(), (uint32_t)db.size(), buf.data() + u0, ubytes);
+            }
+            if (rc == 0) {
+                parallel_for(blks.size(), threads, [&](size_t i) {
+                    const Blk &b = blks[i];
+                    if (b.ulen && fast_crc32(buf.data() + b.uoff, b.ulen) != b.crc) bad = 1;
+                });
+                if (bad) return fail(PLO_ERR_IO, "BGZF block CRC mismatch after device inflate");
+                return PLO_OK;
+            }
+            if (rc <= -100 && rc > -200) device = 0;  // no usable device: stay on the host from now on
+            // a block the device rejects is inflated again on the host, which reports what is wrong with it
+        }
         parallel_ranges(blks.size(), threads, [&](size_t lo, size_t hi) {
             const LibDeflate &ld = libdeflate();
             if (ld.ok) {

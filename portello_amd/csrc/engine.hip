@@ -25,12 +25,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "enumerate.hpp"
 #include "finish_core.hpp"
 #include "index_pack.hpp"
+#include "inflate.hpp"
 #include "lift_core.hpp"
 
 using namespace plo;
@@ -461,6 +463,33 @@ __global__ __launch_bounds__(256) void k_revcomp(DevBatch bt, DevWork wk, DevFin
         uint32_t read = e < n ? f.item_read[e] : e - n;
         revcomp_record(bt, f, read, f.rev_seq + (uint64_t)f.soff[e] * 16u, f.rev_qual + (uint64_t)f.qoff[e] * 16u, (int)threadIdx.x,
                        (int)blockDim.x);
+    }
+}
+
+// ---- BGZF inflate (inflate.hpp): every block of a chunk of the BAM stream at once, one wave per block ----------------------
+struct BgzfBlk {
+    unsigned long long coff, uoff;  // offsets of the block's deflate data / inflated bytes inside the chunk buffers
+    uint32_t clen, ulen;
+};
+struct InfWave {  // the lanes of one wave run the decoder together (inflate.hpp)
+    PLO_DEV int lane() const { return wv::lane(); }
+    PLO_DEV int width() const { return 64; }
+    PLO_DEV void sync() const {  // LDS tables and the wave's own global stores (match sources) are visible to all its lanes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    PLO_DEV uint32_t uniform(uint32_t v) const { return wv::bcast_first(v); }
+};
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfBlk *blks, uint32_t n, uint8_t *out, int *status) {
+    __shared__ InfWork ws;
+    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+        const BgzfBlk k = blks[b];
+        uint32_t w = 0;
+        int rc = k.ulen ? inflate_block(InfWave{}, comp + k.coff, k.clen, out + k.uoff, k.ulen, ws, &w) : 0;
+        if (rc == 0 && w != k.ulen) rc = -9;  // the stream ended before ISIZE bytes
+        if (wv::lane() == 0) status[b] = rc;
+        InfWave{}.sync();
     }
 }
 
@@ -1491,6 +1520,54 @@ plo_status plo_compact_output_dev(plo_ctx *c, plo_batch_out *out) {
     out->n_cigar = total;
     c->dense_total = total;
     return PLO_OK;
+}
+
+// Inflates the n BGZF blocks of one chunk on the device (bam_host.cpp's reader when PLO_BGZF_DEVICE is not 0): `comp` = the
+// chunk's compressed bytes (host, pageable or pinned), `blks` = BgzfBlk[n] with offsets inside comp / out, `out` = host
+// destination (page-locked for a direct DMA).  Returns 0, or a negative number when the device is unusable / a block is corrupt
+// (the caller then inflates on the host, which also produces the diagnostics).  Not part of the public ABI.
+int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
+    static std::mutex mu;
+    static DevBuf d_comp, d_out, d_blk, d_st;
+    static hipStream_t st = nullptr;
+    static int dev_ok = -1;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev_ok < 0) {
+        int nd = 0;
+        dev_ok = (hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) ? 1 : 0;
+    }
+    if (!dev_ok) return -100;
+    if (!n) return 0;
+    if (d_comp.ensure(comp_bytes + 16) != hipSuccess || d_out.ensure(out_bytes + 16) != hipSuccess || d_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess ||
+        d_st.ensure((size_t)n * 4) != hipSuccess)
+        return -101;
+    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const bool dbg = getenv("PLO_DEBUG_INFLATE") != nullptr;
+    if (dbg && !ev[0])
+        for (auto &e : ev) (void)hipEventCreate(&e);
+    if (dbg) (void)hipEventRecord(ev[0], st);
+    if (hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
+    if (hipMemcpyAsync(d_blk.p, blks, (size_t)n * sizeof(BgzfBlk), hipMemcpyHostToDevice, st) != hipSuccess) return -102;
+    if (dbg) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>(n, 256u * 16u)), dim3(64), 0, st, (const uint8_t *)d_comp.p, (const BgzfBlk *)d_blk.p, n,
+                       (uint8_t *)d_out.p, (int *)d_st.p);
+    if (hipGetLastError() != hipSuccess) return -103;
+    if (dbg) (void)hipEventRecord(ev[2], st);
+    if (hipMemcpyAsync(out, d_out.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
+    std::vector<int> stv(n);
+    if (hipMemcpyAsync(stv.data(), d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
+    if (dbg) (void)hipEventRecord(ev[3], st);
+    if (hipStreamSynchronize(st) != hipSuccess) return -105;
+    if (dbg) {
+        float a = 0, b = 0, c2 = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&c2, ev[2], ev[3]);
+        fprintf(stderr, "[plo] device inflate: %u blocks, %.1f MB -> %.1f MB: H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", n, comp_bytes / 1e6, out_bytes / 1e6, a, b, c2);
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (stv[i] != 0) return -200;
+    return 0;
 }
 
 plo_status plo_host_alloc(size_t bytes, void **out) {

@@ -724,6 +724,9 @@ struct WaveCtx {
     unsigned long long algo_bytes = 0;  // per lane
     unsigned long long in_ops = 0;      // per lane
     unsigned long long out_ops = 0;     // per lane
+#ifdef PLO_PHASE_TIMING
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader cycles per pipeline phase, flushed once per wave
+#endif
 };
 constexpr unsigned long long SLAB_OPS = 16384;
 
@@ -745,6 +748,10 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx, uint32_t slot) {
     ctx.algo_bytes = 0;
     ctx.in_ops = 0;
     ctx.out_ops = 0;
+#ifdef PLO_PHASE_TIMING
+    if (wv::lane() == 0)
+        for (int k = 0; k < 12; ++k) wv::atomic_add_global(&wk.counters[CNT_PHASE0 + k], (unsigned long long)ctx.tph[k]);
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -766,12 +773,11 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     const bool last_resort = level == LEVEL_LAST;
     const int lane = wv::lane();
 #ifdef PLO_PHASE_TIMING
-    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = wv::clock();
 #define PLO_T(k)                      \
     {                                 \
         long long now_ = wv::clock(); \
-        tph[k] += now_ - tlast;       \
+        ctx.tph[k] += now_ - tlast;   \
         tlast = now_;                 \
     }
 #else
@@ -1706,10 +1712,6 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     ctx.in_ops += (has && co.lead()) ? (unsigned long long)n_in : 0ull;
     ctx.out_ops += co.lead() ? (unsigned long long)oc : 0ull;
     PLO_T(9)
-#ifdef PLO_PHASE_TIMING
-    if (lane == 0)
-        for (int k = 0; k < 12; ++k) wv::atomic_add_global(&wk.counters[CNT_PHASE0 + k], (unsigned long long)tph[k]);
-#endif
 #undef PLO_T
 }
 

@@ -8,6 +8,7 @@
 #include "../../portello_amd/csrc/enumerate.hpp"
 #include "../../portello_amd/csrc/finish_core.hpp"
 #include "../../portello_amd/csrc/index_pack.hpp"
+#include "../../portello_amd/csrc/inflate.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
 
 using namespace plo;
@@ -436,4 +437,35 @@ extern "C" int emu_sa_segments(const plo_batch_out *lift, const uint16_t *item_f
 extern "C" void emu_sa_free(uint32_t *off, uint8_t *text) {
     free(off);
     free(text);
+}
+
+// the device's DEFLATE decoder (inflate.hpp) executed on the host: serially, and by the 64 lanes of an emulated wave
+extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *written) {
+    plo::InfWork ws;
+    return plo::inflate_block(plo::InfSerial{}, in, in_len, out, out_len, ws, written);
+}
+namespace {
+struct InfEmuWave {
+    int lane() const { return wv::lane(); }
+    int width() const { return 64; }
+    void sync() const { wv::sync(); }
+    uint32_t uniform(uint32_t v) const { return (uint32_t)wv::bcast_first((int)v); }
+};
+}  // namespace
+extern "C" int emu_inflate_wave(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *written, unsigned order_seed) {
+    plo::InfWork ws;
+    int rc_all[64];
+    uint32_t w_all[64];
+    wv::EmuWave w;
+    w.order_seed = order_seed;
+    w.run([&]() {
+        uint32_t wr = 0;
+        int rc = plo::inflate_block(InfEmuWave{}, in, in_len, out, out_len, ws, &wr);
+        rc_all[wv::lane()] = rc;
+        w_all[wv::lane()] = wr;
+    });
+    for (int l = 1; l < 64; ++l)
+        if (rc_all[l] != rc_all[0] || (rc_all[0] == 0 && w_all[l] != w_all[0])) return -1000;  // the lanes must agree
+    *written = w_all[0];
+    return rc_all[0];
 }

@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False, sanitize=False):
     srcs = [os.path.join(_HERE, "emu", "emu_harness.cpp"), os.path.join(_HERE, "emu", "plo_wave.hpp")] + [
-        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
+        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "emu"),

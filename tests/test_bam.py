@@ -356,3 +356,32 @@ def test_bam_to_bam_through_the_hip_engine(oracle, tmp_path):
     assert out_recs == all_out and text.startswith("@HD\tVN:1.6\tSO:unsorted\n") and [n for n, _ in refs] == rn
     eng.close()
     index.close()
+
+
+@pytest.mark.gpu
+def test_device_inflate_matches_host_inflate(tmp_path, monkeypatch):
+    """the BGZF blocks of a chunk inflated on the GPU (one thread per block, portello_amd/csrc/inflate.hpp) give the same
+    records as zlib / libdeflate on the host, for stored, fast and well-compressed files"""
+    import time
+
+    w = synth.generate(synth.config("tiny", n_reads=1500, seed=413, split_read_frac=0.2, sorted_reads=True))
+    for level in (0, 1, 9):
+        path = str(tmp_path / f"r{level}.bam")
+        bamsynth.write_read_bam(w, path, level=level)
+        got = {}
+        for dev in ("0", "1"):
+            monkeypatch.setenv("PLO_BGZF_DEVICE", dev)
+            t0 = time.perf_counter()
+            rd = bam.BamReader(path, 4)
+            wins = []
+            while True:
+                win = rd.read_window(400)
+                if win is None:
+                    break
+                b = win.batch_data()
+                wins.append((b.n_reads, b.seq.tobytes(), b.cigar.tobytes(), b.seg_pos.tobytes(), win.unmapped_bytes()))
+                win.close()
+            rd.close()
+            got[dev] = wins
+            print(f"level {level} device {dev}: {time.perf_counter() - t0:.3f} s")
+        assert got["0"] == got["1"] and sum(x[0] for x in got["1"]) == w.n_reads
