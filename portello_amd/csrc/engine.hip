@@ -52,7 +52,8 @@ constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 
 // outside its array (PLO_ERR_INVALID_ARG), bit 1 = a coordinate outside the 31-bit BAM range, an op code above 8 or a CIGAR
 // spanning more than 2^30 bases (PLO_ERR_RANGE) -- what the reference's types rule out by construction.
 enum { VERR_INDEX = 1u, VERR_RANGE = 2u };
-__global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen, uint32_t *err) {
+__global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen, uint32_t *seg_readlen,
+                                                   uint32_t *err) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = t / SEG_LANES, sub = t % SEG_LANES;
     const bool live = s < bt.n_segs;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
         g1 = ix.contig_seg_off[contig + 1];  // g0 == g1: contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
     }
     long long part = 0;
+    unsigned long long rpart = 0;  // read bases the CIGAR consumes (M I S H = X): what the length check compares with seq_len
     for (uint32_t i = c0 + sub; i < c1; i += SEG_LANES * SEG_UNROLL) {  // independent loads in flight
         uint32_t c[SEG_UNROLL];
 #pragma unroll
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
 #pragma unroll
         for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
             if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
+            if ((0x1B3 >> (c[u] & 15u)) & 1) rpart += (unsigned long long)(c[u] >> 4);
             if ((c[u] & 15u) > 8u) bad |= VERR_RANGE;
         }
     }
@@ -109,7 +112,10 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
         ce = (long long)ix.cs_end[gl];
     }
 #pragma unroll
-    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) part += __shfl_xor(part, (int)d, 64);
+    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) {
+        part += __shfl_xor(part, (int)d, 64);
+        rpart += (unsigned long long)__shfl_xor((long long)rpart, (int)d, 64);
+    }
     if (part > 0x3fffffffLL) bad |= VERR_RANGE;
     if (bad) atomicOr(err, bad);
     const long long r_end = r_start + part;
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     for (uint32_t d = 1; d < SEG_LANES; d <<= 1) n += (uint32_t)__shfl_xor((int)n, (int)d, 64);
     if (!live || sub != 0) return;
     seg_reflen[s] = (int)part;
+    seg_readlen[s] = rpart > 0xfffffffeull ? 0xffffffffu : (uint32_t)rpart;
     seg_cnt[s] = n;
 }
 
@@ -603,9 +610,9 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr;
+    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
-        d_chrom_ref, d_chrom_ref_len;
+        d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
     DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense, wave_stats;
     // host staging for plo_liftover_batch
@@ -869,10 +876,10 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
-                      &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
+                      &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
                       &c->i_item_seg, &c->i_item_cseg};
@@ -974,9 +981,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->seg_cnt.ensure((size_t)std::max(1u, ns) * 4));
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
+        HIP_TRY(c, c->seg_readlen.ensure((size_t)std::max(1u, ns) * 4));
         if (ns)
             hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt,
-                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>(), c->verr.as<uint32_t>());
+                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->verr.as<uint32_t>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
         uint32_t *h = c->h_counters.as<uint32_t>();
@@ -1016,6 +1024,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->d_shift_ref_len.ensure(ni * 4));
     HIP_TRY(c, c->d_chrom_ref.ensure(ni * 8));
     HIP_TRY(c, c->d_chrom_ref_len.ensure(ni * 4));
+    HIP_TRY(c, c->d_read_len.ensure(ni * 4));
     HIP_TRY(c, c->o_status.ensure(ni));
     HIP_TRY(c, c->o_flip.ensure(ni));
     HIP_TRY(c, c->o_mapq.ensure(ni));
@@ -1051,6 +1060,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.d.shift_ref_len = c->d_shift_ref_len.as<int>();
     wk.d.chrom_ref = c->d_chrom_ref.as<uint64_t>();
     wk.d.chrom_ref_len = c->d_chrom_ref_len.as<int>();
+    wk.d.read_len = c->d_read_len.as<uint32_t>();
+    wk.seg_readlen = c->seg_readlen.as<uint32_t>();
     wk.status = c->o_status.as<uint8_t>();
     wk.flip = c->o_flip.as<uint8_t>();
     wk.mapq = c->o_mapq.as<uint8_t>();

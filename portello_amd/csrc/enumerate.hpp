@@ -19,6 +19,17 @@ PLO_DEV long long segment_ref_len(const DevBatch &bt, uint32_t seg) {
     return r;
 }
 
+// get_cigar_read_offset(cigar, false) (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:164-170), saturated at 2^32 - 1
+PLO_DEV uint32_t segment_read_len_sat(const DevBatch &bt, uint32_t seg) {
+    uint32_t c0 = bt.seg_cigar_off[seg], c1 = bt.seg_cigar_off[seg + 1];
+    unsigned long long r = 0;
+    for (uint32_t i = c0; i < c1; ++i) {
+        uint32_t c = bt.cigar[i];
+        if ((0x1B3 >> (c & 15u)) & 1) r += (unsigned long long)(c >> 4);  // M I S H = X
+    }
+    return r > 0xfffffffeull ? 0xffffffffu : (uint32_t)r;
+}
+
 // block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
 PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
     while (lo < hi) {
@@ -164,6 +175,11 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     uint32_t chrom = ix.cs_chrom[gseg];
     wk.d.chrom_ref[i] = (uint64_t)(uintptr_t)ix.chrom_seq[chrom];
     wk.d.chrom_ref_len[i] = ix.chrom_len[chrom];
+    // The length check of src/read_alignment_scanner.rs:204-229 compares seq_len with the read bases the LIFTED CIGAR consumes.
+    // Neither left_shift_indels nor liftover_read_alignment changes that number: the shift re-emits the same match / insertion
+    // bases; the liftover turns every read-consuming piece into M, I or S of the same length (:102-123), copies I / S / H ops
+    // (:157-160), and its edge clean-up turns insertions into clips of the same length.  So the check is made on the input CIGAR.
+    wk.d.read_len[i] = wk.seg_readlen ? wk.seg_readlen[seg] : segment_read_len_sat(bt, seg);
     // outputs that do not depend on the CIGAR pipeline
     wk.flip[i] = (uint8_t)flip;
     wk.mapq[i] = ix.cs_mapq[gseg];

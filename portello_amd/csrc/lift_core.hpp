@@ -34,6 +34,7 @@ struct TileMem {
     int *itl;  // [64] last match index   (clean-up)
     int *its;  // [64] leading-deletion shift (clean-up) / ref2_start (liftover)
     int *itp;  // [64] panic flags
+    int *itq;  // [64] first piece of the item (liftover)
     int *K, *V;  // [capk] block-map entries (key, val) of the tile's items, staged once per tile
     int cap;
     int capk;
@@ -42,7 +43,7 @@ constexpr int tile_capk(int cap) { return cap / 2; }
 // capk < 0: room for cap / 2 staged block-map entries (a tile of many short items); the workgroup-per-item kernel stages
 // the window of ONE item and passes a fixed number (longer windows are read from global memory)
 constexpr size_t tile_mem_bytes(int cap, int capk = -1) {
-    return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 5 * 64 * 4 + (size_t)(capk < 0 ? tile_capk(cap) : capk) * 8;
+    return (size_t)cap * (4 + 4 + 1 + 1 + 5 * 4) + 6 * 64 * 4 + (size_t)(capk < 0 ? tile_capk(cap) : capk) * 8;
 }
 
 PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap, int capk = -1) {
@@ -59,8 +60,9 @@ PLO_DEV TileMem carve_tile_mem(unsigned char *base, int cap, int capk = -1) {
     m.itl = m.itf + 64;
     m.its = m.itl + 64;
     m.itp = m.its + 64;
+    m.itq = m.itp + 64;
     m.capk = capk < 0 ? tile_capk(cap) : capk;
-    m.K = m.itp + 64;
+    m.K = m.itq + 64;
     m.V = m.K + m.capk;
     m.idA = (uint8_t *)(m.V + m.capk);
     m.idB = m.idA + cap;
@@ -407,11 +409,8 @@ PLO_DEV void finish_counts(const int *E, int s, int c, int &ns, int &nc) {
 // -------------------------------------------------------------------------------------------------------------------
 template <int NW>
 PLO_DEV void cleanup_compress(Coop<NW> &co, TileMem &m, uint32_t *X, uint8_t *idX, uint32_t *Y, uint8_t *idY, int n, int &s, int &c,
-                              bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false, int *read_len = nullptr) {
-    // read_len (optional, [64] in LDS): per item, the read bases its CIGAR consumes -- the edge clean-up and the merge do not
-    // change that sum, so it is taken from the raw ops on the way (saves the length check its own pass)
+                              bool active, int &shift, int &n_out, bool &indel_pairs, bool edges_known = false) {
     const int lane = wv::lane();
-    if (read_len) read_len[lane] = 0;
     if (!edges_known) {
         m.itf[lane] = IMAX;
         m.itl[lane] = -1;
@@ -468,7 +467,7 @@ PLO_DEV void cleanup_compress(Coop<NW> &co, TileMem &m, uint32_t *X, uint8_t *id
         MaxScanT<NW> lasta(co, -1);
         AddScanT<NW> heads(co);
         bool pairs = false;
-        int rl_acc = 0, shift_acc = 0;  // NW > 1: per-lane sums of the one item, one LDS atomic per wave at the end
+        int shift_acc = 0;  // NW > 1: per-lane sum of the one item, one LDS atomic per wave at the end
         PLO_CHUNKS(base, n) {
             int e = base + lane;
             bool valid = e < n;
@@ -477,11 +476,6 @@ PLO_DEV void cleanup_compress(Coop<NW> &co, TileMem &m, uint32_t *X, uint8_t *id
             int i_act = co.item((int)active, id);
             uint32_t cc = valid ? X[e] : 0;
             int t = op_type(cc), L = op_len(cc);
-            if constexpr (NW > 1) {
-                if (valid && read_consuming(t)) rl_acc += L;
-            } else {
-                if (read_len && valid && read_consuming(t) && L > 0) wv::atomic_add(&read_len[id], L);
-            }
             int f = IMAX, l = -1;
             if (valid && i_act) {
                 f = m.itf[id];
@@ -530,12 +524,8 @@ PLO_DEV void cleanup_compress(Coop<NW> &co, TileMem &m, uint32_t *X, uint8_t *id
         }
         n_out = heads.carry;
         if constexpr (NW > 1) {
-            rl_acc = wv::reduce_add(rl_acc);
             shift_acc = wv::reduce_add(shift_acc);
-            if (lane == 0) {
-                if (read_len && rl_acc) wv::atomic_add(&read_len[0], rl_acc);
-                if (shift_acc) wv::atomic_add(&m.its[0], shift_acc);
-            }
+            if (lane == 0 && shift_acc) wv::atomic_add(&m.its[0], shift_acc);
         }
         indel_pairs = co.any(pairs);
     }
@@ -790,6 +780,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
     int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;
     int shift_ref_len = 0, chrom_ref_len = 0;
+    uint32_t read_len_in = 0;
     unsigned long long seq_off = 0, shift_ref = 0, chrom_ref = 0;
     bool rev = false, do_shift = false, flip = false;
     if (has) {
@@ -812,6 +803,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         pos1 = wk.d.pos1[g];
         kv0 = (int)wk.d.kv0[g];
         seq_len = (int)wk.d.seq_len[g];
+        read_len_in = wk.d.read_len[g];
         seq_off = wk.d.seq_off[g];
         shift_ref = wk.d.shift_ref[g];
         shift_ref_len = wk.d.shift_ref_len[g];
@@ -1175,7 +1167,6 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     PLO_T(2)
     // the lifted CIGARs of the tile have an indel cluster of more than one op (known after the liftover's clean-up)
     bool lifted_pairs = true;
-    bool have_read_len = false;  // m.itc holds the read bases consumed by every item's lifted CIGAR
     // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ------------------------------------------------------------------
     if (!overflow && (stages & PLO_STAGE_LIFTOVER)) {
         // per item: the window [W0, W1) of the block map that can intersect the item was located by build_item_desc;
@@ -1191,6 +1182,11 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         // maps staged in LDS and once for maps read from global memory (a run-time select between the two pointers would
         // turn every probe into a flat load behind a branch).
         int P = 0;
+        if constexpr (NW == 1) {  // piece range [itq, itc) of every item, published by pass A (items without ops: empty)
+            m.itq[lane] = 0;
+            m.itc[lane] = 0;
+            co.sync();
+        }
         auto pass_a = [&](auto staged_c) {
             constexpr bool STAGED = decltype(staged_c)::value;
             SegSumT<NW> sr(co);
@@ -1201,6 +1197,8 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                 uint32_t c = valid ? m.A[e] : 0;
                 int id = co.elem_id(m.idA, e, valid);
                 int i_alive = co.item((int)alive, id), i_s = co.item(sA, id), i_pos = co.item(pos1, id);
+                int i_c = 0;
+                if constexpr (NW == 1) i_c = co.item(cA, id);
                 int i_w0 = co.item(W0, id), i_w1 = co.item(W1, id), i_kb = co.item(kb, id);
                 int t = op_type(c), L = op_len(c);
                 bool on = valid && i_alive;
@@ -1236,6 +1234,10 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                     m.T0[e] = s;
                     m.T1[e] = f;
                     m.T2[e] = cnt > 0 ? b : -1;
+                    if constexpr (NW == 1) {
+                        if (e == i_s) m.itq[id] = b;
+                        if (e == i_s + i_c - 1) m.itc[id] = b + cnt;
+                    }
                 }
             }
             P = pieces.carry;
@@ -1249,8 +1251,14 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                 int j = base + lane;
                 if (j < P) m.T3[j] = 0;
             }
+            int ps_t = 0, pe_t = 0;  // NW == 1: the item's pieces are [ps_t, pe_t)
+            if constexpr (NW == 1) {
+                co.sync();
+                ps_t = m.itq[lane];
+                pe_t = m.itc[lane];
+            }
             m.its[lane] = NONE32;  // ref2_start_pos = None
-            m.itc[lane] = 0;
+            if constexpr (NW > 1) m.itc[lane] = 0;
             m.itf[lane] = IMAX;    // first / last match op of the item's lifted CIGAR, published by pass B for the clean-up
             m.itl[lane] = -1;
             co.sync();
@@ -1312,6 +1320,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                     // at most two ops per piece, as flags + values (no indexed local array: that would live in scratch)
                     bool e0 = false, started = false, started_before = false;  // e0: the jump deletion of :91-96
                     uint32_t v0 = 0;
+                    int i_ps = 0, i_pe = 0, fi_last = -1;
                     if constexpr (NW > 1) {
                         // One item: "the previous mapped piece" needs no owner test, and its end (ref2_end_pos) is the running
                         // maximum of the ends -- reference positions never decrease along a block map built from a CIGAR -- so
@@ -1332,21 +1341,21 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                             }
                         }
                     } else {
-                    if (valid) {
-                        m.T3[j] = id | (mapped ? 256 : 0);
-                        m.T4[j] = endval;
-                    }
+                    // The pieces of an item are consecutive ([i_ps, i_pe), published by pass A): "the previous mapped piece /
+                    // the first mapped match piece belongs to my item" is a comparison with i_ps, no look-up of that piece.
+                    i_ps = co.item(ps_t, id);
+                    i_pe = co.item(pe_t, id);
+                    if (valid) m.T4[j] = endval;
                     co.sync();
                     int mi = lastmap.incl(mapped ? j : -1);
                     int pmap = lastmap.excl_of(mi);
-                    int fi = lastfm.incl(fm ? j : -1);
-                    int fe = lastfm.excl_of(fi);
+                    fi_last = lastfm.incl(fm ? j : -1);
+                    int fe = lastfm.excl_of(fi_last);
                     if (mapped) {
-                        bool prev_ok = pmap >= 0 && (m.T3[pmap] & 63) == id;
-                        started = fi >= 0 && (m.T3[fi] & 63) == id;  // ref2_start_pos.is_some(), after :84-88
-                        started_before = fe >= 0 && (m.T3[fe] & 63) == id;
+                        started = fi_last >= i_ps;  // ref2_start_pos.is_some(), after :84-88
+                        started_before = fe >= i_ps;
                         if (fm && !started_before) m.its[id] = startval;
-                        if (prev_ok) {  // :91-96
+                        if (pmap >= i_ps) {  // :91-96
                             int d = val - m.T4[pmap];
                             e0 = d > 0 && started;
                             v0 = mk_op(OP_D, d);
@@ -1368,13 +1377,16 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                             int pm = p + (e0 ? 1 : 0);
                             if (!started_before) m.itf[id] = pm;  // single writer, like m.its
                             if constexpr (NW > 1) last_fm = pm;  // positions grow with j
-                            else wv::atomic_max(&m.itl[id], pm);
                         }
                         put_op(m.B, m.idB, p, e0, v0, id);
                         put_op(m.B, m.idB, p, e1, v1, id);
                     }
                     if constexpr (NW == 1) {
-                        if (ne > 0) wv::atomic_add(&m.itc[id], ne);
+                        // no per-item atomics: the inclusive emission prefix of every piece stays in T3 (the owner mark of the
+                        // piece has been consumed above); item op counts and the last match op are differences / look-ups of it
+                        // after the pass.  The item's last piece leaves the index of its last mapped match piece.
+                        if (valid) m.T3[j] = ei;
+                        if (valid && j == i_pe - 1) m.itl[id] = fi_last >= i_ps ? fi_last : -1;
                     }
                 }
                 nB = emit.carry;
@@ -1392,7 +1404,16 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
             co.sync();
             PLO_T(4)
             if (!overflow) {
-                int cB = m.itc[lane];
+                int cB;
+                if constexpr (NW == 1) {
+                    cB = pe_t > ps_t ? m.T3[pe_t - 1] - (ps_t > 0 ? m.T3[ps_t - 1] : 0) : 0;
+                    const int lf = m.itl[lane];  // piece index of the item's last mapped match piece: its match op is the last op it emitted
+                    const int lpos = lf >= 0 ? m.T3[lf] - 1 : -1;
+                    co.sync();
+                    m.itl[lane] = lpos;
+                } else {
+                    cB = m.itc[lane];
+                }
                 int incB = wv::scan_add(cB);
                 int sB = incB - cB;
                 int r2s = m.its[lane];
@@ -1402,8 +1423,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                     alive = false;
                 }
                 int shift = 0, nOut = 0;
-                cleanup_compress(co, m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true, m.itc);  // :219-220
-                have_read_len = true;
+                cleanup_compress(co, m, m.B, m.idB, m.A, m.idA, nB, sB, cB, alive, shift, nOut, lifted_pairs, /*edges_known=*/true);  // :219-220
                 sA = sB;
                 cA = cB;
                 nA = nOut;
@@ -1415,31 +1435,12 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     PLO_T(5)
     // ---- LENGTH CHECK (src/read_alignment_scanner.rs:204-229) ------------------------------------------------------------------
     bool simp = alive;
-    if (!overflow && (stages & PLO_STAGE_LENCHECK) && have_read_len) {
-        // the liftover's clean-up/compress pass has summed the read bases of every item's CIGAR into m.itc
-        int rl = m.itc[lane];
-        if (alive && seq_len != rl) {
+    if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
+        // The read bases consumed by the CIGAR at this point equal those of the input CIGAR (build_item_desc explains why the
+        // shift and the liftover keep that number), which the enumerate pass has summed: no pass over the ops here.
+        if (alive && (read_len_in == 0xffffffffu || (uint32_t)seq_len != read_len_in)) {
             status = PLO_ITEM_LEN_MISMATCH;
             simp = false;
-        }
-    } else if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
-        AddScanT<NW> rs(co);
-        PLO_CHUNKS(base, nA) {
-            int e = base + lane;
-            bool valid = e < nA;
-            uint32_t c = valid ? m.A[e] : 0;
-            int r = rs.incl((valid && read_consuming(op_type(c))) ? op_len(c) : 0);
-            if (valid) m.T0[e] = r;
-        }
-        co.sync();
-        int ns, rl;
-        finish_counts(m.T0, sA, cA, ns, rl);
-        co.sync();
-        if (alive) {
-            if (seq_len != rl) {
-                status = PLO_ITEM_LEN_MISMATCH;
-                simp = false;
-            }
         }
     }
 

@@ -68,6 +68,7 @@ struct ItemDesc {
     int *shift_ref_len;    // contig length
     uint64_t *chrom_ref;   // reference[chrom_index]: ref_seq of simplify_alignment_indels
     int *chrom_ref_len;
+    uint32_t *read_len;    // read bases the input CIGAR consumes (get_cigar_read_offset(cigar, false)), saturated at 2^32 - 1
 };
 enum { ITF_REV = 1, ITF_FLIP = 2, ITF_CONTIG_FWD = 4 };
 
@@ -105,6 +106,7 @@ struct DevWork {
     uint32_t slab_pre;
     unsigned long long *wave_stats;  // [waves of the launch][4]: algorithmic bytes, input ops, output ops of every wave (summed by k_sum_stats)
     uint32_t *big_list;            // items too heavy for a shared tile: workgroup-per-item kernel (k_lift_mid)
+    const uint32_t *seg_readlen;   // [n_segs] read bases consumed by every read segment's CIGAR (k_seg_count); NULL: computed per item
     uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
 };
 

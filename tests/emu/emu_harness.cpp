@@ -93,6 +93,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     std::vector<int> d_pos1(a);
     std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
     std::vector<int> d_shift_ref_len(a), d_chrom_ref_len(a);
+    std::vector<uint32_t> d_read_len(a);
     unsigned long long counters[CNT_N];
     memset(counters, 0, sizeof(counters));
 
@@ -119,6 +120,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.d.shift_ref_len = d_shift_ref_len.data();
     wk.d.chrom_ref = d_chrom_ref.data();
     wk.d.chrom_ref_len = d_chrom_ref_len.data();
+    wk.d.read_len = d_read_len.data();
     wk.status = o->status.data();
     wk.flip = o->flip.data();
     wk.mapq = o->mapq.data();
