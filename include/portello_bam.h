@@ -71,6 +71,21 @@ void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uin
  * packed sequences.  Also returns the qualities and flags that plo_finish_batch_dev takes (optional, may be NULL). */
 plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin);
 
+/* The same with the read bases as PLO_SEQ_BAM4_SPARSE (portello_liftover.h): only the granules within `margin` bases of an
+ * insertion or deletion of a read->contig CIGAR are copied out of the records (about 3 % of a HiFi read at margin 32), and
+ * seq_full / read_seq_full_off point at the complete bases inside the window's records, where plo_liftover_batch looks when a
+ * comparison runs past what was sent.  For the path that finishes records on the host (plo_records_build); the result of
+ * plo_liftover_batch is the same as with plo_bam_window_batch whatever the margin. */
+plo_status plo_bam_window_batch_sparse(plo_bam_window *w, uint32_t margin, plo_batch_in *batch, plo_finish_in *fin);
+
+/* The same transformation for a batch that already exists with dense PLO_SEQ_BAM4 bases in host memory (seg_read non-decreasing).
+ * `out` needs plo_sparse_seq_bound(dense) bytes (page-locked memory from plo_host_alloc makes the upload faster), out_read_off
+ * n_reads entries.  *sparse = *dense with seq / seq_bytes / seq_fmt / read_seq_off replaced and seq_full / read_seq_full_off
+ * pointing at the dense bases. */
+uint64_t plo_sparse_seq_bound(const plo_batch_in *dense);
+plo_status plo_sparse_seq_pack(const plo_batch_in *dense, uint32_t margin, int n_threads, uint8_t *out, uint64_t out_cap,
+                               uint64_t *out_read_off, plo_batch_in *sparse);
+
 /* Output records of a window.  `lift` = host result of plo_liftover_batch on the window's batch (items ordered by read
  * segment, contig segment).  For every read, in order: its lifted records (item order) with flags, bin, PS/ZM/SA tags as
  * the reference writes them, or -- when nothing lifted and !is_target_region -- the unmapped copy.

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLO_API_VERSION 2
+#define PLO_API_VERSION 3
 
 typedef enum plo_status {
     PLO_OK = 0,
@@ -51,19 +51,33 @@ typedef enum plo_status {
  *   NO_LIFTOVER   liftover_read_alignment returned None           src/liftover_read_alignment.rs:218
  *   LEN_MISMATCH  read length of lifted CIGAR != seq_len; the reference aborts   src/read_alignment_scanner.rs:204-229
  *   PANIC         a sequence index would be out of bounds (Rust slice-index panic in
- *                 simplify_alignment_indels.rs:58-60,74-77 / indel_breakend_homology.rs:38-39)          */
+ *                 simplify_alignment_indels.rs:58-60,74-77 / indel_breakend_homology.rs:38-39)
+ *   NEED_BASES    no counterpart in the reference: the batch came with PLO_SEQ_BAM4_SPARSE bases, a sequence comparison
+ *                 of this item reached bases the batch does not carry, and no `seq_full` was given to look them up in.
+ *                 The item has no result; lift it again from a batch that holds the read's complete bases.       */
 enum {
     PLO_ITEM_LIFTED = 0,
     PLO_ITEM_NO_LIFTOVER = 1,
     PLO_ITEM_LEN_MISMATCH = 2,
-    PLO_ITEM_PANIC = 3
+    PLO_ITEM_PANIC = 3,
+    PLO_ITEM_NEED_BASES = 4
 };
 
 /* Read-sequence encodings accepted at the boundary */
 enum {
     PLO_SEQ_BAM4 = 0, /* BAM 4-bit packing, 2 bases per byte, high nibble first, code table "=ACMGRSVTWYHKDBN"
                          (what bam::Record::seq() holds; decoded by as_bytes() at read_alignment_scanner.rs:170,238) */
-    PLO_SEQ_ASCII = 1 /* one byte per base */
+    PLO_SEQ_ASCII = 1, /* one byte per base */
+    PLO_SEQ_BAM4_SPARSE = 2
+    /* BAM 4-bit packing, but only the bases the kernels are likely to look at travel to the device (the sequence
+       comparisons of left_shift_indels / simplify_alignment_indels touch a few dozen bases around each indel, the other
+       ~97 % of a HiFi read never leave the host).  A read's bases are cut into granules of 32 bases (16 bytes).  At
+       read_seq_off[r] (a multiple of 16): a header of ceil(seq_len / 1024) pairs {uint32 mask, uint32 rank} -- mask bit k of
+       pair b set = granule 32 b + k is present, rank = number of present granules before granule 32 b -- padded to a
+       multiple of 16 bytes, followed by the present granules in ascending order, each the 16 bytes of the dense BAM4
+       encoding (the last one zero-padded).  plo_sparse_seq_pack (portello_bam.h) writes this form from records / dense
+       bases and CIGARs.  A comparison that reaches an absent granule is detected on the device and the item is lifted
+       again from the read's complete bases (plo_batch_in::seq_full), so results never depend on which granules were sent. */
 };
 
 /* Where the sequence / batch buffers of a descriptor live */
@@ -159,6 +173,12 @@ typedef struct plo_batch_in {
     uint32_t n_items;
     const uint32_t *item_seg;
     const uint32_t *item_cseg;
+
+    /* PLO_SEQ_BAM4_SPARSE only, optional (NULL: items that reach absent bases end PLO_ITEM_NEED_BASES).  HOST memory in both
+       entry points: the dense BAM4 bases of read r start at seq_full + read_seq_full_off[r] (e.g. inside the BAM record the
+       read came from).  Read only for the reads of such items, after the first pass over the batch. */
+    const uint8_t *seq_full;
+    const uint64_t *read_seq_full_off; /* [n_reads] */
 } plo_batch_in;
 
 /* Batch output (SoA, one entry per item, ordered by (read segment, contig segment index)).
@@ -197,6 +217,8 @@ typedef struct plo_timing {
     uint32_t n_retry_items;
     float mid_ms;        /* workgroup-per-item kernel (items too heavy for a shared tile)             */
     uint32_t n_mid_items;
+    uint32_t n_miss_items; /* PLO_SEQ_BAM4_SPARSE: items that reached absent bases (lifted again from seq_full) */
+    float miss_ms;         /* that second pass: list download, host gather, upload, kernel (wall clock)         */
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

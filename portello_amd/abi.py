@@ -24,9 +24,11 @@ ITEM_LIFTED = 0
 ITEM_NO_LIFTOVER = 1
 ITEM_LEN_MISMATCH = 2
 ITEM_PANIC = 3
+ITEM_NEED_BASES = 4  # sparse bases only: a comparison reached bases the batch does not carry (and no seq_full was given)
 
 SEQ_BAM4 = 0
 SEQ_ASCII = 1
+SEQ_BAM4_SPARSE = 2
 
 MEM_HOST = 0
 MEM_DEVICE = 1
@@ -88,6 +90,8 @@ class PloBatchIn(C.Structure):
         ("n_items", C.c_uint32),
         ("item_seg", _u32p),
         ("item_cseg", _u32p),
+        ("seq_full", _u8p),
+        ("read_seq_full_off", _u64p),
     ]
 
 
@@ -125,6 +129,8 @@ class PloTiming(C.Structure):
         ("n_retry_items", C.c_uint32),
         ("mid_ms", C.c_float),
         ("n_mid_items", C.c_uint32),
+        ("n_miss_items", C.c_uint32),
+        ("miss_ms", C.c_float),
     ]
 
 
@@ -265,6 +271,9 @@ class BatchData:
     cigar: np.ndarray
     item_seg: Optional[np.ndarray] = None
     item_cseg: Optional[np.ndarray] = None
+    # seq_fmt SEQ_BAM4_SPARSE: the reads' complete BAM4 bases (host), looked up when a comparison runs past the granules sent
+    seq_full: Optional[np.ndarray] = None
+    read_seq_full_off: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.read_is_reverse = _np(self.read_is_reverse, np.uint8)
@@ -280,6 +289,9 @@ class BatchData:
         if self.item_seg is not None:
             self.item_seg = _np(self.item_seg, np.uint32)
             self.item_cseg = _np(self.item_cseg, np.uint32)
+        if self.seq_full is not None:
+            self.seq_full = _np(self.seq_full, np.uint8)
+            self.read_seq_full_off = _np(self.read_seq_full_off, np.uint64)
 
     @property
     def n_reads(self) -> int:
@@ -313,6 +325,8 @@ class BatchData:
             b.n_items = 0
             b.item_seg = _ptr(None, C.c_uint32)
             b.item_cseg = _ptr(None, C.c_uint32)
+        b.seq_full = _ptr(self.seq_full, C.c_uint8)
+        b.read_seq_full_off = _ptr(self.read_seq_full_off, C.c_uint64)
         return b
 
 

@@ -48,6 +48,12 @@ def lib():
         L.plo_bam_window_unmapped.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.plo_bam_window_batch.restype = C.c_int
         L.plo_bam_window_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
+        L.plo_bam_window_batch_sparse.restype = C.c_int
+        L.plo_bam_window_batch_sparse.argtypes = [vp, C.c_uint32, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
+        L.plo_sparse_seq_bound.restype = C.c_uint64
+        L.plo_sparse_seq_bound.argtypes = [C.POINTER(abi.PloBatchIn)]
+        L.plo_sparse_seq_pack.restype = C.c_int
+        L.plo_sparse_seq_pack.argtypes = [C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, vp, C.c_uint64, vp, C.POINTER(abi.PloBatchIn)]
         L.plo_records_build.restype = C.c_int
         L.plo_records_build.argtypes = [vp, C.POINTER(abi.PloBatchOut), C.POINTER(PloRecordsParams), C.POINTER(PloRecordBuf)]
         L.plo_bam_output_header.restype = vp
@@ -77,6 +83,22 @@ def _names(names: Sequence[str]):
     return arr
 
 
+def sparse_pack(batch: abi.BatchData, margin: int = 32, n_threads: int = 4) -> abi.BatchData:
+    """plo_sparse_seq_pack: the batch with its read bases as PLO_SEQ_BAM4_SPARSE (granules within `margin` bases of an indel of a
+    read->contig CIGAR); seq_full / read_seq_full_off of the result point at the dense bases of `batch`, which must stay alive."""
+    import dataclasses
+
+    d = batch.to_desc()
+    cap = int(lib().plo_sparse_seq_bound(C.byref(d)))
+    out = np.zeros(cap, np.uint8)
+    off = np.zeros(max(1, batch.n_reads), np.uint64)
+    sp = abi.PloBatchIn()
+    _check(lib().plo_sparse_seq_pack(C.byref(d), int(margin), int(n_threads), out.ctypes.data_as(C.c_void_p), cap, off.ctypes.data_as(C.c_void_p),
+                                     C.byref(sp)), "plo_sparse_seq_pack")
+    return dataclasses.replace(batch, seq=out[:int(sp.seq_bytes)], seq_fmt=abi.SEQ_BAM4_SPARSE, read_seq_off=off[:batch.n_reads],
+                               seq_full=batch.seq, read_seq_full_off=batch.read_seq_off)
+
+
 class Window:
     """a decoded window of primary records (plo_bam_window)"""
 
@@ -93,11 +115,17 @@ class Window:
         lib().plo_bam_window_unmapped(self.handle, C.byref(p), C.byref(n), C.byref(k))
         return (C.string_at(p, n.value) if n.value else b""), int(k.value)
 
-    def batch_desc(self, with_finish: bool = False):
-        """plo_batch_in (host arrays owned by the window) [+ plo_finish_in]"""
+    def batch_desc(self, with_finish: bool = False, sparse_margin: Optional[int] = None):
+        """plo_batch_in (host arrays owned by the window) [+ plo_finish_in].  sparse_margin: read bases as PLO_SEQ_BAM4_SPARSE --
+        only the granules within that many bases of an indel of a read->contig CIGAR, the complete bases stay in the records
+        (plo_bam_window_batch_sparse)"""
         b = abi.PloBatchIn()
         f = abi.PloFinishIn()
-        _check(lib().plo_bam_window_batch(self.handle, C.byref(b), C.byref(f) if with_finish else None), "plo_bam_window_batch")
+        if sparse_margin is not None:
+            _check(lib().plo_bam_window_batch_sparse(self.handle, int(sparse_margin), C.byref(b), C.byref(f) if with_finish else None),
+                   "plo_bam_window_batch_sparse")
+        else:
+            _check(lib().plo_bam_window_batch(self.handle, C.byref(b), C.byref(f) if with_finish else None), "plo_bam_window_batch")
         self._batch = b
         return (b, f) if with_finish else b
 

@@ -30,7 +30,7 @@ struct plo_bam_window {
     std::vector<uint8_t> unmapped;
     uint32_t n_unmapped = 0;
     // batch (plo_batch_in) arrays
-    HostBuf b_rev, b_len, b_soff, b_seq, b_seg_read, b_seg_contig, b_seg_pos, b_seg_fwd, b_coff, b_cigar, b_flags, b_qual, b_qoff;
+    HostBuf b_rev, b_len, b_soff, b_seq, b_seg_read, b_seg_contig, b_seg_pos, b_seg_fwd, b_coff, b_cigar, b_flags, b_qual, b_qoff, b_full_off;
     std::vector<uint32_t> read_seg_off;  // [n + 1] first segment of every read
     // output records
     RawBuf out;
@@ -165,9 +165,145 @@ void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uin
 
 }  // extern "C"
 
-extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin) {
+// ---------------------------------------------------------------------------------------------------------------------
+// PLO_SEQ_BAM4_SPARSE: only the bases around the indels of the read->contig CIGARs travel to the device
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+inline uint32_t sparse_hdr_bytes(uint32_t len) { return ((((len + 1023u) >> 10) * 8u) + 15u) & ~15u; }
+inline uint32_t sparse_words(uint32_t len) { return (len + 1023u) >> 10; }
+
+// Granule mask of one read: every I / D op of every segment's CIGAR marks its read interval, widened by `margin` bases on both
+// sides, in the coordinates of the stored sequence (a segment on the other strand than the record counts from the far end:
+// `changes`, src/read_alignment_scanner.rs:153-157).  These are the places the homology probes of left_shift_indels and the
+// cluster trimming of simplify_alignment_indels start from; probes that run further are caught on the device.
+void sparse_mark(uint32_t len, bool read_rev, uint32_t s0, uint32_t s1, const uint8_t *seg_fwd, const uint32_t *coff, const uint32_t *cigar,
+                 uint32_t margin, uint32_t *mask) {
+    const uint32_t nw = sparse_words(len);
+    for (uint32_t k = 0; k < nw; ++k) mask[k] = 0;
+    if (!len) return;
+    for (uint32_t s = s0; s < s1; ++s) {
+        const bool changes = read_rev == (seg_fwd[s] != 0);
+        int64_t q = 0;
+        for (uint32_t o = coff[s]; o < coff[s + 1]; ++o) {
+            const uint32_t t = cigar[o] & 15u, L = cigar[o] >> 4;
+            if (t == 1 || t == 2) {
+                int64_t a = q, b = q + (t == 1 ? (int64_t)L : 0);
+                if (changes) {
+                    const int64_t a2 = (int64_t)len - b;
+                    b = (int64_t)len - a;
+                    a = a2;
+                }
+                a = std::max<int64_t>(0, a - (int64_t)margin);
+                b = std::min<int64_t>((int64_t)len, b + (int64_t)margin);
+                if (b > a)
+                    for (int64_t g = a >> 5; g <= (b - 1) >> 5; ++g) mask[g >> 5] |= 1u << (g & 31);
+            }
+            if ((0x1B3u >> t) & 1u) q += L;
+        }
+    }
+}
+uint32_t sparse_granules(uint32_t len, const uint32_t *mask) {
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < sparse_words(len); ++k) n += (uint32_t)__builtin_popcount(mask[k]);
+    return n;
+}
+// header + present granules of one read at dst (sparse_hdr_bytes(len) + 16 * granules bytes)
+void sparse_write(uint32_t len, const uint8_t *dense, const uint32_t *mask, uint8_t *dst) {
+    const uint32_t nw = sparse_words(len), hb = sparse_hdr_bytes(len);
+    const size_t nbytes = ((size_t)len + 1) / 2;
+    uint32_t *hdr = (uint32_t *)dst;
+    uint8_t *out = dst + hb;
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k < hb / 4; ++k) hdr[k] = 0;
+    for (uint32_t k = 0; k < nw; ++k) {
+        hdr[2 * k] = mask[k];
+        hdr[2 * k + 1] = rank;
+        for (uint32_t m = mask[k]; m; m &= m - 1) {
+            const size_t g = (size_t)k * 32 + (size_t)__builtin_ctz(m), at = g * 16;
+            const size_t nb = at < nbytes ? std::min<size_t>(16, nbytes - at) : 0;
+            memcpy(out + (size_t)rank * 16, dense + at, nb);
+            if (nb < 16) memset(out + (size_t)rank * 16 + nb, 0, 16 - nb);
+            ++rank;
+        }
+    }
+}
+
+// the reads' segment ranges (segments grouped by read, as get_seq_order_read_split_segments yields them)
+bool read_seg_ranges(uint32_t n_reads, uint32_t n_segs, const uint32_t *seg_read, std::vector<uint32_t> &first) {
+    first.assign((size_t)n_reads + 1, 0);
+    for (uint32_t s = 0; s < n_segs; ++s) {
+        if (seg_read[s] >= n_reads || (s && seg_read[s] < seg_read[s - 1])) return false;
+        ++first[seg_read[s] + 1];
+    }
+    for (uint32_t i = 0; i < n_reads; ++i) first[i + 1] += first[i];
+    return true;
+}
+
+constexpr uint64_t SPARSE_SLACK = 32;  // zero bytes behind the last granule: the wide window loads of the probes end inside the buffer
+
+}  // namespace
+
+extern "C" uint64_t plo_sparse_seq_bound(const plo_batch_in *dense) {
+    if (!dense) return 0;
+    uint64_t b = SPARSE_SLACK;
+    for (uint32_t i = 0; i < dense->n_reads; ++i) {
+        const uint32_t len = dense->read_seq_len[i];
+        b += sparse_hdr_bytes(len) + 16ull * (((uint64_t)len + 31) >> 5);
+    }
+    return b;
+}
+
+extern "C" plo_status plo_sparse_seq_pack(const plo_batch_in *dense, uint32_t margin, int n_threads, uint8_t *out, uint64_t out_cap,
+                                          uint64_t *out_read_off, plo_batch_in *sparse) {
+    if (!dense || !out || !out_read_off || !sparse) return PLO_ERR_INVALID_ARG;
+    if (dense->seq_fmt != PLO_SEQ_BAM4) return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: the batch must carry dense BAM 4-bit bases");
+    const uint32_t n = dense->n_reads;
+    std::vector<uint32_t> first;
+    if (!read_seg_ranges(n, dense->n_segs, dense->seg_read, first))
+        return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: seg_read must be non-decreasing and below n_reads");
+    std::vector<uint64_t> woff((size_t)n + 1, 0), boff((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) woff[i + 1] = woff[i] + sparse_words(dense->read_seq_len[i]);
+    std::vector<uint32_t> masks(woff[n] + 1);
+    const int th = std::max(1, n_threads);
+    parallel_ranges(n, th, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t len = dense->read_seq_len[i];
+            sparse_mark(len, dense->read_is_reverse[i] != 0, first[i], first[i + 1], dense->seg_is_fwd_strand, dense->seg_cigar_off, dense->cigar,
+                        margin, masks.data() + woff[i]);
+            boff[i + 1] = sparse_hdr_bytes(len) + 16ull * sparse_granules(len, masks.data() + woff[i]);
+        }
+    });
+    for (uint32_t i = 0; i < n; ++i) boff[i + 1] += boff[i];
+    const uint64_t total = boff[n] + SPARSE_SLACK;
+    if (total > out_cap) return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: output buffer smaller than plo_sparse_seq_bound");
+    parallel_ranges(n, th, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            out_read_off[i] = boff[i];
+            sparse_write(dense->read_seq_len[i], dense->seq + dense->read_seq_off[i], masks.data() + woff[i], out + boff[i]);
+        }
+    });
+    memset(out + boff[n], 0, SPARSE_SLACK);
+    *sparse = *dense;
+    sparse->seq = out;
+    sparse->seq_bytes = total;
+    sparse->seq_fmt = PLO_SEQ_BAM4_SPARSE;
+    sparse->read_seq_off = out_read_off;
+    sparse->seq_full = dense->seq;
+    sparse->read_seq_full_off = dense->read_seq_off;
+    return PLO_OK;
+}
+
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin);
+extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin) { return window_batch(w, batch, fin, -1); }
+extern "C" plo_status plo_bam_window_batch_sparse(plo_bam_window *w, uint32_t margin, plo_batch_in *batch, plo_finish_in *fin) {
+    return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20));
+}
+
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin) {
     if (!w || !batch) return PLO_ERR_INVALID_ARG;
     memset(batch, 0, sizeof(*batch));
+    const bool sparse = sparse_margin >= 0;
     const uint32_t n = w->n_records();
     // pass 1 (parallel): segments of every read; sizes
     std::vector<std::vector<SaSeg>> segs(n);
@@ -210,7 +346,8 @@ extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batc
     uint8_t *rev = (uint8_t *)w->b_rev.ensure(std::max<size_t>(n, 1));
     uint32_t *rlen = (uint32_t *)w->b_len.ensure(std::max<size_t>(n, 1) * 4);
     uint64_t *soff = (uint64_t *)w->b_soff.ensure(std::max<size_t>(n, 1) * 8);
-    uint8_t *seq = (uint8_t *)w->b_seq.ensure(std::max<uint64_t>(n_seqb[n], 16));
+    uint8_t *seq = sparse ? nullptr : (uint8_t *)w->b_seq.ensure(std::max<uint64_t>(n_seqb[n], 16));
+    uint64_t *full_off = sparse ? (uint64_t *)w->b_full_off.ensure(std::max<size_t>(n, 1) * 8) : soff;
     uint32_t *seg_read = (uint32_t *)w->b_seg_read.ensure(std::max<size_t>(ns, 1) * 4);
     uint32_t *seg_contig = (uint32_t *)w->b_seg_contig.ensure(std::max<size_t>(ns, 1) * 4);
     int64_t *seg_pos = (int64_t *)w->b_seg_pos.ensure(std::max<size_t>(ns, 1) * 8);
@@ -220,16 +357,20 @@ extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batc
     uint16_t *flags = (uint16_t *)w->b_flags.ensure(std::max<size_t>(n, 1) * 2);
     uint8_t *qual = fin ? (uint8_t *)w->b_qual.ensure(std::max<uint64_t>(n_qual[n], 16)) : nullptr;
     uint64_t *qoff = fin ? (uint64_t *)w->b_qoff.ensure(std::max<size_t>(n, 1) * 8) : nullptr;
-    if (!rev || !rlen || !soff || !seq || !seg_read || !seg_contig || !seg_pos || !seg_fwd || !coff || !cigar || !flags || (fin && (!qual || !qoff)))
+    if (!rev || !rlen || !soff || !full_off || (!sparse && !seq) || !seg_read || !seg_contig || !seg_pos || !seg_fwd || !coff || !cigar || !flags || (fin && (!qual || !qoff)))
         return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the window's batch");
     // pass 2 (parallel): fill
     parallel_for(n, w->threads, [&](size_t i) {
         Rec rec = w->record((uint32_t)i);
         rev[i] = (rec.flag() & 0x10) ? 1 : 0;
         rlen[i] = rec.l_seq();
-        soff[i] = n_seqb[i];
         flags[i] = rec.flag();
-        memcpy(seq + n_seqb[i], rec.seq(), (size_t)(n_seqb[i + 1] - n_seqb[i]));
+        if (sparse) {  // the complete bases stay where they are, inside the window's copy of the records
+            full_off[i] = (uint64_t)(rec.seq() - w->raw.data());
+        } else {
+            soff[i] = n_seqb[i];
+            memcpy(seq + n_seqb[i], rec.seq(), (size_t)(n_seqb[i + 1] - n_seqb[i]));
+        }
         if (fin) {
             qoff[i] = n_qual[i];
             memcpy(qual + n_qual[i], rec.qual(), rec.l_seq());
@@ -249,13 +390,39 @@ extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batc
         }
     });
     coff[ns] = (uint32_t)n_ops[n];
+    uint64_t seq_bytes = n_seqb[n];
+    if (sparse) {
+        // pass 3 (parallel): granule masks from the CIGARs just written, then headers + granules straight from the records
+        std::vector<uint64_t> woff((size_t)n + 1, 0), boff((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) woff[i + 1] = woff[i] + sparse_words(rlen[i]);
+        std::vector<uint32_t> masks(woff[n] + 1);
+        parallel_ranges(n, w->threads, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                sparse_mark(rlen[i], rev[i] != 0, n_seg[i], n_seg[i + 1], seg_fwd, coff, cigar, (uint32_t)sparse_margin, masks.data() + woff[i]);
+                boff[i + 1] = sparse_hdr_bytes(rlen[i]) + 16ull * sparse_granules(rlen[i], masks.data() + woff[i]);
+            }
+        });
+        for (uint32_t i = 0; i < n; ++i) boff[i + 1] += boff[i];
+        seq_bytes = boff[n] + SPARSE_SLACK;
+        seq = (uint8_t *)w->b_seq.ensure(seq_bytes);
+        if (!seq) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the window's batch");
+        parallel_ranges(n, w->threads, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                soff[i] = boff[i];
+                sparse_write(rlen[i], w->raw.data() + full_off[i], masks.data() + woff[i], seq + boff[i]);
+            }
+        });
+        memset(seq + boff[n], 0, SPARSE_SLACK);
+        batch->seq_full = w->raw.data();
+        batch->read_seq_full_off = full_off;
+    }
     batch->n_reads = n;
     batch->read_is_reverse = rev;
     batch->read_seq_len = rlen;
     batch->read_seq_off = soff;
     batch->seq = seq;
-    batch->seq_bytes = n_seqb[n];
-    batch->seq_fmt = PLO_SEQ_BAM4;
+    batch->seq_bytes = seq_bytes;
+    batch->seq_fmt = sparse ? PLO_SEQ_BAM4_SPARSE : PLO_SEQ_BAM4;
     batch->n_segs = ns;
     batch->seg_read = seg_read;
     batch->seg_contig = seg_contig;

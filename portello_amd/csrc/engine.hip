@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -80,9 +81,13 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
                 bad |= VERR_INDEX;
             } else {
                 const unsigned long long len = bt.read_seq_len[rd];
-                const unsigned long long need = bt.seq_fmt == PLO_SEQ_BAM4 ? (len + 1) / 2 : len;
+                // (sparse bases: the header must lie inside the buffer; where it points is checked by every probe)
+                const unsigned long long need = bt.seq_fmt == PLO_SEQ_BAM4          ? (len + 1) / 2
+                                                : bt.seq_fmt == PLO_SEQ_BAM4_SPARSE ? (unsigned long long)sparse_header_bytes((uint32_t)len)
+                                                                                    : len;
                 const unsigned long long off = bt.read_seq_off[rd];
                 if (off > bt.seq_bytes || need > bt.seq_bytes - off) bad |= VERR_INDEX;
+                if (bt.seq_fmt == PLO_SEQ_BAM4_SPARSE && (off & 15ull)) bad |= VERR_INDEX;
             }
         }
     }
@@ -312,9 +317,10 @@ constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its o
 #define PLO_TILE_WPE 3
 #endif
 #define PLO_TILE_OCC __attribute__((amdgpu_waves_per_eu(PLO_TILE_WPE, PLO_TILE_WPE)))
-__global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
-                                                               uint32_t n_tiles, int window, int big_thresh, int cap,
-                                                               uint32_t lds_per_wave) {
+// (every lift kernel exists twice: for dense read bases and, `_sp`, for PLO_SEQ_BAM4_SPARSE batches, whose probes look granules up)
+template <bool SP>
+PLO_DEV void lift_tiles_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n_tiles, int window,
+                               int big_thresh, int cap, uint32_t lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order); consecutive wave ids -- hence
@@ -332,34 +338,51 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(Dev
         ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lift_tiles_persistent(ix, bt, wk, stages, wave, n_waves, n_tiles, big_thresh, m, ctx);
+    lift_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n_tiles, big_thresh, m, ctx);
     wave_ctx_flush(wk, ctx, wave);
+}
+__global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+                                                               uint32_t n_tiles, int window, int big_thresh, int cap,
+                                                               uint32_t lds_per_wave) {
+    lift_tiles_kernel<false>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
+}
+__global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+                                                                  uint32_t n_tiles, int window, int big_thresh, int cap,
+                                                                  uint32_t lds_per_wave) {
+    lift_tiles_kernel<true>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
 // items per wave with a larger LDS slice (retry_cap)
 constexpr uint32_t RETRY_PER = 1;
-__global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_retry,
-                                                   int big_thresh, int cap) {
+template <bool SP>
+PLO_DEV void lift_retry_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n_retry, int big_thresh, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileMem m = carve_tile_mem(smem, cap);
     WaveCtx ctx;
     Coop<1> co;
     for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
         uint32_t left = n_retry - r;
-        lift_tile(co, ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+        lift_tile<1, SP>(co, ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_lift_retry(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_retry,
+                                                   int big_thresh, int cap) {
+    lift_retry_kernel<false>(ix, bt, wk, stages, n_retry, big_thresh, cap);
+}
+__global__ __launch_bounds__(64) void k_lift_retry_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_retry,
+                                                      int big_thresh, int cap) {
+    lift_retry_kernel<true>(ix, bt, wk, stages, n_retry, big_thresh, cap);
 }
 
 // One workgroup of NW waves per item (Coop<NW>): the item's op stream, temporaries and block-map window live in the
 // workgroup's LDS (cap elements), every pass walks it NW x 64 elements at a time.  Persistent workgroups over `list`.
 constexpr int MID_CAPK = 512;  // staged block-map entries of the one item (4 KB); longer windows are read from global memory
 // 128 VGPRs at most: 16 waves per CU, as one workgroup of 16 or two of 8
-template <int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lift_mid(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_list,
-                                                      int mid_thresh, int cap) {
+template <int NW, bool SP>
+PLO_DEV void lift_mid_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n_list, int mid_thresh, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileMem m = carve_tile_mem(smem, cap, MID_CAPK);
     Coop<NW> co;
@@ -369,27 +392,62 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __syncthreads();
     WaveCtx ctx;
     for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
-        lift_tile(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
+        lift_tile<NW, SP>(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
         co.sync();
     }
     wave_ctx_flush(wk, ctx, blockIdx.x * NW + (uint32_t)co.w);
+}
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lift_mid(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_list,
+                                                      int mid_thresh, int cap) {
+    lift_mid_kernel<NW, false>(ix, bt, wk, stages, n_list, mid_thresh, cap);
+}
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lift_mid_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_list,
+                                                         int mid_thresh, int cap) {
+    lift_mid_kernel<NW, true>(ix, bt, wk, stages, n_list, mid_thresh, cap);
 }
 template <int NW>
 static size_t mid_lds_bytes(int cap) {
     return ((tile_mem_bytes(cap, MID_CAPK) + 15) & ~(size_t)15) + (size_t)Coop<NW>::XCH_INTS * 4;
 }
 
-__global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
-                                                 const uint32_t *list, unsigned char *scratch, int big_cap,
-                                                 unsigned long long bytes_per_wave) {
+template <bool SP>
+PLO_DEV void lift_big_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n_big, const uint32_t *list,
+                             unsigned char *scratch, int big_cap, unsigned long long bytes_per_wave) {
     TileMem m = carve_tile_mem(scratch + (unsigned long long)blockIdx.x * bytes_per_wave, big_cap);
     WaveCtx ctx;
     Coop<1> co;
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        lift_tile(co, ix, bt, wk, stages, i, 1, m, list, LEVEL_LAST, 0, ctx);
+        lift_tile<1, SP>(co, ix, bt, wk, stages, i, 1, m, list, LEVEL_LAST, 0, ctx);
         wv::sync();
     }
     wave_ctx_flush(wk, ctx, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_lift_big(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
+                                                 const uint32_t *list, unsigned char *scratch, int big_cap,
+                                                 unsigned long long bytes_per_wave) {
+    lift_big_kernel<false>(ix, bt, wk, stages, n_big, list, scratch, big_cap, bytes_per_wave);
+}
+__global__ __launch_bounds__(64) void k_lift_big_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n_big,
+                                                    const uint32_t *list, unsigned char *scratch, int big_cap,
+                                                    unsigned long long bytes_per_wave) {
+    lift_big_kernel<true>(ix, bt, wk, stages, n_big, list, scratch, big_cap, bytes_per_wave);
+}
+
+// Sparse bases (PLO_SEQ_BAM4_SPARSE): the items whose probes reached absent granules are lifted again from the complete bases of
+// their reads, which the host gathers from plo_batch_in::seq_full.  k_miss_info tells it which reads; k_miss_patch points the
+// items' sequence offsets (a copy of the descriptor column) into the side buffer with those bases.
+__global__ void k_miss_info(const uint32_t *list, uint32_t n, DevBatch bt, DevWork wk, uint32_t *out_read, uint32_t *out_len) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t rd = bt.seg_read[wk.item_seg[list[k]]];
+    out_read[k] = rd;
+    out_len[k] = bt.read_seq_len[rd];
+}
+__global__ void k_miss_patch(const uint32_t *list, uint32_t n, const uint64_t *vals, uint64_t *seq_off) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) seq_off[list[k]] = vals[k];
 }
 
 // sums (and clears) the per-wave statistic slots of the lift kernel that has just run into the batch counters; one block
@@ -610,7 +668,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr;
+    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
@@ -618,7 +676,7 @@ struct plo_ctx {
     // host staging for plo_liftover_batch
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
-    HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters;
+    HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters, h_miss, h_side;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_big = false, ev_mid = false;
     uint64_t dense_total = 0;
@@ -846,6 +904,10 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
         if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     }
     (void)hipFuncSetAttribute((const void *)k_lift_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_tiles_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_retry_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_mid_sp<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_mid_sp<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (getenv("PLO_DEBUG")) {
         for (int cap : {256, 320, 384, 512}) {
             int nb = -1;
@@ -882,10 +944,10 @@ void plo_ctx_destroy(plo_ctx *c) {
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
-                      &c->i_item_seg, &c->i_item_cseg};
+                      &c->i_item_seg, &c->i_item_cseg, &c->miss_list, &c->miss_info, &c->miss_vals, &c->miss_seq_off, &c->miss_side};
     for (DevBuf *b : bufs) b->release();
     HostBuf *hb[] = {&c->h_item_seg, &c->h_item_cseg, &c->h_status, &c->h_flip, &c->h_mapq, &c->h_chrom, &c->h_pos,
-                     &c->h_coff, &c->h_clen, &c->h_cigar, &c->h_counters};
+                     &c->h_coff, &c->h_clen, &c->h_cigar, &c->h_counters, &c->h_miss, &c->h_side};
     for (HostBuf *b : hb) b->release();
     for (int i = 0; i < 7; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -937,7 +999,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         c->err = "plo_batch_in: NULL segment array";
         return PLO_ERR_INVALID_ARG;
     }
-    if (in->seq_fmt != PLO_SEQ_BAM4 && in->seq_fmt != PLO_SEQ_ASCII) {
+    if (in->seq_fmt != PLO_SEQ_BAM4 && in->seq_fmt != PLO_SEQ_ASCII && in->seq_fmt != PLO_SEQ_BAM4_SPARSE) {
         c->err = "plo_batch_in: unknown seq_fmt";
         return PLO_ERR_INVALID_ARG;
     }
@@ -1033,6 +1095,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->o_coff.ensure(ni * 8));
     HIP_TRY(c, c->o_clen.ensure(ni * 4));
     HIP_TRY(c, c->big_list.ensure(ni * 4));
+    if (in->seq_fmt == PLO_SEQ_BAM4_SPARSE) HIP_TRY(c, c->miss_list.ensure(ni * 4));
     HIP_TRY(c, c->counters.ensure(CNT_N * 8));
     DevWork wk;
     memset(&wk, 0, sizeof(wk));
@@ -1082,6 +1145,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), (uint32_t)(n_waves_), \
                        c->counters.as<unsigned long long>())
     wk.big_list = c->big_list.as<uint32_t>();
+    wk.miss_list = c->miss_list.as<uint32_t>();
     if (n_items) {
         if (in->item_seg)
             hipLaunchKernelGGL(k_item_desc, dim3((n_items + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages, in->item_seg,
@@ -1187,7 +1251,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
-    uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0;
+    uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0, n_miss = 0;
+    const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;
+    float miss_ms = 0.f;
     for (int attempt = 0;; ++attempt) {
         wk.out_cigar = c->o_cigar.as<uint32_t>();
         wk.out_cap = c->o_cigar.cap / 4;
@@ -1201,15 +1267,19 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nblk = (n_tiles + tw - 1) / tw;
             // persistent grid: what the chip keeps resident (CUs x blocks per CU), a multiple of 8 for the XCD mapping
             int occ = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_tiles, (int)tw * 64,
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_tiles_sp : (const void *)k_lift_tiles, (int)tw * 64,
                                                              (size_t)lds_per_wave * tw) != hipSuccess || occ < 1)
                 occ = 1;
             nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
             nblk = (nblk + 7u) & ~7u;
             wk.slab_pre = n_small == 0 ? 1u : 0u;  // nothing has been reserved yet (the lane kernel did not run)
             wk.slab_offset = wk.slab_pre ? (unsigned long long)nblk * tw * SLAB_OPS : 0ull;
-            hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages,
-                               n_tiles, c->window, c->big_thresh, c->cap, lds_per_wave);
+            if (sp)
+                hipLaunchKernelGGL(k_lift_tiles_sp, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
+                                   c->big_thresh, c->cap, lds_per_wave);
+            else
+                hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
+                                   c->big_thresh, c->cap, lds_per_wave);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
             PLO_SUM_STATS(nblk * tw);
@@ -1224,7 +1294,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             const int retry_cap = std::min(4096, std::max(c->cap, (2 * c->big_thresh + 64 + 63) & ~63));
             uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15);
             uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 6u);
-            hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
+            if (sp) hipLaunchKernelGGL(k_lift_retry_sp, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
+            else hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
             PLO_SUM_STATS(nw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
@@ -1244,7 +1315,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             const int mid_thresh = (cap - 64) * 4 / 5;
             const int nw = c->mid_waves;
             const size_t lds = nw == 16 ? mid_lds_bytes<16>(cap) : mid_lds_bytes<8>(cap);
-            const void *fn = nw == 16 ? (const void *)k_lift_mid<16> : (const void *)k_lift_mid<8>;
+            const void *fn = sp ? (nw == 16 ? (const void *)k_lift_mid_sp<16> : (const void *)k_lift_mid_sp<8>)
+                                : (nw == 16 ? (const void *)k_lift_mid<16> : (const void *)k_lift_mid<8>);
             int occ = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nw * 64, lds) != hipSuccess || occ < 1) occ = 1;
             uint32_t nblk = std::min<uint32_t>(n_big, (uint32_t)(c->n_cus * occ));
@@ -1253,7 +1325,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             if (getenv("PLO_DEBUG_GEOMETRY"))
                 fprintf(stderr, "[plo] workgroup-per-item kernel: %u items, %d waves, cap %d (threshold %d), %zu B LDS, %d workgroups per CU\n", n_big, nw,
                         cap, mid_thresh, lds, occ);
-            if (nw == 16)
+            if (sp && nw == 16)
+                hipLaunchKernelGGL(k_lift_mid_sp<16>, dim3(nblk), dim3(16 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
+            else if (sp)
+                hipLaunchKernelGGL(k_lift_mid_sp<8>, dim3(nblk), dim3(8 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
+            else if (nw == 16)
                 hipLaunchKernelGGL(k_lift_mid<16>, dim3(nblk), dim3(16 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
             else
                 hipLaunchKernelGGL(k_lift_mid<8>, dim3(nblk), dim3(8 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
@@ -1278,14 +1354,81 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nw = std::min<uint32_t>(n_huge, (uint32_t)c->n_cus * 12u);
             nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
             HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
-            hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_huge, huge_src, c->scratch.as<unsigned char>(),
-                               big_cap, bpw);
+            if (sp)
+                hipLaunchKernelGGL(k_lift_big_sp, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_huge, huge_src, c->scratch.as<unsigned char>(),
+                                   big_cap, bpw);
+            else
+                hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_huge, huge_src, c->scratch.as<unsigned char>(),
+                                   big_cap, bpw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[3], st));
             PLO_SUM_STATS(nw);
             c->ev_big = true;
             HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        n_miss = (uint32_t)hc[CNT_NMISS];
+        if (n_miss && in->seq_full && in->read_seq_full_off) {
+            // second look at the items that reached bases a sparse batch does not carry: their reads' complete bases go up now
+            const auto t0 = std::chrono::steady_clock::now();
+            HIP_TRY(c, c->miss_info.ensure((size_t)n_miss * 8));
+            HIP_TRY(c, c->h_miss.ensure((size_t)n_miss * 16));
+            uint32_t *d_read = c->miss_info.as<uint32_t>(), *d_len = d_read + n_miss;
+            hipLaunchKernelGGL(k_miss_info, dim3((n_miss + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->miss_list.as<uint32_t>(), n_miss,
+                               bt, wk, d_read, d_len);
+            uint32_t *h_read = c->h_miss.as<uint32_t>(), *h_len = h_read + n_miss;
+            HIP_TRY(c, hipMemcpyAsync(h_read, d_read, (size_t)n_miss * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            std::vector<uint32_t> order(n_miss);
+            for (uint32_t k = 0; k < n_miss; ++k) order[k] = k;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_read[a] < h_read[b]; });
+            uint64_t *h_vals = (uint64_t *)(h_read + 2 * (size_t)n_miss);
+            uint64_t total = 0;
+            for (uint32_t k = 0; k < n_miss; ++k) {  // one copy per read, 16-byte aligned, 16 spare bytes for the wide window loads
+                const uint32_t a = order[k];
+                if (k && h_read[order[k - 1]] == h_read[a]) {
+                    h_vals[a] = h_vals[order[k - 1]];
+                    continue;
+                }
+                h_vals[a] = total;
+                total += ((((uint64_t)h_len[a] + 1) / 2 + 15) & ~15ull) + 16;
+            }
+            HIP_TRY(c, c->h_side.ensure((size_t)total));
+            HIP_TRY(c, c->miss_side.ensure((size_t)total));
+            HIP_TRY(c, c->miss_vals.ensure((size_t)n_miss * 8));
+            HIP_TRY(c, c->miss_seq_off.ensure((size_t)std::max(1u, n_items) * 8));
+            for (uint32_t k = 0; k < n_miss; ++k) {
+                const uint32_t a = order[k];
+                if (k && h_read[order[k - 1]] == h_read[a]) continue;
+                const size_t nb = ((size_t)h_len[a] + 1) / 2;
+                uint8_t *dst = c->h_side.as<uint8_t>() + h_vals[a];
+                memcpy(dst, in->seq_full + in->read_seq_full_off[h_read[a]], nb);
+                memset(dst + nb, 0, (((nb + 15) & ~(size_t)15) + 16) - nb);
+            }
+            HIP_TRY(c, hipMemcpyAsync(c->miss_side.p, c->h_side.p, (size_t)total, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(c->miss_vals.p, h_vals, (size_t)n_miss * 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_miss_patch, dim3((n_miss + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->miss_list.as<uint32_t>(), n_miss,
+                               (const uint64_t *)c->miss_vals.as<uint64_t>(), c->miss_seq_off.as<uint64_t>());
+            DevBatch bt2 = bt;
+            bt2.seq = c->miss_side.as<uint8_t>();
+            bt2.seq_bytes = total;
+            bt2.seq_fmt = PLO_SEQ_BAM4;
+            DevWork wk2 = wk;
+            wk2.d.seq_off = c->miss_seq_off.as<uint64_t>();
+            int big_cap = 4096;
+            while (big_cap < (1 << 22) && (unsigned long long)big_cap < 6ull * max_nin + 2048ull) big_cap <<= 1;
+            if (const char *e = getenv("PLO_BIG_CAP")) big_cap = std::max(1024, atoi(e));
+            unsigned long long bpw = (tile_mem_bytes(big_cap) + 255) & ~(unsigned long long)255;
+            uint32_t nw = std::min<uint32_t>(n_miss, (uint32_t)c->n_cus * 12u);
+            nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
+            HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
+            hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt2, wk2, stages, n_miss, (const uint32_t *)c->miss_list.as<uint32_t>(),
+                               c->scratch.as<unsigned char>(), big_cap, bpw);
+            HIP_TRY(c, hipGetLastError());
+            PLO_SUM_STATS(nw);
+            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            miss_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
         if (hc[CNT_OVERFLOW] == 0) break;
         if (attempt >= 3) {
@@ -1301,6 +1444,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_items = n_items;
     c->timing.n_big_items = n_huge;
     c->timing.n_mid_items = n_mid;
+    c->timing.n_miss_items = n_miss;
+    c->timing.miss_ms = miss_ms;
     c->timing.n_lane_items = n_small;
     c->timing.n_retry_items = n_retry;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
@@ -1333,6 +1478,10 @@ plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_fi
     c->err.clear();
     if (!c->have_last || c->last_bt.n_segs != in->n_segs || c->last_bt.n_reads != in->n_reads) {
         c->err = "plo_finish_batch_dev: call plo_liftover_batch_dev on the same batch first";
+        return PLO_ERR_INVALID_ARG;
+    }
+    if (c->last_bt.seq_fmt == PLO_SEQ_BAM4_SPARSE) {
+        c->err = "plo_finish_batch_dev: the batch came with sparse bases (PLO_SEQ_BAM4_SPARSE); the flipped sequences are written from complete ones";
         return PLO_ERR_INVALID_ARG;
     }
     HIP_TRY(c, hipSetDevice(c->ix->device));

@@ -101,12 +101,38 @@ struct ReadSeq {
     int fmt;
     int flip;
     int lo, hi;  // bytes p[lo .. hi) belong to the batch's seq buffer (bounds for the wide-window loads), clamped to +-2^30
+    int data;    // PLO_SEQ_BAM4_SPARSE: byte offset of the first granule behind the read's header
+    bool miss;   // PLO_SEQ_BAM4_SPARSE: a probe needed bases the batch does not carry
 };
-PLO_DEV int read_base(const ReadSeq &r, int i) {
+// PLO_SEQ_BAM4_SPARSE (include/portello_liftover.h): the read's bases in granules of 32 (16 bytes of BAM 4-bit packing), only some
+// of them present.  Header at p: one {u32 mask, u32 rank} pair per 32 granules (mask bit k = granule 32 b + k is present, rank =
+// present granules before granule 32 b), padded to a multiple of 16 bytes; the present granules follow in ascending order.
+// Stored bases [j0, j1] (at most two adjacent granules): byte offset of base j0's byte relative to p, or -1 when a granule is
+// absent or the header points outside the buffer (garbage headers cannot make a probe leave the batch's buffer).
+PLO_DEV int sparse_locate(const ReadSeq &r, int j0, int j1) {
+    const int g0 = j0 >> 5, g1 = j1 >> 5;
+    const PLO_GLOBAL uint32_t *hdr = (const PLO_GLOBAL uint32_t *)r.p;
+    const uint32_t m0 = hdr[2 * (g0 >> 5)], r0 = hdr[2 * (g0 >> 5) + 1], m1 = hdr[2 * (g1 >> 5)];
+    if (!((m0 >> (g0 & 31)) & 1u) || !((m1 >> (g1 & 31)) & 1u)) return -1;
+    const unsigned rank = r0 + (unsigned)__builtin_popcount(m0 & ((1u << (g0 & 31)) - 1u));
+    if (rank > 0x3ffffffu) return -1;
+    const long long off = (long long)r.data + (long long)rank * 16 + ((j0 >> 1) & 15);
+    if (off + (g1 - g0) * 16 + 20 > (long long)r.hi) return -1;
+    return (int)off;
+}
+PLO_DEV int read_base(ReadSeq &r, int i) {
     int j = r.flip ? (r.len - 1 - i) : i;
     int c;
-    if (r.fmt == PLO_SEQ_BAM4) {
-        int b = r.p[j >> 1];
+    if (r.fmt != PLO_SEQ_ASCII) {
+        int at = j >> 1;
+        if (r.fmt == PLO_SEQ_BAM4_SPARSE) {
+            at = sparse_locate(r, j, j);
+            if (at < 0) {
+                r.miss = true;
+                return 'N';
+            }
+        }
+        int b = r.p[at];
         int nib = (j & 1) ? (b & 15) : (b >> 4);
         // "=ACMGRSVTWYHKDBN"
         const unsigned long long lo = 0x565352474d43413dull;  // = A C M G R S V
@@ -117,16 +143,20 @@ PLO_DEV int read_base(const ReadSeq &r, int i) {
     }
     return r.flip ? comp_base(c) : c;
 }
-
+// SP: the kernel variant for batches with sparse bases.  The dense variants never see PLO_SEQ_BAM4_SPARSE (the format is folded to
+// one of the two dense ones, so the compiler drops the granule look-ups from them: they cost the tile kernel registers otherwise).
+template <bool SP>
 PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, int seq_len, int flip) {
     ReadSeq r;
     r.p = bt.seq + seq_off;
     r.len = seq_len;
-    r.fmt = bt.seq_fmt;
+    r.fmt = SP ? (int)PLO_SEQ_BAM4_SPARSE : (bt.seq_fmt == PLO_SEQ_ASCII ? (int)PLO_SEQ_ASCII : (int)PLO_SEQ_BAM4);
     r.flip = flip;
     const unsigned long long before = seq_off, after = bt.seq_bytes - seq_off;
     r.lo = -(int)(before < (1ull << 30) ? before : (1ull << 30));
     r.hi = (int)(after < (1ull << 30) ? after : (1ull << 30));
+    r.data = (int)sparse_header_bytes((uint32_t)seq_len);
+    r.miss = false;
     return r;
 }
 
@@ -139,6 +169,7 @@ PLO_DEV ReadSeq item_read_seq(const DevBatch &bt, unsigned long long seq_off, in
 // workgroup wherever a scan, co.sync() or co.any() is called.
 template <int NW>
 struct Coop {
+    static constexpr int NWAVES = NW;
     static constexpr int STEP = 64 * NW;
     static constexpr int XCH_INTS = 2 * 4 * NW + 4;  // two exchange buffers of 4 x NW words + 3 rotating flags
     int w = 0;           // index of the wave inside the workgroup
@@ -551,15 +582,23 @@ PLO_DEV unsigned comp4(unsigned w) {  // comp_base on the four ASCII bytes of w
 
 // X byte t (little-endian over X[0..3]) = ref[r0 + t] ^ read_base(rd, q0 + t), t = 0..15.
 // Returns false when a window does not lie inside its buffer: the caller then compares byte-wise.
-PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, unsigned X[4]) {
+PLO_DEV bool xor_window16(const uint8_t *ref, int ref_len, int r0, ReadSeq &rd, int q0, unsigned X[4]) {
     // all positions are below 2^31 (BAM coordinates): 32-bit index arithmetic throughout
     if (r0 < 0 || q0 < 0 || q0 > rd.len - 16) return false;
     const int rsh = (int)(((unsigned)(uintptr_t)ref + (unsigned)r0) & 3u);
     if (r0 - rsh < 0 || r0 - rsh > ref_len - 20) return false;
     // read bases q0 .. q0+15 are the stored positions jmin .. jmin+15 (in reverse order when flipped)
     const int jmin = rd.flip ? rd.len - q0 - 16 : q0;
-    const bool bam4 = rd.fmt == PLO_SEQ_BAM4;
-    const int b0 = bam4 ? (jmin >> 1) : jmin;  // first byte of the read window
+    const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
+    int b0 = bam4 ? (jmin >> 1) : jmin;  // first byte of the read window
+    if (rd.fmt == PLO_SEQ_BAM4_SPARSE) {
+        b0 = sparse_locate(rd, jmin, jmin + 15);
+        if (b0 < 0) {  // the batch does not carry these bases: the item is reported PLO_ITEM_NEED_BASES, the probe result is not used
+            rd.miss = true;
+            X[0] = X[1] = X[2] = X[3] = 0xffffffffu;
+            return true;
+        }
+    }
     const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
     const int qwords = bam4 ? 3 : 5;
     if (b0 - qsh < rd.lo || b0 - qsh + 4 * qwords > rd.hi) return false;
@@ -626,7 +665,7 @@ PLO_DEV int zero_bytes_from_bottom(const unsigned X[4]) {  // t = 0, 1, ...
 
 // number of k in [0, maxk) with ref[re-1-k] == read[qe-1-k], stopping at the first mismatch.  All indices are valid
 // (checked by the callers); `probes` counts the compared base pairs like the reference's loop would.
-PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, const ReadSeq &rd, int qe, int maxk, int &probes) {
+PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, ReadSeq &rd, int qe, int maxk, int &probes) {
     int k = 0;
     while (k < maxk) {
         unsigned X[4];
@@ -657,7 +696,7 @@ PLO_DEV int match_run_back(const uint8_t *ref, int ref_len, int re, const ReadSe
     return k;
 }
 // number of k in [0, maxk) with ref[rs+k] == read[qs+k], stopping at the first mismatch
-PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, const ReadSeq &rd, int qs, int maxk, int &probes) {
+PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, ReadSeq &rd, int qs, int maxk, int &probes) {
     int k = 0;
     while (k < maxk) {
         unsigned X[4];
@@ -690,7 +729,7 @@ PLO_DEV int match_run_fwd(const uint8_t *ref, int ref_len, int rs, const ReadSeq
 
 // left homology of get_indel_breakend_homology_info (lib/rust-vc-utils/src/indel_breakend_homology.rs:32-47),
 // capped at `bound` (the result is only used as min(match_run, h), cigar_indel_shifter.rs:132-133).
-PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound,
+PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, ReadSeq &rd, int qs, int ins, int bound,
                           bool &panic, int &probes) {
     int re = rs + del, qe = qs + ins;
     int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
@@ -753,7 +792,7 @@ struct TilePre {
     uint32_t g = 0, in_off = 0, n_in = 0, w0 = 0, w1 = 0, kv1 = 0, fl = 0;
 };
 
-template <int NW>
+template <int NW, bool SP = false>
 PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin,
                        int nit, TileMem m, const uint32_t *list, int level, int big_thresh, WaveCtx &ctx, const TilePre *pre = nullptr) {
     // NW > 1 (k_lift_mid): nit == 1, every wave of the workgroup runs this function on the same item; lane 0 of every wave
@@ -1051,11 +1090,15 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
             if (valid) {
                 bool panic = false;
                 int probes = 0;
-                ReadSeq rd = item_read_seq(bt, i_soff, i_slen, i_flip);
+                ReadSeq rd = item_read_seq<SP>(bt, i_soff, i_slen, i_flip);
                 int h = left_homology((const uint8_t *)(uintptr_t)i_ref, i_rlen, m.T0[e], m.T3[e], rd, m.T1[e], m.T4[e], m.T2[e],
                                       panic, probes);
                 algo_bytes += 2ull * (unsigned)probes;
                 if (panic) wv::atomic_or(&m.itp[id], 1);
+                if (rd.miss) {
+                    wv::atomic_or(&m.itp[id], 2);
+                    h = 0;
+                }
                 m.T1[e] = h;  // the read start is not needed any more: the head's slot carries the homology to pass B
             }
         }
@@ -1157,8 +1200,8 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
             cA = cB;
             nA = nOut;
             pos1 += shift;
-            if (has && m.itp[lane]) {
-                status = PLO_ITEM_PANIC;
+            if (has && m.itp[lane]) {  // absent bases (sparse batches) come first: what the probes saw then is not the read
+                status = (m.itp[lane] & 2) ? PLO_ITEM_NEED_BASES : PLO_ITEM_PANIC;
                 alive = false;
             }
         }
@@ -1538,7 +1581,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                 int complex_done = 0;
                 if (del > 0 && ins > 0 && !(del == 1 && ins == 1)) {
                     int rs0 = m.T0[e], qs0 = m.T1[e];
-                    ReadSeq rd = item_read_seq(bt, i_soff, i_slen, i_flip);
+                    ReadSeq rd = item_read_seq<SP>(bt, i_soff, i_slen, i_flip);
                     const uint8_t *ref = (const uint8_t *)(uintptr_t)i_ref;
                     if (rs0 < 0 || rs0 + del - 1 >= i_rlen || qs0 + ins - 1 >= rd.len) {
                         wv::atomic_or(&m.itp[id], 1);  // slice index out of bounds: the reference panics (:58-60)
@@ -1557,6 +1600,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                             ++post;
                         }
                         algo_bytes += 2ull * (unsigned)cmp;
+                        if (rd.miss) wv::atomic_or(&m.itp[id], 2);
                         m.T0[e] = pre;
                         m.T1[e] = post;
                         m.T3[e] = del;
@@ -1636,8 +1680,8 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
             cA = cB;
             nA = nOut;
             if (simp) pos1 += shift;  // :155
-            if (has && m.itp[lane]) {
-                status = PLO_ITEM_PANIC;
+            if (has && m.itp[lane]) {  // absent bases (sparse batches) come first: what the probes saw then is not the read
+                status = (m.itp[lane] & 2) ? PLO_ITEM_NEED_BASES : PLO_ITEM_PANIC;
                 alive = false;
             }
         }
@@ -1702,6 +1746,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         if (valid && i_em && fits) wk.out_cigar[gbase + (unsigned long long)(i_o + (e - i_s))] = m.A[e];
     }
     if (has && co.lead()) {
+        if (status == PLO_ITEM_NEED_BASES) wk.miss_list[wv::atomic_add_global(&wk.counters[CNT_NMISS], 1ull)] = g;  // rare
         wk.status[g] = (uint8_t)status;
         wk.pos[g] = emit_cigar ? (int64_t)pos1 : (int64_t)-1;
         wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
@@ -1725,6 +1770,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
 // would cost four memory round trips per tile; the first three are software-pipelined across tiles (bounds three tiles
 // ahead, item indices two, descriptor fields one), so that only the gather itself is waited for.
 // -------------------------------------------------------------------------------------------------------------------
+template <bool SP = false>
 PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first,
                                    uint32_t stride, uint32_t n_tiles, int big_thresh, TileMem m, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
@@ -1767,7 +1813,7 @@ PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         const uint32_t lo = (uint32_t)wv::bcast_first((int)lo0), hi = (uint32_t)wv::bcast_first((int)hi0);
         for (uint32_t b = lo; b < hi; b += 64) {
             int nit = (int)((hi - b) < 64u ? (hi - b) : 64u);
-            lift_tile(co, ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx, b == lo ? &d0 : nullptr);
+            lift_tile<1, SP>(co, ix, bt, wk, stages, b, nit, m, wk.perm, LEVEL_TILE, big_thresh, ctx, b == lo ? &d0 : nullptr);
             wv::sync();
         }
         lo0 = lo1;

@@ -11,6 +11,8 @@ constexpr int NONE32 = (int)0x80000000;  // Option::None for 32-bit positions / 
 constexpr int IMAX = 0x7fffffff;
 constexpr int ITEM_NEED_BIG = 0xFF;  // internal: tile capacity exceeded, item re-queued for the large-item kernel
 constexpr int MAXI = 64;             // items per tile = lanes per wave
+// PLO_SEQ_BAM4_SPARSE: bytes of a read's granule header ({u32 mask, u32 rank} per 1024 bases, padded to 16 bytes)
+constexpr uint32_t sparse_header_bytes(uint32_t seq_len) { return ((((seq_len + 1023u) >> 10) * 8u) + 15u) & ~15u; }
 
 struct alignas(8) KV {
     int key;  // contig position starting a block          (ReadToRefTreeMap key, read_to_ref_map.rs:59-64)
@@ -50,7 +52,7 @@ struct DevBatch {
     uint32_t n_reads, n_segs;
 };
 
-enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_NHUGE = 20, CNT_N = 24 };
+enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_NHUGE = 20, CNT_NMISS = 21, CNT_N = 24 };
 
 // Resolved per-item descriptors, written once per batch by the item kernels (thread per item, full occupancy) so that
 // the tile kernel starts from ONE level of coalesced loads instead of chasing item -> segment -> contig -> block map.
@@ -108,6 +110,7 @@ struct DevWork {
     uint32_t *big_list;            // items too heavy for a shared tile: workgroup-per-item kernel (k_lift_mid)
     const uint32_t *seg_readlen;   // [n_segs] read bases consumed by every read segment's CIGAR (k_seg_count); NULL: computed per item
     uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
+    uint32_t *miss_list;           // PLO_SEQ_BAM4_SPARSE: items whose probes needed absent bases (PLO_ITEM_NEED_BASES)
 };
 
 }  // namespace plo

@@ -67,7 +67,9 @@ class PipelineStats:
 def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: abi.IndexData, contig_names: Sequence[str],
                    ref_names: Sequence[str], ref_lens: Sequence[int], window_reads: int = 50_000, n_workers: int = 2,
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
-                   cmdline: str = "") -> PipelineStats:
+                   cmdline: str = "", sparse_margin: Optional[int] = 32) -> PipelineStats:
+    """sparse_margin: the windows' read bases go to the device as PLO_SEQ_BAM4_SPARSE (granules within that many bases of an indel;
+    the complete bases stay in the window's records for the engine's second look); None = dense bases"""
     st = PipelineStats()
     ixd = index_data.to_desc()
     rd = bam.BamReader(in_path, io_threads)
@@ -107,7 +109,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 win = rd.read_window(window_reads)
                 if win is None:
                     break
-                desc = win.batch_desc() if win.n_records else None
+                desc = win.batch_desc(sparse_margin=sparse_margin) if win.n_records else None
                 st.read_s += time.perf_counter() - t
                 put(q_in, (win, desc))
         except BaseException as e:  # noqa: BLE001

@@ -89,7 +89,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     o->cig_off.assign(a, 0);
     o->cig_len.assign(a, 0);
     std::vector<uint32_t> item_cls(a, 0), item_nin(a, 0), d_in_off(a), d_n_in(a), d_w0(a), d_w1(a), d_kv0(a), d_kv1(a), d_flags(a), d_contig(a),
-        d_seq_len(a), big_list(a, 0), huge_list(a, 0);
+        d_seq_len(a), big_list(a, 0), huge_list(a, 0), miss_list(a, 0);
     std::vector<int> d_pos1(a);
     std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
     std::vector<int> d_shift_ref_len(a), d_chrom_ref_len(a);
@@ -139,6 +139,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     };
     wk.big_list = big_list.data();
     wk.huge_list = huge_list.data();
+    wk.miss_list = miss_list.data();
+    const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;  // (sparse bases: such items keep PLO_ITEM_NEED_BASES here, the second look is the engine's)
     if (in->item_seg) {
         for (uint32_t i = 0; i < n_items; ++i)
             build_item_desc(ix, bt, wk, stages, i, in->item_seg[i], in->item_cseg[i], segment_ref_len(bt, in->item_seg[i]));
@@ -192,7 +194,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             TileMem m = carve_tile_mem(lds.data(), cap);
             w.run([&]() {
                 WaveCtx ctx;
-                lift_tiles_persistent(ix, bt, wk, stages, wv_id, n_waves, n_tiles, big_thresh, m, ctx);
+                if (sp) lift_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, n_tiles, big_thresh, m, ctx);
+                else lift_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, n_tiles, big_thresh, m, ctx);
                 wave_ctx_flush(wk, ctx, 0);
             });
             sum_stats();
@@ -210,7 +213,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.run([&]() {
                     WaveCtx ctx;
                     Coop<1> co;
-                    lift_tile(co, ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+                    if (sp) lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, true>(co, ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+ else lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, false>(co, ix, bt, wk, stages, r, (int)std::min<uint32_t>(per, n_retry - r), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();
@@ -237,7 +241,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                         co.w = wv::wave_id();
                         co.xch = xch;
                         for (uint32_t i = blk; i < n_big; i += n_blocks) {
-                            lift_tile(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
+                            if (sp) lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, true>(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
+ else lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, false>(co, ix, bt, wk, stages, i, 1, m, wk.big_list, LEVEL_MID, mid_thresh, ctx);
                             co.sync();
                         }
                         // the waves of the emulated workgroup share the one statistics slot: one wave at a time
@@ -269,7 +274,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                     WaveCtx ctx;
                     Coop<1> co;
                     for (uint32_t i = wv_id; i < n_big; i += n_bw) {
-                        lift_tile(co, ix, bt, wk, stages, i, 1, m, last_list, LEVEL_LAST, 0, ctx);
+                        if (sp) lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, true>(co, ix, bt, wk, stages, i, 1, m, last_list, LEVEL_LAST, 0, ctx);
+ else lift_tile<std::remove_reference_t<decltype(co)>::NWAVES, false>(co, ix, bt, wk, stages, i, 1, m, last_list, LEVEL_LAST, 0, ctx);
                         wv::sync();
                     }
                     wave_ctx_flush(wk, ctx, 0);

@@ -21,7 +21,7 @@ def declared_symbols():
     out = set()
     for h in ("portello_liftover.h", "portello_bam.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
-        out |= set(re.findall(r"^(?:plo_status|void|int|uint32_t|char \*|const char \*)\s*\*?(plo_[a-z0-9_]+)\(", text, flags=re.M))
+        out |= set(re.findall(r"^(?:plo_status|void|int|uint32_t|uint64_t|char \*|const char \*)\s*\*?(plo_[a-z0-9_]+)\(", text, flags=re.M))
     return sorted(out)
 
 
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     syms = declared_symbols()
     assert {"plo_index_create", "plo_ctx_create", "plo_liftover_batch", "plo_liftover_batch_dev", "plo_selftest", "plo_bam_open",
             "plo_bam_read_window", "plo_bam_window_batch", "plo_records_build", "plo_bam_writer_open", "plo_bam_output_header",
-            "plo_bam_window_n_records"} <= set(syms)
+            "plo_bam_window_n_records", "plo_bam_window_batch_sparse", "plo_sparse_seq_pack", "plo_sparse_seq_bound"} <= set(syms)
     for s in syms:
         assert hasattr(L, s), f"{s} declared in the header but not exported"
 
@@ -43,8 +43,8 @@ def test_version_string(lib_path):
 def test_ctypes_struct_layout_matches_header():
     # sizes implied by the header on LP64
     assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8
-    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8 + 4 * 4 + 2 * 4
-    assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8
+    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8 + 4 * 4 + 2 * 4 + 2 * 4
+    assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8 + 2 * 8
     assert C.sizeof(abi.PloIndexDesc) == 8 + 2 * 8 + 8 + 8 * 8 + 8 + 3 * 8 + 8
 
 
