@@ -609,6 +609,8 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
     for (uint32_t i = 0; i < ni; ++i)
         if (lift->item_status[i] == PLO_ITEM_LEN_MISMATCH || lift->item_status[i] == PLO_ITEM_PANIC)
             return fail(PLO_ERR_DATA, "an item ended LEN_MISMATCH / PANIC: the reference aborts here (src/read_alignment_scanner.rs:207-229)");
+        else if (lift->item_status[i] == PLO_ITEM_NEED_BASES)
+            return fail(PLO_ERR_INVALID_ARG, "plo_records_build: an item is PLO_ITEM_NEED_BASES (sparse bases lifted without seq_full): it has no result yet");
 
     struct ItemInfo {
         uint32_t flag;

@@ -167,7 +167,7 @@ PLO_DEV void finish_read(const DevBatch &bt, const DevWork &wk, const DevFinish 
     uint32_t i0 = u32_lower_bound(f.item_read, n, r), i1 = u32_lower_bound(f.item_read, n, r + 1);
     uint32_t nl = 0, best = 0xffffffffu;
     for (uint32_t i = i0; i < i1; ++i) {
-        if (wk.status[i] == PLO_ITEM_LEN_MISMATCH || wk.status[i] == PLO_ITEM_PANIC) wv::atomic_add_global(f.n_fault, 1u);
+        if (wk.status[i] == PLO_ITEM_LEN_MISMATCH || wk.status[i] == PLO_ITEM_PANIC || wk.status[i] == PLO_ITEM_NEED_BASES) wv::atomic_add_global(f.n_fault, 1u);
         if (wk.status[i] != PLO_ITEM_LIFTED) continue;
         ++nl;
         if (best == 0xffffffffu || wk.mapq[best] < wk.mapq[i]) best = i;
