@@ -318,7 +318,11 @@ constexpr int TILE_WAVES = 4;  // waves per workgroup; every wave works on its o
 #endif
 #define PLO_TILE_OCC __attribute__((amdgpu_waves_per_eu(PLO_TILE_WPE, PLO_TILE_WPE)))
 // (every lift kernel exists twice: for dense read bases and, `_sp`, for PLO_SEQ_BAM4_SPARSE batches, whose probes look granules up)
-template <bool SP>
+// CAPC > 0: the slice capacity as a compile-time constant.  The arrays of the slice then sit at constant offsets from one base and
+// the LDS instructions carry them as immediates (one address register per element instead of one per array and access): 166 -> 137
+// VGPRs at cap 320, and with cap 256 the kernel fits 128 VGPRs, i.e. 16 waves per CU -- which is also exactly what 16 slices of
+// tile_mem_bytes(256) = 10 240 B leave of the 160 KB of LDS.
+template <bool SP, int CAPC>
 PLO_DEV void lift_tiles_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n_tiles, int window,
                                int big_thresh, int cap, uint32_t lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -331,6 +335,10 @@ PLO_DEV void lift_tiles_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
     uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
     const uint32_t tw = blockDim.x >> 6;
     const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
+    if constexpr (CAPC > 0) {
+        cap = CAPC;
+        lds_per_wave = (uint32_t)((tile_mem_bytes(CAPC) + 15) & ~(size_t)15);
+    }
     TileMem m = carve_tile_mem(smem + (size_t)w * lds_per_wave, cap);
     WaveCtx ctx;
     (void)window;
@@ -344,12 +352,18 @@ PLO_DEV void lift_tiles_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
 __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
                                                                uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                uint32_t lds_per_wave) {
-    lift_tiles_kernel<false>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
+    lift_tiles_kernel<false, 0>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
+}
+constexpr int TILE_CAP_SMALL = 256;  // the geometry of batches without heavy items (HiFi reads on a clean assembly): see lift_tiles_kernel
+__global__ __launch_bounds__(TILE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lift_tiles_c256(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
+                                                               uint32_t n_tiles, int window, int big_thresh, int cap,
+                                                               uint32_t lds_per_wave) {
+    lift_tiles_kernel<false, TILE_CAP_SMALL>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
 }
 __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages,
                                                                   uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                   uint32_t lds_per_wave) {
-    lift_tiles_kernel<true>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
+    lift_tiles_kernel<true, 0>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
@@ -905,6 +919,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     }
     (void)hipFuncSetAttribute((const void *)k_lift_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_tiles_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_tiles_c256, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_retry_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_mid_sp<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_mid_sp<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1019,6 +1034,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     bt.n_reads = in->n_reads;
     bt.n_segs = in->n_segs;
     const DevIndex &ix = c->ix->d;
+    const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;  // the `_sp` kernels: probes look granules up
     hipStream_t st = c->stream;
     memset(&c->timing, 0, sizeof(c->timing));
     c->ev_big = false;
@@ -1230,7 +1246,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             // up to a threshold of 256 the 320-element slice (12 waves per CU) stays: the few tiles it cannot hold are re-run
             // item by item (k_lift_retry); measured on MI355X, 1 M reads, contig indel rate 1e-3: 4.3 ms against 5.3-7.2 ms
             // with 384-element slices.  Workgroup width per slice size as measured (tools/tune.py --contig-indel).
-            c->cap = thresh <= 256 ? 320 : (thresh + 144 + 63) & ~63;
+            // Lowest threshold (no heavy tail at all): the 256-element slice, whose kernel has the capacity compiled in and runs 16
+            // waves per CU (wgs30x, 2 M reads: 2.28 ms against 2.43 ms with 320-element slices at 12 waves per CU).
+            c->cap = thresh <= 176 && !sp && !getenv("PLO_NO_SMALL_CAP") ? TILE_CAP_SMALL : (thresh <= 256 ? 320 : (thresh + 144 + 63) & ~63);
             c->window = c->cap - 64;
             c->tile_waves = c->cap <= 320 ? TILE_WAVES : (c->cap <= 448 ? 2 : 1);
             if (getenv("PLO_DEBUG_GEOMETRY"))
@@ -1252,7 +1270,6 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
 
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
     uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0, n_miss = 0;
-    const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;
     float miss_ms = 0.f;
     for (int attempt = 0;; ++attempt) {
         wk.out_cigar = c->o_cigar.as<uint32_t>();
@@ -1267,7 +1284,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nblk = (n_tiles + tw - 1) / tw;
             // persistent grid: what the chip keeps resident (CUs x blocks per CU), a multiple of 8 for the XCD mapping
             int occ = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_tiles_sp : (const void *)k_lift_tiles, (int)tw * 64,
+            const bool c256 = !sp && c->cap == TILE_CAP_SMALL && tw == (uint32_t)TILE_WAVES && lds_per_wave == (uint32_t)((tile_mem_bytes(TILE_CAP_SMALL) + 15) & ~(size_t)15);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_tiles_sp : (c256 ? (const void *)k_lift_tiles_c256 : (const void *)k_lift_tiles), (int)tw * 64,
                                                              (size_t)lds_per_wave * tw) != hipSuccess || occ < 1)
                 occ = 1;
             nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
@@ -1276,6 +1294,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_offset = wk.slab_pre ? (unsigned long long)nblk * tw * SLAB_OPS : 0ull;
             if (sp)
                 hipLaunchKernelGGL(k_lift_tiles_sp, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
+                                   c->big_thresh, c->cap, lds_per_wave);
+            else if (c256)
+                hipLaunchKernelGGL(k_lift_tiles_c256, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
                                    c->big_thresh, c->cap, lds_per_wave);
             else
                 hipLaunchKernelGGL(k_lift_tiles, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,

@@ -750,9 +750,10 @@ PLO_DEV int left_homology(const uint8_t *ref, int ref_len, int rs, int del, Read
 struct WaveCtx {
     unsigned long long slab_base = 0;  // next free op of the wave's current slab
     unsigned long long slab_left = 0;  // ops left in it
-    unsigned long long algo_bytes = 0;  // per lane
-    unsigned long long in_ops = 0;      // per lane
-    unsigned long long out_ops = 0;     // per lane
+    // per lane, 32 bits: a wave's share of one launch stays far below 2^32 bytes / ops per lane (a batch is at most 2^31 ops in all)
+    unsigned algo_bytes = 0;
+    unsigned in_ops = 0;
+    unsigned out_ops = 0;
 #ifdef PLO_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader cycles per pipeline phase, flushed once per wave
 #endif
@@ -762,11 +763,11 @@ constexpr unsigned long long SLAB_OPS = 16384;
 // A retiring wave leaves its statistics in its own slot (plain stores): 3 atomics per wave on one cache line used to cost a
 // fixed ~75 us per launch (3 072 waves x 3 atomics at ~88 per microsecond and address).  k_sum_stats adds the slots up.
 PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx, uint32_t slot) {
-    unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.algo_bytes & 0xffffffull));
+    unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.algo_bytes & 0xffffffu));
     unsigned hi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.algo_bytes >> 24));
-    unsigned nlo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.in_ops & 0xffffffull));
+    unsigned nlo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.in_ops & 0xffffffu));
     unsigned nhi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.in_ops >> 24));
-    unsigned olo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops & 0xffffffull));
+    unsigned olo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops & 0xffffffu));
     unsigned ohi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops >> 24));
     if (wv::lane() == 0) {
         unsigned long long *w = wk.wave_stats + (size_t)slot * 4;
@@ -818,9 +819,9 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
 
     // ---- item descriptors: lane t <-> item t, resolved by build_item_desc (enumerate.hpp): one level of coalesced loads
     int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0;
-    int shift_ref_len = 0, chrom_ref_len = 0;
-    uint32_t read_len_in = 0;
-    unsigned long long seq_off = 0, shift_ref = 0, chrom_ref = 0;
+    int shift_ref_len = 0;
+    bool len_bad = false;  // LENGTH CHECK, decided from the descriptors (see there)
+    unsigned long long seq_off = 0, shift_ref = 0;
     bool rev = false, do_shift = false, flip = false;
     if (has) {
         uint32_t fl;
@@ -842,12 +843,13 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         pos1 = wk.d.pos1[g];
         kv0 = (int)wk.d.kv0[g];
         seq_len = (int)wk.d.seq_len[g];
-        read_len_in = wk.d.read_len[g];
+        {
+            const uint32_t read_len_in = wk.d.read_len[g];
+            len_bad = read_len_in == 0xffffffffu || (uint32_t)seq_len != read_len_in;
+        }
         seq_off = wk.d.seq_off[g];
         shift_ref = wk.d.shift_ref[g];
         shift_ref_len = wk.d.shift_ref_len[g];
-        chrom_ref = wk.d.chrom_ref[g];
-        chrom_ref_len = wk.d.chrom_ref_len[g];
         rev = (fl & ITF_REV) != 0;
         flip = (fl & ITF_FLIP) != 0;
         bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
@@ -884,7 +886,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         do_shift = false;
     }
     bool overflow = false;
-    unsigned long long algo_bytes = 0;
+    unsigned algo_bytes = 0;
 
     // Block-map windows of the tile's items -> LDS (m.K / m.V), flattened: entry j of the tile belongs to the item whose
     // [kb, kb + nk) contains j.  Only the source indices are computed here (into the idle ping-pong array); the loads go out
@@ -1093,7 +1095,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                 ReadSeq rd = item_read_seq<SP>(bt, i_soff, i_slen, i_flip);
                 int h = left_homology((const uint8_t *)(uintptr_t)i_ref, i_rlen, m.T0[e], m.T3[e], rd, m.T1[e], m.T4[e], m.T2[e],
                                       panic, probes);
-                algo_bytes += 2ull * (unsigned)probes;
+                algo_bytes += 2u * (unsigned)probes;
                 if (panic) wv::atomic_or(&m.itp[id], 1);
                 if (rd.miss) {
                     wv::atomic_or(&m.itp[id], 2);
@@ -1217,7 +1219,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         if (alive) {
             int nb = kv1 - kv0, lg = 0;
             while ((1 << lg) < nb) ++lg;
-            if (co.lead()) algo_bytes += 16ull * (unsigned)(W1 - W0) + 8ull * (unsigned)lg;
+            if (co.lead()) algo_bytes += 16u * (unsigned)(W1 - W0) + 8u * (unsigned)lg;
         } else {
             W1 = W0;
         }
@@ -1481,7 +1483,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
     if (!overflow && (stages & PLO_STAGE_LENCHECK)) {
         // The read bases consumed by the CIGAR at this point equal those of the input CIGAR (build_item_desc explains why the
         // shift and the liftover keep that number), which the enumerate pass has summed: no pass over the ops here.
-        if (alive && (read_len_in == 0xffffffffu || (uint32_t)seq_len != read_len_in)) {
+        if (alive && len_bad) {
             status = PLO_ITEM_LEN_MISMATCH;
             simp = false;
         }
@@ -1567,6 +1569,16 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         // (same test on the clusters themselves: complex clusters of items that take no part do not count)
         const bool identity = (stages & PLO_STAGE_LIFTOVER) && !co.any(changes);
         if (!identity) {
+        // The items' reference chromosome and read bases are fetched here, not with the other descriptor fields: few tiles get
+        // this far (the lifted CIGARs of most have no multi-op cluster), and the tile kernel is short of registers.
+        unsigned long long chrom_ref = 0, seq_off_s = 0;
+        int chrom_ref_len = 0, seq_len_s = 0;
+        if (has && !overflow) {
+            chrom_ref = wk.d.chrom_ref[g];
+            chrom_ref_len = wk.d.chrom_ref_len[g];
+            seq_off_s = wk.d.seq_off[g];
+            seq_len_s = (int)wk.d.seq_len[g];
+        }
         // pass H: one lane per cluster; only complex clusters (both I and D, not 1/1) look at the sequences
         // (CigarBlockInfo::end_indel :49-105).  Results overwrite the head's slots: T0 pre, T1 post, T3 del, T4 ins.
         if (!overflow) PLO_CHUNKS(base, nH) {
@@ -1574,8 +1586,8 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
             bool valid = hl < nH;
             int e = valid ? heads_list[hl] : 0;
             int id = co.elem_id(m.idA, e, true);
-            int i_flip = co.item((int)flip, id), i_slen = co.item(seq_len, id), i_rlen = co.item(chrom_ref_len, id);
-            unsigned long long i_soff = co.item(seq_off, id), i_ref = co.item(chrom_ref, id);
+            int i_flip = co.item((int)flip, id), i_slen = co.item(seq_len_s, id), i_rlen = co.item(chrom_ref_len, id);
+            unsigned long long i_soff = co.item(seq_off_s, id), i_ref = co.item(chrom_ref, id);
             if (valid) {
                 int del = m.T3[e], ins = m.T4[e];
                 int complex_done = 0;
@@ -1599,7 +1611,7 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
                             ins = 0;
                             ++post;
                         }
-                        algo_bytes += 2ull * (unsigned)cmp;
+                        algo_bytes += 2u * (unsigned)cmp;
                         if (rd.miss) wv::atomic_or(&m.itp[id], 2);
                         m.T0[e] = pre;
                         m.T1[e] = post;
@@ -1751,12 +1763,12 @@ PLO_DEV void lift_tile(Coop<NW> &co, const DevIndex &ix, const DevBatch &bt, con
         wk.pos[g] = emit_cigar ? (int64_t)pos1 : (int64_t)-1;
         wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
         wk.cig_len[g] = (uint32_t)oc;
-        algo_bytes += 40ull + 4ull * (unsigned)n_in + 24ull + 4ull * (unsigned)oc;
+        algo_bytes += 40u + 4u * (unsigned)n_in + 24u + 4u * (unsigned)oc;
     }
     // statistics stay in registers until the wave retires (wave_ctx_flush)
     ctx.algo_bytes += algo_bytes;
-    ctx.in_ops += (has && co.lead()) ? (unsigned long long)n_in : 0ull;
-    ctx.out_ops += co.lead() ? (unsigned long long)oc : 0ull;
+    ctx.in_ops += (has && co.lead()) ? (unsigned)n_in : 0u;
+    ctx.out_ops += co.lead() ? (unsigned)oc : 0u;
     PLO_T(9)
 #undef PLO_T
 }
@@ -1800,6 +1812,10 @@ PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
     bounds(t, lo0, hi0);
     bounds(t + stride, lo1, hi1);
     bounds(t + 2 * stride, lo2, hi2);
+    lo1 = (uint32_t)wv::bcast_first((int)lo1);
+    hi1 = (uint32_t)wv::bcast_first((int)hi1);
+    lo2 = (uint32_t)wv::bcast_first((int)lo2);
+    hi2 = (uint32_t)wv::bcast_first((int)hi2);
     uint32_t g1 = load_g(lo1, hi1);
     TilePre d0;
     load_desc(lo0, hi0, load_g(lo0, hi0), d0);
@@ -1820,8 +1836,8 @@ PLO_DEV void lift_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         hi0 = hi1;
         lo1 = lo2;
         hi1 = hi2;
-        lo2 = lo3;
-        hi2 = hi3;
+        lo2 = (uint32_t)wv::bcast_first((int)lo3);  // (the same value in every lane: kept as scalars from here on)
+        hi2 = (uint32_t)wv::bcast_first((int)hi3);
         g1 = g2;
         d0 = d1;
     }
