@@ -219,6 +219,9 @@ typedef struct plo_timing {
     uint32_t n_mid_items;
     uint32_t n_miss_items; /* PLO_SEQ_BAM4_SPARSE: items that reached absent bases (lifted again from seq_full) */
     float miss_ms;         /* that second pass: list download, host gather, upload, kernel (wall clock)         */
+    uint32_t tile_cap;     /* geometry of the tile kernel for this batch: elements per LDS slice (256: the variant with the
+                              capacity compiled in, k_lift_tiles_c256) and window of item weights per tile        */
+    uint32_t tile_window;
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

@@ -131,6 +131,8 @@ class PloTiming(C.Structure):
         ("n_mid_items", C.c_uint32),
         ("n_miss_items", C.c_uint32),
         ("miss_ms", C.c_float),
+        ("tile_cap", C.c_uint32),
+        ("tile_window", C.c_uint32),
     ]
 
 

@@ -704,6 +704,7 @@ struct plo_ctx {
     bool adaptive = true;  // geometry chosen per batch (off when any of PLO_WINDOW / PLO_BIG_THRESH / PLO_CAP is set)
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
+    bool small_window_tight = false;  // the 256-element slice re-ran too many items with the wide window: keep 64 elements of allowance
     // (a lane-per-item kernel for short CIGARs was measured in round 1: forward items 1.6x faster than the tile kernel of that
     // time, reverse items 0.8x -- per-lane homology probes serialise HBM latency -- a net loss; removed.  The class order
     // it needed stays: tiles are strand-homogeneous.)
@@ -1249,7 +1250,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             // Lowest threshold (no heavy tail at all): the 256-element slice, whose kernel has the capacity compiled in and runs 16
             // waves per CU (wgs30x, 2 M reads: 2.28 ms against 2.43 ms with 320-element slices at 12 waves per CU).
             c->cap = thresh <= 176 && !sp && !getenv("PLO_NO_SMALL_CAP") ? TILE_CAP_SMALL : (thresh <= 256 ? 320 : (thresh + 144 + 63) & ~63);
-            c->window = c->cap - 64;
+            // the slice holds one window plus the overhang of its last item; weights count two units per block-map entry, ops only one,
+            // so the small slice gets by with half the allowance (measured: window 192 2.27 ms, 208 2.22 ms, 224 2.21 ms with 204 of
+            // 2 M items re-run) -- until a batch re-runs more than 0.5 % of its items
+            c->window = c->cap - (c->cap == TILE_CAP_SMALL && !c->small_window_tight ? 32 : 64);
             c->tile_waves = c->cap <= 320 ? TILE_WAVES : (c->cap <= 448 ? 2 : 1);
             if (getenv("PLO_DEBUG_GEOMETRY"))
                 fprintf(stderr, "[plo] batch geometry: thresh %d cap %d window %d tile_waves %d (max weight %u, %llu items beyond the 0.2 %% cut)\n", thresh, c->cap,
@@ -1466,9 +1470,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_big_items = n_huge;
     c->timing.n_mid_items = n_mid;
     c->timing.n_miss_items = n_miss;
+    c->timing.tile_cap = (uint32_t)c->cap;
+    c->timing.tile_window = (uint32_t)c->window;
     c->timing.miss_ms = miss_ms;
     c->timing.n_lane_items = n_small;
     c->timing.n_retry_items = n_retry;
+    if (c->adaptive && c->cap == TILE_CAP_SMALL && n_retry > n_items / 200) c->small_window_tight = true;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
     c->timing.n_out_ops = hc[CNT_OUT_OPS];
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];

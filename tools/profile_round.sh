@@ -10,8 +10,8 @@ python bench.py > $o/bench.json 2>/dev/null
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --e2e-reads 0 > $o/bench_under_rocprof.json 2>/dev/null
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/kernel_stats.csv
 PMC_EXTRA="--e2e-reads 0"
-tools/pmc_pass.sh "FETCH_SIZE" "k_lift" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
-tools/pmc_pass.sh "WRITE_SIZE" "k_lift" $PMC_EXTRA > $o/pmc_write.csv 2>&1
+tools/pmc_pass.sh "FETCH_SIZE" "k_lift_tiles" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
+tools/pmc_pass.sh "WRITE_SIZE" "k_lift_tiles" $PMC_EXTRA > $o/pmc_write.csv 2>&1
 tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "k_lift_tiles" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
 tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "k_lift_tiles" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
 # stress: the workgroup-per-item kernel

@@ -33,7 +33,7 @@ def rd(p):
 fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
 with open(f"{pre}_pmc_summary.csv", "w") as f:
     f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_tiles --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0\n")
-    f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of k_lift_tiles; FETCH_SIZE / WRITE_SIZE in KiB\n")
+    f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of the tile kernel (k_lift_tiles_c256 for this workload); FETCH_SIZE / WRITE_SIZE in KiB\n")
     f.write("counter,mean_per_launch,launches\n")
     for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
         for l in open(f"{src}/{p}.csv"):
@@ -41,7 +41,7 @@ with open(f"{pre}_pmc_summary.csv", "w") as f:
                 f.write(l)
 h = json.load(open("profiles/hbm_traffic.json"))
 b = json.load(open(f"{src}/bench.json"))
-h["wgs30x"] = {"k_lift_tiles": int((2 * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr,
+h["wgs30x"] = {b["roofline"]["kernel"]: int((2 * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr,
                "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"]}
 json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
 print(h["wgs30x"])
