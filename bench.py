@@ -55,7 +55,8 @@ def cpu_baseline(w, got, budget_s: float = 12.0, ixd=None):
     from oracle import pyoracle
 
     pyoracle.build()
-    cores = os.cpu_count() or 1
+    # threads = the cores this process may actually use (the GPU boxes report 256 logical CPUs under a cgroup quota of 16)
+    cores = pipeline_cpus()
     ixd = w.index_data() if ixd is None else ixd  # host copy of the index
     n_reads = w.n_reads
     # calibrate on a small slice, then size the sample for ~budget_s of wall time on all cores
@@ -95,7 +96,7 @@ def cpu_baseline(w, got, budget_s: float = 12.0, ixd=None):
                       f"oracle/liboracle.so = C restatement of the reference algorithm, not the reference binary (sorted-array block "
                       f"maps with bisection where the reference has a BTreeMap; segments split evenly over {cores} pthreads where the "
                       f"reference spawns rayon tasks per 20 Mb window); 1 thread: {rate1:.0f} reads/s",
-            "single_thread_value": rate1, "seconds": dt}, ok, n_items
+            "single_thread_value": rate1, "seconds": dt, "host_cpus_reported": os.cpu_count()}, ok, n_items
 
 
 def pipeline_cpus() -> int:

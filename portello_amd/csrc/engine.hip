@@ -46,7 +46,8 @@ using namespace plo;
 // xor-shuffle reduction, so that one load instruction covers SEG_LANES * 4 contiguous bytes of every segment's CIGAR;
 // lane 0 of the group then does the overlap test against the contig's segments.
 #ifndef PLO_SEG_LANES
-#define PLO_SEG_LANES 8  // measured on MI355X (wgs30x enumerate pass): 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms
+#define PLO_SEG_LANES 4  // measured on MI355X (wgs30x enumerate pass, round 1): 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms;
+                         // round 2: 8 lanes 0.539 ms, 4 lanes (8 loads in flight per lane) 0.485 ms, 2 lanes 0.486 ms
 #endif
 constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 2 : 32 / SEG_LANES;
 // It is also the boundary check of the device path (the kernels index with what the batch says): bit 0 of *err = an index
@@ -375,6 +376,7 @@ PLO_DEV void lift_retry_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
     TileMem m = carve_tile_mem(smem, cap);
     WaveCtx ctx;
     Coop<1> co;
+    if (n_retry == 0xffffffffu) n_retry = (uint32_t)wk.counters[CNT_NRETRY];  // as the tile kernel left it (this kernel hands on to big_list)
     for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
         uint32_t left = n_retry - r;
         lift_tile<1, SP>(co, ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
@@ -464,13 +466,13 @@ __global__ void k_miss_patch(const uint32_t *list, uint32_t n, const uint64_t *v
     if (k < n) seq_off[list[k]] = vals[k];
 }
 
-// sums (and clears) the per-wave statistic slots of the lift kernel that has just run into the batch counters; one block
+// sums (and clears) the per-wave statistic slots of the lift kernels that have run since the last call into the batch counters
 __global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint32_t n_slots, unsigned long long *counters) {
     __shared__ unsigned long long acc[3];
     if (threadIdx.x < 3) acc[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long a = 0, b = 0, c = 0;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
         unsigned long long *w = ws + (size_t)i * 4;
         a += w[0];
         b += w[1];
@@ -482,9 +484,9 @@ __global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint3
     atomicAdd(&acc[2], c);
     __syncthreads();
     if (threadIdx.x == 0) {
-        counters[CNT_ALGO_BYTES] += acc[0];
-        counters[CNT_IN_OPS] += acc[1];
-        counters[CNT_OUT_OPS] += acc[2];
+        atomicAdd(&counters[CNT_ALGO_BYTES], acc[0]);
+        atomicAdd(&counters[CNT_IN_OPS], acc[1]);
+        atomicAdd(&counters[CNT_OUT_OPS], acc[2]);
     }
 }
 
@@ -1158,9 +1160,23 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         }
     }
     wk.wave_stats = c->wave_stats.as<unsigned long long>();
-#define PLO_SUM_STATS(n_waves_)                                                                                                 \
-    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), (uint32_t)(n_waves_), \
-                       c->counters.as<unsigned long long>())
+    // every lift launch of a batch leaves its waves' statistics in its own range of slots (PLO_STAT_RANGE before the launch); they
+    // are added up once before the host reads the counters (PLO_READ_COUNTERS), not after every kernel
+    uint32_t stat_used = 0;
+#define PLO_STAT_RANGE(n_waves_)     \
+    do {                             \
+        wk.stat_base = stat_used;    \
+        stat_used += (n_waves_);     \
+    } while (0)
+#define PLO_READ_COUNTERS()                                                                                                          \
+    do {                                                                                                                             \
+        if (stat_used)                                                                                                               \
+            hipLaunchKernelGGL(k_sum_stats, dim3(std::min<uint32_t>((stat_used + 255) / 256, 16u)), dim3(256), 0, st,                 \
+                               c->wave_stats.as<unsigned long long>(), stat_used, c->counters.as<unsigned long long>());            \
+        stat_used = 0;                                                                                                               \
+        HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));                                         \
+        HIP_TRY(c, hipStreamSynchronize(st));                                                                                        \
+    } while (0)
     wk.big_list = c->big_list.as<uint32_t>();
     wk.miss_list = c->miss_list.as<uint32_t>();
     if (n_items) {
@@ -1296,6 +1312,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             nblk = (nblk + 7u) & ~7u;
             wk.slab_pre = n_small == 0 ? 1u : 0u;  // nothing has been reserved yet (the lane kernel did not run)
             wk.slab_offset = wk.slab_pre ? (unsigned long long)nblk * tw * SLAB_OPS : 0ull;
+            PLO_STAT_RANGE(nblk * tw);
             if (sp)
                 hipLaunchKernelGGL(k_lift_tiles_sp, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
                                    c->big_thresh, c->cap, lds_per_wave);
@@ -1307,26 +1324,24 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                    c->big_thresh, c->cap, lds_per_wave);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
-            PLO_SUM_STATS(nblk * tw);
         } else {
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
         }
-        HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        n_retry = (uint32_t)hc[CNT_NRETRY];
-        if (n_retry) {
-            // one item of at most big_thresh weight: the shift / simplify stages at most double its ops
+        if (n_items > n_small) {
+            // Items of tiles whose intermediates overflowed the slice, one per wave with a slice of twice the threshold (the shift /
+            // simplify stages at most double an item's ops).  Launched without asking the host how many there are: the kernel reads
+            // the count the tile kernel left (mostly zero -- a few microseconds -- and a host round trip less when it is not).
             const int retry_cap = std::min(4096, std::max(c->cap, (2 * c->big_thresh + 64 + 63) & ~63));
             uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15);
-            uint32_t nw = std::min<uint32_t>((n_retry + RETRY_PER - 1) / RETRY_PER, (uint32_t)c->n_cus * 6u);
-            if (sp) hipLaunchKernelGGL(k_lift_retry_sp, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
-            else hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, n_retry, c->big_thresh, retry_cap);
-            PLO_SUM_STATS(nw);
+            uint32_t nw = (uint32_t)c->n_cus * 2u;
+            PLO_STAT_RANGE(nw);
+            if (sp) hipLaunchKernelGGL(k_lift_retry_sp, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, c->big_thresh, retry_cap);
+            else hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, c->big_thresh, retry_cap);
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
         }
         HIP_TRY(c, hipEventRecord(c->ev[5], st));
+        PLO_READ_COUNTERS();
+        n_retry = (uint32_t)hc[CNT_NRETRY];
         n_big = (uint32_t)hc[CNT_NBIG];
         n_mid = 0;
         n_huge = n_big;
@@ -1350,6 +1365,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             if (getenv("PLO_DEBUG_GEOMETRY"))
                 fprintf(stderr, "[plo] workgroup-per-item kernel: %u items, %d waves, cap %d (threshold %d), %zu B LDS, %d workgroups per CU\n", n_big, nw,
                         cap, mid_thresh, lds, occ);
+            PLO_STAT_RANGE(nblk * (uint32_t)nw);
             if (sp && nw == 16)
                 hipLaunchKernelGGL(k_lift_mid_sp<16>, dim3(nblk), dim3(16 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
             else if (sp)
@@ -1360,10 +1376,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 hipLaunchKernelGGL(k_lift_mid<8>, dim3(nblk), dim3(8 * 64), lds, st, ix, bt, wk, stages, n_big, mid_thresh, cap);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[6], st));
-            PLO_SUM_STATS(nblk * (uint32_t)nw);
             c->ev_mid = true;
-            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
+            PLO_READ_COUNTERS();
             n_huge = (uint32_t)hc[CNT_NHUGE];
             n_mid = n_big - n_huge;
             huge_src = c->huge_list.as<uint32_t>();
@@ -1379,6 +1393,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nw = std::min<uint32_t>(n_huge, (uint32_t)c->n_cus * 12u);
             nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
             HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
+            PLO_STAT_RANGE(nw);
             if (sp)
                 hipLaunchKernelGGL(k_lift_big_sp, dim3(nw), dim3(64), 0, st, ix, bt, wk, stages, n_huge, huge_src, c->scratch.as<unsigned char>(),
                                    big_cap, bpw);
@@ -1387,10 +1402,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                    big_cap, bpw);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[3], st));
-            PLO_SUM_STATS(nw);
             c->ev_big = true;
-            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
+            PLO_READ_COUNTERS();
         }
         n_miss = (uint32_t)hc[CNT_NMISS];
         if (n_miss && in->seq_full && in->read_seq_full_off) {
@@ -1447,12 +1460,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nw = std::min<uint32_t>(n_miss, (uint32_t)c->n_cus * 12u);
             nw = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nw, (4ull << 30) / bpw));
             HIP_TRY(c, c->scratch.ensure((size_t)bpw * nw));
+            wk2.stat_base = stat_used;
+            stat_used += nw;
             hipLaunchKernelGGL(k_lift_big, dim3(nw), dim3(64), 0, st, ix, bt2, wk2, stages, n_miss, (const uint32_t *)c->miss_list.as<uint32_t>(),
                                c->scratch.as<unsigned char>(), big_cap, bpw);
             HIP_TRY(c, hipGetLastError());
-            PLO_SUM_STATS(nw);
-            HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
+            PLO_READ_COUNTERS();
             miss_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
         if (hc[CNT_OVERFLOW] == 0) break;

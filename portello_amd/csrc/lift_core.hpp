@@ -770,7 +770,7 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx, uint32_t slot) {
     unsigned olo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops & 0xffffffu));
     unsigned ohi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops >> 24));
     if (wv::lane() == 0) {
-        unsigned long long *w = wk.wave_stats + (size_t)slot * 4;
+        unsigned long long *w = wk.wave_stats + (size_t)(wk.stat_base + slot) * 4;
         w[0] = (unsigned long long)lo + ((unsigned long long)hi << 24);
         w[1] = (unsigned long long)nlo + ((unsigned long long)nhi << 24);
         w[2] = (unsigned long long)olo + ((unsigned long long)ohi << 24);

@@ -110,6 +110,7 @@ struct DevWork {
     uint32_t *big_list;            // items too heavy for a shared tile: workgroup-per-item kernel (k_lift_mid)
     const uint32_t *seg_readlen;   // [n_segs] read bases consumed by every read segment's CIGAR (k_seg_count); NULL: computed per item
     uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
+    uint32_t stat_base;            // first statistic slot of the launch (every lift launch of a batch has its own range)
     uint32_t *miss_list;           // PLO_SEQ_BAM4_SPARSE: items whose probes needed absent bases (PLO_ITEM_NEED_BASES)
 };
 
