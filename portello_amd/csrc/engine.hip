@@ -227,21 +227,45 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n,
     __syncthreads();
     uint32_t m = 0;
     unsigned long long sum = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t v = in[i];
+    // (the weights of a batch crowd into a few bins: one LDS atomic per distinct bin of a wave's 64 items, not one per item)
+    const uint32_t n_up = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += gridDim.x * blockDim.x) {
+        const bool live = i < n;
+        uint32_t v = live ? in[i] : 0u;
         m = v > m ? v : m;
         sum += v;
         uint32_t b = v / WHIST_STEP;
-        atomicAdd(&hist[b < WHIST_BINS - 1 ? b : WHIST_BINS - 1], 1u);
+        b = b < WHIST_BINS - 1 ? b : WHIST_BINS - 1;
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lb = (uint32_t)__shfl((int)b, leader, 64);
+            const unsigned long long same = __ballot(live && b == lb);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
     }
     __syncthreads();
     if (threadIdx.x < WHIST_BINS && hist[threadIdx.x]) atomicAdd(out + WHIST_AT + threadIdx.x, hist[threadIdx.x]);
     int r = wv::reduce_max((int)(m & 0x7fffffffu));
     unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(sum & 0xffffffull));
     unsigned hi = (unsigned)wv::reduce_add((int)(unsigned)(sum >> 24));
+    // one global atomic per block and counter (a hot address takes ~88 atomics per microsecond)
+    __shared__ unsigned long long bsum;
+    __shared__ unsigned bmax;
+    if (threadIdx.x == 0) {
+        bsum = 0;
+        bmax = 0;
+    }
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        if (r > 0) atomicMax(out, (uint32_t)r);
-        atomicAdd((unsigned long long *)(out + 2), (unsigned long long)lo + ((unsigned long long)hi << 24));
+        if (r > 0) atomicMax(&bmax, (unsigned)r);
+        atomicAdd(&bsum, (unsigned long long)lo + ((unsigned long long)hi << 24));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bmax) atomicMax(out, bmax);
+        atomicAdd((unsigned long long *)(out + 2), bsum);
     }
 }
 
@@ -1219,7 +1243,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->misc.ensure(256));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
         if (n_items)
-            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 64u)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 256u)), dim3(256), 0, st,
                                (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>(),
                                (const uint32_t *)c->op_prefix.as<uint32_t>() + n_items, (const uint32_t *)c->rank0.as<uint32_t>() + n_items,
                                (const uint32_t *)c->rank1.as<uint32_t>() + n_items);

@@ -31,15 +31,29 @@ PLO_DEV uint32_t segment_read_len_sat(const DevBatch &bt, uint32_t seg) {
 }
 
 // block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
+// Eight-way: seven independent probes per level, so that a map of a few thousand blocks costs four or five memory round trips
+// instead of a dozen dependent ones (the descriptor kernel is a chain of dependent loads per item, nothing else).
 PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (kv[mid].key <= x)
-            lo = mid + 1;
-        else
-            hi = mid;
+    // invariant: keys below lo are <= x, keys from hi on are > x
+    while (hi - lo > 8) {
+        const int step = (hi - lo) >> 3;
+        int k[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) k[j] = kv[lo + (j + 1) * step].key;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) c += k[j] <= x ? 1 : 0;  // sorted keys: the probes with key <= x are the first c
+        const int nlo = c > 0 ? lo + c * step + 1 : lo;
+        hi = c < 7 ? lo + (c + 1) * step : hi;
+        lo = nlo;
     }
-    return lo;
+    int k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = lo + j < hi ? kv[lo + j].key : 0x7fffffff;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += (lo + j < hi && k[j] <= x) ? 1 : 0;
+    return lo + c;
 }
 PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key >= x, else hi
     while (lo < hi) {
@@ -55,6 +69,16 @@ PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first inde
 // same result as kv_lower_bound when the answer is expected a few entries after `lo` (the end of an item's window):
 // probes lo, lo+1, lo+3, lo+7, ... before bisecting the bracket
 PLO_DEV int kv_lower_bound_near(const KV *kv, int lo, int hi, int x) {
+    {   // the next eight entries at once: nearly always enough (a read crosses a few blocks)
+        int k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = lo + j < hi ? kv[lo + j].key : 0x7fffffff;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c += (lo + j < hi && k[j] < x) ? 1 : 0;
+        if (c < 8 || lo + 8 >= hi) return lo + c;
+        lo += 8;
+    }
     int step = 1;
     while (lo < hi) {
         int probe = lo + step - 1;
