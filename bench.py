@@ -350,64 +350,6 @@ def main():
     else:
         total_reads = float(my_reads)
 
-    # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
-    no_gather = async_gather = verify = None
-    if dist is not None:
-        dt_ng = timed(lambda n: run_steps(n, False, gather=False), args.steps)
-        no_gather = {"value": total_reads * args.steps / dt_ng, "unit": "reads/s", "ms_per_step": dt_ng / args.steps * 1e3,
-                     "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
-        if n_workers == 1:
-            # the exchange of batch i stays in flight while batch i+1 is computed into a second context's buffers.  Both the
-            # posting and the wait happen under the owning engine's stream: RCCL then starts the sends behind the compaction
-            # kernel, and the engine's next kernels start behind the sends that still read its buffers.
-            s2 = torch.cuda.Stream(device=dev)
-            a_streams = [streams[0], s2]
-            a_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
-            a_engs[1].liftover_batch_dev(desc)  # sizes its buffers
-            a_engs[1].sync()
-
-            def run_async(n_steps):
-                pending = [None, None]
-                for i in range(n_steps):
-                    k = i & 1
-                    if pending[k] is not None:
-                        with torch.cuda.stream(a_streams[k]):
-                            pending[k].wait()
-                        pending[k] = None
-                    out_k = a_engs[k].liftover_batch_dev(desc)
-                    a_engs[k].compact_output_dev(out_k)
-                    with torch.cuda.stream(a_streams[k]):
-                        pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
-                for k, p_ in enumerate(pending):
-                    if p_ is not None:
-                        with torch.cuda.stream(a_streams[k]):
-                            p_.wait()
-
-            run_async(2)
-            dt_a = timed(run_async, args.steps)
-            async_gather = {"value": total_reads * args.steps / dt_a, "unit": "reads/s", "ms_per_step": dt_a / args.steps * 1e3,
-                            "note": "record gather of batch i overlapped with the compute of batch i+1 (two contexts alternate)"}
-            a_engs[1].close()
-        # one more synchronous step whose gathered records rank 0 compares with its own result of the WHOLE read set
-        step(0)
-        torch.cuda.synchronize()
-        if strong and not args.no_verify:
-            if rank == 0:
-                seg_maps = [plo_gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)) for r in range(world)]
-                got_all = plo_gather.combine(last_gather[0], seg_maps)
-                got_all = {k_: v.clone() for k_, v in got_all.items()}
-                whole_db = devbatch.DeviceBatch.from_workload(w)
-                whole_out = eng.liftover_batch_dev(whole_db.desc())
-                eng.sync()
-                whole = plo_gather.tensors_from_out(whole_out, dev)
-                same = plo_gather.same_records(got_all, whole)
-                verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
-                          "reads": int(w.n_reads)}
-                if not same:
-                    log("[bench] VERIFY FAILURE: gathered records differ from the single-GPU result")
-                step(0, gather=False)  # restore this rank's own result in the context (read by the roofline object below)
-            barrier()
-
     overlap = None
     if dist is None and n_workers == 1 and args.overlap_workers > 1:
         # supplementary: the same K batches dealt to several workers (not `value`: see --workers)
@@ -481,6 +423,83 @@ def main():
                      "enumerate_ms": float(np.mean(times["enum"])), "lift_tiles_ms": kms["k_lift_tiles"],
                      "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"]},
     }
+    # Everything from here on is supplementary.  At N > 1 it runs more collectives (gather variants, verification): if any of that
+    # does not finish, every rank gives up after a while and rank 0 still prints the headline measurement made above.
+    watchdog = None
+    if dist is not None:
+        def bail():
+            log("[bench] the supplementary distributed measurements did not finish in time: printing the headline result without them")
+            result["supplementary_timed_out"] = True
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(float(os.environ.get("PLO_BENCH_SUPP_TIMEOUT", "300")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        no_gather = async_gather = verify = None
+        # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
+        if dist is not None:
+            dt_ng = timed(lambda n: run_steps(n, False, gather=False), args.steps)
+            no_gather = {"value": total_reads * args.steps / dt_ng, "unit": "reads/s", "ms_per_step": dt_ng / args.steps * 1e3,
+                         "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
+            if n_workers == 1:
+                # the exchange of batch i stays in flight while batch i+1 is computed into a second context's buffers.  Both the
+                # posting and the wait happen under the owning engine's stream: RCCL then starts the sends behind the compaction
+                # kernel, and the engine's next kernels start behind the sends that still read its buffers.
+                s2 = torch.cuda.Stream(device=dev)
+                a_streams = [streams[0], s2]
+                a_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
+                a_engs[1].liftover_batch_dev(desc)  # sizes its buffers
+                a_engs[1].sync()
+
+                def run_async(n_steps):
+                    pending = [None, None]
+                    for i in range(n_steps):
+                        k = i & 1
+                        if pending[k] is not None:
+                            with torch.cuda.stream(a_streams[k]):
+                                pending[k].wait()
+                            pending[k] = None
+                        out_k = a_engs[k].liftover_batch_dev(desc)
+                        a_engs[k].compact_output_dev(out_k)
+                        with torch.cuda.stream(a_streams[k]):
+                            pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
+                    for k, p_ in enumerate(pending):
+                        if p_ is not None:
+                            with torch.cuda.stream(a_streams[k]):
+                                p_.wait()
+
+                run_async(2)
+                dt_a = timed(run_async, args.steps)
+                async_gather = {"value": total_reads * args.steps / dt_a, "unit": "reads/s", "ms_per_step": dt_a / args.steps * 1e3,
+                                "note": "record gather of batch i overlapped with the compute of batch i+1 (two contexts alternate)"}
+                a_engs[1].close()
+            # one more synchronous step whose gathered records rank 0 compares with its own result of the WHOLE read set
+            step(0)
+            torch.cuda.synchronize()
+            if strong and not args.no_verify:
+                if rank == 0:
+                    seg_maps = [plo_gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)) for r in range(world)]
+                    got_all = plo_gather.combine(last_gather[0], seg_maps)
+                    got_all = {k_: v.clone() for k_, v in got_all.items()}
+                    whole_db = devbatch.DeviceBatch.from_workload(w)
+                    whole_out = eng.liftover_batch_dev(whole_db.desc())
+                    eng.sync()
+                    whole = plo_gather.tensors_from_out(whole_out, dev)
+                    same = plo_gather.same_records(got_all, whole)
+                    verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
+                              "reads": int(w.n_reads)}
+                    if not same:
+                        log("[bench] VERIFY FAILURE: gathered records differ from the single-GPU result")
+                    step(0, gather=False)  # restore this rank's own result in the context (read by the roofline object below)
+                barrier()
+
+    except Exception as e:  # noqa: BLE001 -- supplementary objects must never hide the measurement
+        log(f"[bench] supplementary distributed measurements failed: {e!r}")
+    if watchdog is not None:
+        watchdog.cancel()
     for name, obj in (("shard", shard_info), ("overlap", overlap), ("no_gather", no_gather), ("async_gather", async_gather),
                       ("verify", verify)):
         if obj is not None:

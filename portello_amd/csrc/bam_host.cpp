@@ -2,6 +2,8 @@
 // (get_seq_order_read_split_segments), BAM record bytes of the lifted alignments, BGZF output.  Plain C++17 + zlib;
 // no GPU code.  Citations are relative to /root/reference; rust-htslib / htslib semantics are restated from their
 // published behaviour (third party, absent from the reference tree).
+#include <chrono>
+
 #include "bam_internal.hpp"
 
 namespace {
@@ -108,11 +110,21 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     w->reader = r;
     w->threads = r->threads;
     plo_status st = PLO_OK;
+    const bool dbg = getenv("PLO_DEBUG_READER") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_fill = 0;
+    auto timed_fill = [&](size_t want) {
+        if (!dbg) return r->in.fill(want);
+        const auto a = std::chrono::steady_clock::now();
+        plo_status s2 = r->in.fill(want);
+        t_fill += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        return s2;
+    };
     // walk the records of the inflated stream (no copies), then take the whole stretch with one parallel copy
     size_t at = 0;  // offset from r->in.bpos
     std::vector<uint64_t> unm_at;
     while (w->rec_at.size() < max_records) {
-        if (r->in.avail() < at + 4 && (st = r->in.fill(at + 4)) != PLO_OK) break;
+        if (r->in.avail() < at + 4 && (st = timed_fill(at + 4)) != PLO_OK) break;
         if (r->in.avail() == at) break;  // end of file
         if (r->in.avail() < at + 4) {
             st = fail(PLO_ERR_IO, "truncated BAM record");
@@ -123,7 +135,7 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
             st = fail(PLO_ERR_IO, "BAM record shorter than its fixed fields");
             break;
         }
-        if (r->in.avail() < at + 4 + (size_t)bs && (st = r->in.fill(at + 4 + (size_t)bs)) != PLO_OK) break;
+        if (r->in.avail() < at + 4 + (size_t)bs && (st = timed_fill(at + 4 + (size_t)bs)) != PLO_OK) break;
         if (r->in.avail() < at + 4 + (size_t)bs) {
             st = fail(PLO_ERR_IO, "truncated BAM record");
             break;
@@ -144,8 +156,14 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
         delete w;
         return st;
     }
+    const auto t_walk = std::chrono::steady_clock::now();
     parallel_copy(w->raw.data(), r->in.buf.data() + r->in.bpos, at, r->threads);
     r->in.bpos += at;
+    if (dbg) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[plo] read_window: %zu records, %.1f MB: inflate (fill) %.3f s, record walk %.3f s, copy %.3f s\n", w->rec_at.size(), at / 1e6,
+                t_fill, std::chrono::duration<double>(t_walk - t_begin).count() - t_fill, std::chrono::duration<double>(t_end - t_walk).count());
+    }
     for (uint64_t u : unm_at) {
         const uint8_t *p = w->raw.data() + u;
         w->unmapped.insert(w->unmapped.end(), p, p + 4 + rd32(p));
@@ -864,6 +882,8 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
     std::vector<uint32_t> olen(nblk, 0);
     std::atomic<int> bad{0};
     uint8_t *outb = scratch.data();
+    const bool dbg = getenv("PLO_DEBUG_WRITER") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     parallel_ranges(nblk, threads, [&](size_t lo, size_t hi) {
         const LibDeflate &ld = libdeflate();
         void *lc = (level > 0 && ld.ok) ? ld.alloc_compressor(level) : nullptr;
@@ -914,6 +934,7 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
         else if (level > 0) deflateEnd(&zs);
     });
     if (bad) return fail(PLO_ERR_IO, "BGZF block compression failed");
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<uint64_t> at(nblk + 1, 0);
     for (size_t b = 0; b < nblk; ++b) at[b + 1] = at[b] + olen[b];
     if (seekable) {
@@ -955,6 +976,9 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
         }
     }
     file_off += at[nblk];
+    if (dbg)
+        fprintf(stderr, "[plo] bgzf write: %.1f MB in %zu blocks: build %.3f s, write %.3f s\n", n / 1e6, nblk, std::chrono::duration<double>(t1 - t0).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     return PLO_OK;
 }
 

@@ -576,25 +576,44 @@ struct BgzfBlk {
     unsigned long long coff, uoff;  // offsets of the block's deflate data / inflated bytes inside the chunk buffers
     uint32_t clen, ulen;
 };
-struct InfWave {  // the lanes of one wave run the decoder together (inflate.hpp)
+struct InfWave {  // wave primitives of the decoder's I/O policy (InfWaveIO, inflate.hpp)
     PLO_DEV int lane() const { return wv::lane(); }
-    PLO_DEV int width() const { return 64; }
-    PLO_DEV void sync() const {  // LDS tables and the wave's own global stores (match sources) are visible to all its lanes
+    PLO_DEV void sync() const {  // LDS windows / tables and the wave's own global stores (far match sources) are ordered for all its lanes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the write-backs of the ring have reached L2
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     PLO_DEV uint32_t uniform(uint32_t v) const { return wv::bcast_first(v); }
+    PLO_DEV uint32_t scalar(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    PLO_DEV long long clock() const { return wv::clock(); }
+    // a byte this wave wrote back earlier: read at device scope (L2), never from a line the CU's vector cache fetched while the
+    // line was still being filled
+    PLO_DEV uint8_t load_written(const uint8_t *p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+struct InfLds {
+    InfWork ws;
+    InfWaveMem io;
 };
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfBlk *blks, uint32_t n, uint8_t *out, int *status) {
-    __shared__ InfWork ws;
+    __shared__ InfLds lds;  // 15.9 KB: ten blocks in flight per CU
+    InfWaveIO<InfWave> io;
+    io.m = &lds.io;
     for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
         const BgzfBlk k = blks[b];
         uint32_t w = 0;
-        int rc = k.ulen ? inflate_block(InfWave{}, comp + k.coff, k.clen, out + k.uoff, k.ulen, ws, &w) : 0;
+#ifdef PLO_INF_TIMING
+        const long long tb = wv::clock();
+#endif
+        int rc = k.ulen ? inflate_block(io, comp + k.coff, k.clen, out + k.uoff, k.ulen, lds.ws, &w) : 0;
+#ifdef PLO_INF_TIMING
+        if (b == 7 && wv::lane() == 0)
+            printf("[inflate] block %u: %u -> %u bytes, %lld cycles: input chunks %d (%lld), write-backs %d (%lld), matches %d (%lld), far %d (%lld)\n", b, k.clen, k.ulen,
+                   wv::clock() - tb, io.n_load, io.t_load, io.n_flush, io.t_flush, io.n_match, io.t_match, io.n_far, io.t_far);
+#endif
         if (rc == 0 && w != k.ulen) rc = -9;  // the stream ended before ISIZE bytes
         if (wv::lane() == 0) status[b] = rc;
-        InfWave{}.sync();
+        io.sync();
     }
 }
 
@@ -1774,7 +1793,7 @@ int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void
     if (hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
     if (hipMemcpyAsync(d_blk.p, blks, (size_t)n * sizeof(BgzfBlk), hipMemcpyHostToDevice, st) != hipSuccess) return -102;
     if (dbg) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>(n, 256u * 16u)), dim3(64), 0, st, (const uint8_t *)d_comp.p, (const BgzfBlk *)d_blk.p, n,
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>(n, 256u * (uint32_t)std::min<size_t>(16, (160u << 10) / sizeof(InfLds)))), dim3(64), 0, st, (const uint8_t *)d_comp.p, (const BgzfBlk *)d_blk.p, n,
                        (uint8_t *)d_out.p, (int *)d_st.p);
     if (hipGetLastError() != hipSuccess) return -103;
     if (dbg) (void)hipEventRecord(ev[2], st);

@@ -1,14 +1,22 @@
 // inflate.hpp -- DEFLATE (RFC 1951) decoder for one BGZF block, written for ONE WAVEFRONT per block (k_bgzf_inflate,
 // engine.hip) and compiled for the host as well (tests, tests/emu).  A BGZF file is a series of independent deflate streams
 // of at most 64 KiB each, so a BAM of N GB is N x 16 k independent decode jobs: the host cores of a GPU node inflate
-// ~0.25 GB/s each, the device takes every block of a 256 MB chunk at once.
+// ~0.4 GB/s each, the device takes every block of a 256 MB chunk at once.
 //
 // Decoding a Huffman stream is sequential, so all lanes of the wave run the SAME decode on the same bits -- uniform control
-// flow, table look-ups that are LDS broadcasts -- and the wave spreads only the data movement: the primary look-up tables are
-// filled lane-strided, and a match of `len` bytes is copied by `len` lanes at once (byte k from position (k mod dist) of
-// the source period, which also covers overlapping matches).  Codes of up to 10 bits (nearly all) cost one table look-up;
-// longer ones fall back to canonical decoding by code length.  Input and output are bounds-checked: the decoder returns 0 or
-// a negative error code and never reads or writes outside [in, in + in_len) / [out, out + out_len).
+// flow, table look-ups that are LDS broadcasts -- and the wave spreads only the data movement.  What bounds such a decoder is
+// the latency of one symbol (look-up -> shift -> next look-up) times the number of blocks a CU can work on at once, which is
+// an LDS budget.  Hence the I/O policy of the wave (InfWaveIO):
+//   * the compressed bytes pass through a 2 KiB LDS window filled 1 KiB at a time with coalesced loads (first version: every
+//     refill of the bit buffer was a dependent global load);
+//   * the output goes to an 8 KiB LDS ring that is written back 4 KiB at a time with coalesced stores; matches whose source is
+//     still in the ring (distance <= 7 680) are LDS-to-LDS copies by up to 64 lanes at once; the rare far ones (read names and
+//     tags of the previous record) read the bytes this wave wrote back earlier from global memory (first version: every match
+//     did);
+//   * 16 KiB of LDS per block in all (tables 5.7 KiB): ten blocks in flight per CU.
+// Codes of up to 10 bits (nearly all) cost one table look-up; longer ones fall back to canonical decoding by code length.
+// Input and output are bounds-checked: the decoder returns 0 or a negative error code and never reads or writes outside
+// [in, in + in_len) / [out, out + out_len).
 #pragma once
 #include <stdint.h>
 
@@ -29,38 +37,217 @@ struct InfWork {
     uint16_t lcount[16], lsym[288];      // canonical tables (codes by length) for the slow path
     uint16_t dcount[16], dsym[32];
     uint16_t code[288];                  // canonical code of every symbol while a fast table is filled
+    uint16_t offs[16], next[16];         // running offsets / next codes by length while tables are built (indexed arrays in LDS:
+                                         // as locals they would be scratch, i.e. global memory)
     uint8_t lengths[320];
 };
 
-// host execution: one "lane"
+// ---- I/O policies ---------------------------------------------------------------------------------------------------------------
+// The decoder reads its input as aligned 32-bit words (in_word) and hands its output over as literals, matches and stored
+// runs; where those bytes live is the policy's business.
+//
+// host execution: one "lane", input and output used in place
 struct InfSerial {
+    const uint8_t *in = nullptr;
+    uint8_t *out = nullptr;
+    uint32_t in_len = 0;
     PLO_HD int lane() const { return 0; }
     PLO_HD int width() const { return 1; }
     PLO_HD void sync() const {}
     PLO_HD uint32_t uniform(uint32_t v) const { return v; }
+    PLO_HD uint32_t scalar(uint32_t v) const { return v; }
+    PLO_HD void pin() {}
+    PLO_HD void begin(const uint8_t *in_, uint32_t in_len_, uint8_t *out_, uint32_t) {
+        in = in_;
+        in_len = in_len_;
+        out = out_;
+    }
+    PLO_HD uint32_t in_word(uint32_t p) {  // bytes p .. p+3 of the input, little endian, zero beyond its end
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; ++k)
+            if (p + k < in_len) v |= (uint32_t)in[p + k] << (8 * k);
+        return v;
+    }
+    PLO_HD void put_literal(uint32_t pos, uint32_t v) { out[pos] = (uint8_t)v; }
+    PLO_HD void put_match(uint32_t pos, uint32_t dist, uint32_t len) {
+        for (uint32_t k = 0; k < len; ++k) out[pos + k] = out[pos + k - dist];
+    }
+    PLO_HD void put_stored(uint32_t pos, uint32_t in_pos, uint32_t len) {
+        for (uint32_t k = 0; k < len; ++k) out[pos + k] = in[in_pos + k];
+    }
+    PLO_HD void advance(uint32_t) {}
+    PLO_HD void end(uint32_t) {}
 };
 
-struct InfBits {
-    const uint8_t *in;
-    uint32_t in_len, in_pos;
-    unsigned long long buf;
-    int cnt;  // valid bits in buf; negative after reading past the end of the input
+// LDS of one wave's I/O (besides InfWork)
+#ifndef PLO_INF_RING
+#define PLO_INF_RING 8192
+#endif
+constexpr uint32_t INF_RING = PLO_INF_RING, INF_CHUNK = INF_RING / 2, INF_NEAR = INF_RING - 512;  // output ring, write-back unit, largest ring match
+constexpr uint32_t INF_IN_RING = 2048, INF_IN_CHUNK = 1024;
+struct InfWaveMem {
+    alignas(16) uint8_t iring[INF_IN_RING];
+    alignas(16) uint8_t oring[INF_RING];
 };
-PLO_HD void inf_refill(InfBits &s) {
-    while (s.cnt <= 56 && s.in_pos < s.in_len) {
-        s.buf |= (unsigned long long)s.in[s.in_pos++] << s.cnt;
-        s.cnt += 8;
+
+// One wave per block.  `Prim` supplies the wave primitives: lane(), sync() (LDS and the wave's own global stores ordered
+// for all its lanes), uniform(v) (value of the first lane), load_written(p) (a byte this wave stored to global memory earlier
+// and has waited for with sync(): must not come from a stale line of the CU's vector cache), and scalar(v): v is the same in
+// every lane and the device is told so (v_readfirstlane).  Everything the decoder computes from the words of the input and
+// the table entries is wave-uniform; with those two kinds of LDS reads marked scalar, the whole decode state lives in scalar
+// registers and runs on the scalar unit -- a lone wave issues a vector instruction every four cycles at best, and the
+// per-symbol path was ~150 of them (measured: 800 cycles per symbol before).
+template <class Prim>
+struct InfWaveIO {
+    Prim prim;
+    InfWaveMem *m = nullptr;
+    const uint8_t *in = nullptr;
+    uint8_t *out = nullptr;
+    uint32_t in_len = 0, in_hi = 0;  // input bytes [in_hi - INF_IN_RING, in_hi) are in the window (as far as they exist)
+    uint32_t flushed = 0;            // output bytes [0, flushed) are in global memory
+    uint32_t ring_from = 0;          // output bytes [ring_from, pos) are in the ring (unless older than INF_RING)
+#ifdef PLO_INF_TIMING
+    long long t_load = 0, t_flush = 0, t_match = 0, t_far = 0;
+    int n_load = 0, n_flush = 0, n_match = 0, n_far = 0;
+#define INF_T0 long long t0_ = prim.clock();
+#define INF_T1(acc, cnt) acc += prim.clock() - t0_; ++cnt;
+#else
+#define INF_T0
+#define INF_T1(acc, cnt)
+#endif
+
+    PLO_HD int lane() const { return prim.lane(); }
+    PLO_HD int width() const { return 64; }
+    PLO_HD void sync() const { prim.sync(); }
+    PLO_HD uint32_t uniform(uint32_t v) const { return prim.uniform(v); }
+    PLO_HD uint32_t scalar(uint32_t v) const { return prim.scalar(v); }
+    PLO_HD void pin() {  // (see inf_pin)
+        in_hi = prim.scalar(in_hi);
+        flushed = prim.scalar(flushed);
+        ring_from = prim.scalar(ring_from);
+    }
+    PLO_HD void begin(const uint8_t *in_, uint32_t in_len_, uint8_t *out_, uint32_t) {
+        in = in_;
+        in_len = in_len_;
+        out = out_;
+        in_hi = 0;
+        flushed = 0;
+        ring_from = 0;
+    }
+    PLO_HD void load_chunk() {  // the next INF_IN_CHUNK input bytes into the window: 16 coalesced byte loads per lane
+        INF_T0
+        const uint32_t l = (uint32_t)prim.lane();
+        prim.sync();  // (the lanes are done reading the half that is overwritten)
+        for (uint32_t j = 0; j < INF_IN_CHUNK / 64; ++j) {
+            const uint32_t p = in_hi + j * 64 + l;
+            m->iring[p & (INF_IN_RING - 1)] = p < in_len ? in[p] : (uint8_t)0;
+        }
+        in_hi += INF_IN_CHUNK;
+        prim.sync();
+        INF_T1(t_load, n_load)
+    }
+    PLO_HD uint32_t in_word(uint32_t p) {  // p is a multiple of 4 and never goes back by more than a word
+        if (p >= in_len) return 0;
+        if (p >= in_hi + INF_IN_CHUNK) in_hi = p & ~(INF_IN_CHUNK - 1);  // (a stored run was skipped: restart the window there)
+        while (in_hi < in_len && p + 512 > in_hi) load_chunk();
+        const uint32_t *r = (const uint32_t *)(m->iring + (p & (INF_IN_RING - 1)));  // (the window is 4-byte aligned, p a multiple of 4)
+        return prim.scalar(*r);
+    }
+    PLO_HD void put_literal(uint32_t pos, uint32_t v) {
+        if (prim.lane() == 0) m->oring[pos & (INF_RING - 1)] = (uint8_t)v;
+    }
+    // byte k of the match = byte (k mod dist) of the `dist` bytes before pos (an overlapping match repeats them): all sources
+    // are older than pos, so the lanes copy independently
+    PLO_HD void put_match(uint32_t pos, uint32_t dist, uint32_t len) {
+        const uint32_t l = (uint32_t)prim.lane();
+        const uint32_t src0 = pos - dist;
+        INF_T0
+        prim.sync();
+        if (dist <= INF_NEAR && src0 >= ring_from) {
+            for (uint32_t k = l; k < len; k += 64) m->oring[(pos + k) & (INF_RING - 1)] = m->oring[(src0 + (dist >= len ? k : k % dist)) & (INF_RING - 1)];
+        } else {
+            // (part of) the source has left the ring: it was written back at least INF_NEAR - INF_CHUNK - 258 bytes ago, or
+            // was never in the ring (a stored run); prim.sync() above has waited for those stores
+            for (uint32_t k = l; k < len; k += 64) {
+                const uint32_t sp = src0 + (dist >= len ? k : k % dist);
+                const bool near_ = sp >= ring_from && pos - sp <= INF_NEAR;
+                m->oring[(pos + k) & (INF_RING - 1)] = near_ ? m->oring[sp & (INF_RING - 1)] : prim.load_written(out + sp);
+            }
+            INF_T1(t_far, n_far)
+        }
+        prim.sync();
+        INF_T1(t_match, n_match)
+    }
+    PLO_HD void flush(uint32_t upto) {  // ring bytes [flushed, upto) -> global memory, 64 consecutive bytes per store instruction
+        INF_T0
+        const uint32_t l = (uint32_t)prim.lane();
+        prim.sync();
+        for (uint32_t k = flushed + l; k < upto; k += 64) out[k] = m->oring[k & (INF_RING - 1)];
+        flushed = upto;
+        INF_T1(t_flush, n_flush)
+    }
+    PLO_HD void put_stored(uint32_t pos, uint32_t in_pos, uint32_t len) {  // straight from the input to the output, past the ring
+        flush(pos);
+        const uint32_t l = (uint32_t)prim.lane();
+        for (uint32_t k = l; k < len; k += 64) out[pos + k] = in[in_pos + k];
+        flushed = pos + len;
+        ring_from = pos + len;
+    }
+    PLO_HD void advance(uint32_t pos) {  // after every symbol: write back the halves of the ring that are complete
+        const uint32_t b = pos & ~(INF_CHUNK - 1);
+        if (b > flushed) flush(b);
+    }
+    PLO_HD void end(uint32_t pos) {
+        if (pos > flushed) flush(pos);
+        prim.sync();
+    }
+};
+
+// ---- bit reader: 64-bit buffer refilled with aligned 32-bit words ---------------------------------------------------------------
+struct InfBits {
+    uint32_t in_len, ipos;  // ipos: byte position of the next word to fetch (a multiple of 4)
+    unsigned long long buf;
+    int cnt;  // valid bits in buf
+};
+template <class Par>
+PLO_HD void inf_refill(Par &par, InfBits &s) {  // at least 33 bits afterwards (zeros beyond the end of the input)
+    if (s.cnt <= 32) {
+        s.buf |= (unsigned long long)par.in_word(s.ipos) << s.cnt;
+        s.cnt += 32;
+        s.ipos += 4;
     }
 }
-PLO_HD uint32_t inf_take(InfBits &s, int n) {  // n <= 16; bits beyond the input read as zero and drive cnt negative
+PLO_HD uint32_t inf_take(InfBits &s, int n) {  // n <= 16
     uint32_t v = (uint32_t)(s.buf & ((1ull << n) - 1ull));
     s.buf >>= n;
     s.cnt -= n;
     return v;
 }
+PLO_HD bool inf_overrun(const InfBits &s) {  // more bits taken than the input has
+    return (long long)s.ipos * 8 - (long long)s.cnt > (long long)s.in_len * 8;
+}
+template <class Par>
+PLO_HD void inf_seek(Par &par, InfBits &s, uint32_t byte_pos) {  // continue reading at a byte position
+    s.ipos = byte_pos & ~3u;
+    s.buf = 0;
+    s.cnt = 0;
+    inf_refill(par, s);
+    inf_take(s, (int)(8 * (byte_pos & 3u)));
+    inf_refill(par, s);
+}
+
+// The decode state is the same in every lane; saying so once per symbol keeps it in scalar registers whatever the compiler can
+// prove about the paths in between (a no-op for values that are scalar already, and on the host)
+template <class Par>
+PLO_HD void inf_pin(const Par &par, InfBits &s, uint32_t &pos) {
+    s.buf = (unsigned long long)par.scalar((uint32_t)s.buf) | ((unsigned long long)par.scalar((uint32_t)(s.buf >> 32)) << 32);
+    s.cnt = (int)par.scalar((uint32_t)s.cnt);
+    s.ipos = par.scalar(s.ipos);
+    pos = par.scalar(pos);
+}
 
 // canonical tables from code lengths: returns 0 complete, > 0 incomplete, < 0 over-subscribed
-PLO_HD int inf_canonical(uint16_t *count, uint16_t *symbol, const uint8_t *length, int n) {
+PLO_HD int inf_canonical(uint16_t *count, uint16_t *symbol, const uint8_t *length, int n, uint16_t *offs /*[16] workspace*/) {
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[length[s]]++;
     if (count[0] == n) return 0;
@@ -70,7 +257,6 @@ PLO_HD int inf_canonical(uint16_t *count, uint16_t *symbol, const uint8_t *lengt
         left -= count[l];
         if (left < 0) return left;
     }
-    uint16_t offs[16];
     offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     for (int s = 0; s < n; ++s)
@@ -78,12 +264,13 @@ PLO_HD int inf_canonical(uint16_t *count, uint16_t *symbol, const uint8_t *lengt
     return left;
 }
 // slow path: one bit per step (codes longer than the fast table, and the code-length code)
-PLO_HD int inf_decode_slow(InfBits &s, const uint16_t *count, const uint16_t *symbol) {
+template <class Par>
+PLO_HD int inf_decode_slow(const Par &par, InfBits &s, const uint16_t *count, const uint16_t *symbol) {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= 15; ++len) {
         code |= (int)inf_take(s, 1);
-        int c = count[len];
-        if (code - c < first) return symbol[index + (code - first)];
+        int c = (int)par.scalar(count[len]);
+        if (code - c < first) return (int)par.scalar(symbol[index + (code - first)]);
         index += c;
         first += c;
         first <<= 1;
@@ -94,18 +281,18 @@ PLO_HD int inf_decode_slow(InfBits &s, const uint16_t *count, const uint16_t *sy
 // fills fast[] for the code given by length[0..n): every lane computes the canonical codes (uniform work), the table entries
 // are written lane-strided
 template <class Par>
-PLO_HD void inf_fill_fast(const Par &par, uint16_t *fast, uint16_t *code, const uint16_t *count, const uint8_t *length, int n) {
+PLO_HD void inf_fill_fast(const Par &par, uint16_t *fast, uint16_t *code, const uint16_t *count, const uint8_t *length, int n, uint16_t *next /*[16] workspace*/) {
     const int lane = par.lane(), width = par.width();
     for (int i = lane; i < (1 << INF_FAST_BITS); i += width) fast[i] = 0;
-    uint16_t next[16];  // first code of every length (RFC 1951, 3.2.2; count[0] counts the unused symbols and stays out)
-    int c = 0;
-    next[0] = 0;
-    for (int l = 1; l < 16; ++l) {
-        c = (c + (l > 1 ? count[l - 1] : 0)) << 1;
-        next[l] = (uint16_t)c;
-    }
-    if (lane == 0)
+    if (lane == 0) {  // first code of every length (RFC 1951, 3.2.2; count[0] counts the unused symbols and stays out)
+        int c = 0;
+        next[0] = 0;
+        for (int l = 1; l < 16; ++l) {
+            c = (c + (l > 1 ? count[l - 1] : 0)) << 1;
+            next[l] = (uint16_t)c;
+        }
         for (int s = 0; s < n; ++s) code[s] = length[s] ? next[length[s]]++ : 0;
+    }
     par.sync();
     for (int s = lane; s < n; s += width) {
         const int l = length[s];
@@ -119,43 +306,45 @@ PLO_HD void inf_fill_fast(const Par &par, uint16_t *fast, uint16_t *code, const 
 }
 
 template <class Par>
-PLO_HD int inflate_block(const Par &par, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, InfWork &ws, uint32_t *out_written) {
-    // length / distance code bases and extra bits (RFC 1951, 3.2.5)
-    const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    const uint8_t clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+PLO_HD int inflate_block(Par &par, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, InfWork &ws, uint32_t *out_written) {
+    // Length / distance code bases and extra bits (RFC 1951, 3.2.5) and the order of the code-length code lengths (3.2.7) are
+    // computed / unpacked from constants: as indexed arrays they would live in global memory, one dependent load (a microsecond)
+    // per look-up, four look-ups per match.
+    //   length symbol 257 + c: c < 8: 3 + c, no extra bits; else e = (c - 4) >> 2 extra bits, base 3 + ((4 + (c & 3)) << e); c = 28: 258
+    //   distance symbol d:     d < 4: 1 + d, no extra bits; else e = (d >> 1) - 1 extra bits, base 1 + ((2 + (d & 1)) << e)
+    // clorder = 16 17 18 0 8 7 9 6 10 5 11 4 | 12 3 13 2 14 1 15, five bits each
+    constexpr unsigned long long CLO_LO = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) | (6ull << 35) |
+                                          (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+    constexpr unsigned long long CLO_HI = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
     const int lane = par.lane(), width = par.width();
 
+    par.begin(in, in_len, out, out_len);
     InfBits s;
-    s.in = in;
     s.in_len = in_len;
-    s.in_pos = 0;
+    s.ipos = 0;
     s.buf = 0;
     s.cnt = 0;
     uint32_t pos = 0;
     int last;
     do {
-        inf_refill(s);
+        inf_refill(par, s);
         last = (int)inf_take(s, 1);
         const int type = (int)inf_take(s, 2);
-        if (s.cnt < 0) return INF_ERR_INPUT;
+        if (inf_overrun(s)) return INF_ERR_INPUT;
         if (type == 0) {  // stored: back to the byte boundary, LEN, NLEN, bytes
-            const uint32_t whole = (uint32_t)s.cnt >> 3;  // unread whole bytes sitting in the bit buffer
-            s.in_pos -= whole;
-            s.buf = 0;
-            s.cnt = 0;
-            if (s.in_pos + 4 > s.in_len) return INF_ERR_INPUT;
-            const uint32_t len = (uint32_t)in[s.in_pos] | ((uint32_t)in[s.in_pos + 1] << 8);
-            const uint32_t nlen = (uint32_t)in[s.in_pos + 2] | ((uint32_t)in[s.in_pos + 3] << 8);
-            s.in_pos += 4;
+            uint32_t bp = (uint32_t)(((long long)s.ipos * 8 - s.cnt + 7) >> 3);  // first whole byte not yet consumed
+            if ((unsigned long long)bp + 4 > in_len) return INF_ERR_INPUT;
+            inf_seek(par, s, bp);
+            const uint32_t len = inf_take(s, 16);
+            inf_refill(par, s);
+            const uint32_t nlen = inf_take(s, 16);
+            bp += 4;
             if ((len ^ 0xffffu) != nlen) return INF_ERR_STORED;
-            if (s.in_pos + len > s.in_len) return INF_ERR_INPUT;
-            if (pos + len > out_len) return INF_ERR_OUTPUT;
-            for (uint32_t k = (uint32_t)lane; k < len; k += (uint32_t)width) out[pos + k] = in[s.in_pos + k];
+            if ((unsigned long long)bp + len > in_len) return INF_ERR_INPUT;
+            if ((unsigned long long)pos + len > out_len) return INF_ERR_OUTPUT;
+            if (len) par.put_stored(pos, bp, len);
             pos += len;
-            s.in_pos += len;
+            inf_seek(par, s, bp + len);
             continue;
         }
         if (type == 3) return INF_ERR_BTYPE;
@@ -163,46 +352,44 @@ PLO_HD int inflate_block(const Par &par, const uint8_t *in, uint32_t in_len, uin
         if (type == 1) {  // fixed codes
             for (int sym = lane; sym < 288; sym += width) ws.lengths[sym] = (uint8_t)(sym < 144 ? 8 : (sym < 256 ? 9 : (sym < 280 ? 7 : 8)));
             par.sync();
-            if (lane == 0) inf_canonical(ws.lcount, ws.lsym, ws.lengths, 288);
+            if (lane == 0) inf_canonical(ws.lcount, ws.lsym, ws.lengths, 288, ws.offs);
             par.sync();
-            inf_fill_fast(par, ws.lfast, ws.code, ws.lcount, ws.lengths, 288);
+            inf_fill_fast(par, ws.lfast, ws.code, ws.lcount, ws.lengths, 288, ws.next);
             for (int sym = lane; sym < 30; sym += width) ws.lengths[sym] = 5;
             par.sync();
-            if (lane == 0) inf_canonical(ws.dcount, ws.dsym, ws.lengths, 30);
+            if (lane == 0) inf_canonical(ws.dcount, ws.dsym, ws.lengths, 30, ws.offs);
             par.sync();
-            inf_fill_fast(par, ws.dfast, ws.code, ws.dcount, ws.lengths, 30);
+            inf_fill_fast(par, ws.dfast, ws.code, ws.dcount, ws.lengths, 30, ws.next);
         } else {  // dynamic codes
             const int nlen = (int)inf_take(s, 5) + 257;
             const int ndist = (int)inf_take(s, 5) + 1;
             const int ncode = (int)inf_take(s, 4) + 4;
-            if (s.cnt < 0) return INF_ERR_INPUT;
+            if (inf_overrun(s)) return INF_ERR_INPUT;
             if (nlen > 286 || ndist > 30) return INF_ERR_TABLE;
             // every lane decodes the code lengths (uniform); lane 0 writes them
-            uint8_t cl[19];
-            for (int i = 0; i < 19; ++i) cl[i] = 0;
+            for (int i = lane; i < 19; i += width) ws.lengths[i] = 0;
+            par.sync();
             for (int i = 0; i < ncode; ++i) {
-                inf_refill(s);
-                cl[clorder[i]] = (uint8_t)inf_take(s, 3);
+                inf_refill(par, s);
+                const uint32_t v = inf_take(s, 3);
+                const int at = (int)(((i < 12 ? CLO_LO >> (5 * i) : CLO_HI >> (5 * (i - 12)))) & 31ull);
+                if (lane == 0) ws.lengths[at] = (uint8_t)v;
             }
-            if (s.cnt < 0) return INF_ERR_INPUT;
-            if (lane == 0)
-                for (int i = 0; i < 19; ++i) ws.lengths[i] = cl[i];
+            if (inf_overrun(s)) return INF_ERR_INPUT;
             par.sync();
             int err = 0;
-            if (lane == 0) err = inf_canonical(ws.lcount, ws.lsym, ws.lengths, 19);
+            if (lane == 0) err = inf_canonical(ws.lcount, ws.lsym, ws.lengths, 19, ws.offs);
             err = (int)par.uniform((uint32_t)err);
             par.sync();
             if (err != 0) return INF_ERR_TABLE;  // the code-length code must be complete
-            // the 19-symbol code is decoded bit by bit from a private copy of its tables (ws.lengths is about to be overwritten)
-            uint16_t ccount[16], csym[19];
-            for (int l = 0; l < 16; ++l) ccount[l] = ws.lcount[l];
-            for (int i = 0; i < 19; ++i) csym[i] = ws.lsym[i];
-            par.sync();
+            // the 19-symbol code is decoded bit by bit from ws.lcount / ws.lsym, which stay untouched until all lengths are read
+            // (ws.lengths is overwritten as they arrive)
+            const uint16_t *ccount = ws.lcount, *csym = ws.lsym;
             int idx = 0;
             while (idx < nlen + ndist) {
-                inf_refill(s);
-                int sym = inf_decode_slow(s, ccount, csym);
-                if (sym < 0) return s.cnt < 0 ? INF_ERR_INPUT : INF_ERR_SYMBOL;
+                inf_refill(par, s);
+                int sym = inf_decode_slow(par, s, ccount, csym);
+                if (sym < 0) return inf_overrun(s) ? INF_ERR_INPUT : INF_ERR_SYMBOL;
                 if (sym < 16) {
                     if (lane == 0) ws.lengths[idx] = (uint8_t)sym;
                     ++idx;
@@ -211,14 +398,14 @@ PLO_HD int inflate_block(const Par &par, const uint8_t *in, uint32_t in_len, uin
                     if (sym == 16) {
                         if (idx == 0) return INF_ERR_TABLE;
                         par.sync();
-                        len = ws.lengths[idx - 1];
+                        len = (int)par.scalar(ws.lengths[idx - 1]);
                         rep = 3 + (int)inf_take(s, 2);
                     } else if (sym == 17) {
                         rep = 3 + (int)inf_take(s, 3);
                     } else {
                         rep = 11 + (int)inf_take(s, 7);
                     }
-                    if (s.cnt < 0) return INF_ERR_INPUT;
+                    if (inf_overrun(s)) return INF_ERR_INPUT;
                     if (idx + rep > nlen + ndist) return INF_ERR_TABLE;
                     if (lane == 0)
                         for (int r = 0; r < rep; ++r) ws.lengths[idx + r] = (uint8_t)len;
@@ -229,66 +416,69 @@ PLO_HD int inflate_block(const Par &par, const uint8_t *in, uint32_t in_len, uin
             if (ws.lengths[256] == 0) return INF_ERR_TABLE;  // no end-of-block code
             int e1 = 0, e2 = 0;
             if (lane == 0) {
-                e1 = inf_canonical(ws.lcount, ws.lsym, ws.lengths, nlen);
+                e1 = inf_canonical(ws.lcount, ws.lsym, ws.lengths, nlen, ws.offs);
                 if (e1 > 0 && nlen == ws.lcount[0] + ws.lcount[1]) e1 = 0;  // incomplete only as a single one-bit code
-                e2 = inf_canonical(ws.dcount, ws.dsym, ws.lengths + nlen, ndist);
+                e2 = inf_canonical(ws.dcount, ws.dsym, ws.lengths + nlen, ndist, ws.offs);
                 if (e2 > 0 && ndist == ws.dcount[0] + ws.dcount[1]) e2 = 0;
             }
             e1 = (int)par.uniform((uint32_t)(e1 | e2));
             par.sync();
             if (e1 != 0) return INF_ERR_TABLE;
-            inf_fill_fast(par, ws.lfast, ws.code, ws.lcount, ws.lengths, nlen);
-            inf_fill_fast(par, ws.dfast, ws.code, ws.dcount, ws.lengths + nlen, ndist);
+            inf_fill_fast(par, ws.lfast, ws.code, ws.lcount, ws.lengths, nlen, ws.next);
+            inf_fill_fast(par, ws.dfast, ws.code, ws.dcount, ws.lengths + nlen, ndist, ws.next);
         }
         // literal / length + distance symbols until the end-of-block code
         for (;;) {
-            inf_refill(s);
+            inf_pin(par, s, pos);
+            par.pin();
+            inf_refill(par, s);
             int sym;
-            uint32_t e = ws.lfast[s.buf & ((1u << INF_FAST_BITS) - 1u)];
+            uint32_t e = par.scalar(ws.lfast[s.buf & ((1u << INF_FAST_BITS) - 1u)]);
             if (e) {
                 sym = (int)(e >> 4);
                 inf_take(s, (int)(e & 15u));
             } else {
-                sym = inf_decode_slow(s, ws.lcount, ws.lsym);
-                if (sym < 0) return s.cnt < 0 ? INF_ERR_INPUT : INF_ERR_SYMBOL;
+                sym = inf_decode_slow(par, s, ws.lcount, ws.lsym);
+                if (sym < 0) return inf_overrun(s) ? INF_ERR_INPUT : INF_ERR_SYMBOL;
             }
-            if (s.cnt < 0) return INF_ERR_INPUT;
             if (sym < 256) {
                 if (pos >= out_len) return INF_ERR_OUTPUT;
-                if (lane == 0) out[pos] = (uint8_t)sym;
+                par.put_literal(pos, (uint32_t)sym);
                 ++pos;
             } else if (sym == 256) {
+                if (inf_overrun(s)) return INF_ERR_INPUT;
                 break;
             } else {
                 sym -= 257;
                 if (sym >= 29) return INF_ERR_LENGTH;
-                const uint32_t len = lbase[sym] + inf_take(s, lext[sym]);
+                const int le = sym < 8 || sym == 28 ? 0 : (sym - 4) >> 2;
+                const uint32_t lb = sym < 8 ? 3u + (uint32_t)sym : (sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3u)) << le));
+                const uint32_t len = lb + inf_take(s, le);  // (at least 33 - 15 - 5 bits were left: no refill needed)
+                inf_refill(par, s);
                 int ds;
-                e = ws.dfast[s.buf & ((1u << INF_FAST_BITS) - 1u)];
+                e = par.scalar(ws.dfast[s.buf & ((1u << INF_FAST_BITS) - 1u)]);
                 if (e) {
                     ds = (int)(e >> 4);
                     inf_take(s, (int)(e & 15u));
                 } else {
-                    ds = inf_decode_slow(s, ws.dcount, ws.dsym);
-                    if (ds < 0) return s.cnt < 0 ? INF_ERR_INPUT : INF_ERR_SYMBOL;
+                    ds = inf_decode_slow(par, s, ws.dcount, ws.dsym);
+                    if (ds < 0) return inf_overrun(s) ? INF_ERR_INPUT : INF_ERR_SYMBOL;
                 }
                 if (ds >= 30) return INF_ERR_DISTANCE;
-                const uint32_t dist = dbase[ds] + inf_take(s, dext[ds]);
-                if (s.cnt < 0) return INF_ERR_INPUT;
+                const int de = ds < 4 ? 0 : (ds >> 1) - 1;
+                const uint32_t db = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << de);
+                const uint32_t dist = db + inf_take(s, de);
+                if (inf_overrun(s)) return INF_ERR_INPUT;
                 if (dist > pos) return INF_ERR_DISTANCE;
                 if (pos + len > out_len) return INF_ERR_OUTPUT;
-                // byte k of the match = byte (k mod dist) of the `dist` bytes before pos (an overlapping match repeats them)
-                par.sync();  // earlier stores of the wave are visible to its loads
-                if (width == 1) {
-                    for (uint32_t k = 0; k < len; ++k) out[pos + k] = out[pos + k - dist];
-                } else {
-                    for (uint32_t k = (uint32_t)lane; k < len; k += (uint32_t)width) out[pos + k] = out[pos - dist + (k % dist)];
-                    par.sync();
-                }
+                par.put_match(pos, dist, len);
                 pos += len;
             }
+            par.advance(pos);
         }
     } while (!last);
+    if (inf_overrun(s)) return INF_ERR_INPUT;
+    par.end(pos);
     if (out_written) *out_written = pos;
     return INF_OK;
 }

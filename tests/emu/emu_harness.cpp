@@ -450,25 +450,30 @@ extern "C" void emu_sa_free(uint32_t *off, uint8_t *text) {
 // the device's DEFLATE decoder (inflate.hpp) executed on the host: serially, and by the 64 lanes of an emulated wave
 extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *written) {
     plo::InfWork ws;
-    return plo::inflate_block(plo::InfSerial{}, in, in_len, out, out_len, ws, written);
+    plo::InfSerial io;
+    return plo::inflate_block(io, in, in_len, out, out_len, ws, written);
 }
 namespace {
 struct InfEmuWave {
     int lane() const { return wv::lane(); }
-    int width() const { return 64; }
     void sync() const { wv::sync(); }
     uint32_t uniform(uint32_t v) const { return (uint32_t)wv::bcast_first((int)v); }
+    uint32_t scalar(uint32_t v) const { return v; }
+    uint8_t load_written(const uint8_t *p) const { return *p; }
 };
 }  // namespace
 extern "C" int emu_inflate_wave(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *written, unsigned order_seed) {
     plo::InfWork ws;
+    plo::InfWaveMem mem;  // the wave's LDS windows
     int rc_all[64];
     uint32_t w_all[64];
     wv::EmuWave w;
     w.order_seed = order_seed;
     w.run([&]() {
         uint32_t wr = 0;
-        int rc = plo::inflate_block(InfEmuWave{}, in, in_len, out, out_len, ws, &wr);
+        plo::InfWaveIO<InfEmuWave> io;  // per lane, like the registers of the device code
+        io.m = &mem;
+        int rc = plo::inflate_block(io, in, in_len, out, out_len, ws, &wr);
         rc_all[wv::lane()] = rc;
         w_all[wv::lane()] = wr;
     });

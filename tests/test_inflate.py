@@ -91,3 +91,51 @@ def test_wave_cooperative_decode_against_zlib(level, strategy):
     c = zlib.compressobj(6, zlib.DEFLATED, -15)
     comp = c.compress(q * 3) + c.flush()
     assert _inflate(comp[: len(comp) // 2], len(q) * 3, wave=True)[0] < 0
+
+
+def _big_payloads():
+    """block-sized inputs that make the wave's LDS windows wrap: the 8 KiB output ring (write-back in 4 KiB halves), matches
+    nearer and farther than the ring holds, stored runs that bypass the ring and are matched into afterwards"""
+    rng = np.random.default_rng(17)
+    text = (b"@read/%d/ccs\tACGTTGCA\tRG:Z:x\tnp:i:12\n" * 40)
+    rnd = rng.integers(0, 256, 21000, dtype=np.uint8).tobytes()          # incompressible: zlib emits stored blocks for it
+    qual = bytes(rng.choice(np.arange(33, 74, dtype=np.uint8), 15000))
+    # far repeats: 9 000, 20 000 and 31 000 bytes back; near ones; an overlapping run
+    a = text + qual + rnd[:9000] + text + b"A" * 700 + qual[:4000] + rnd[:3000] + qual[5000:9000] + text
+    yield a[:65280]
+    yield rnd + rnd[100:8000] + b"xyz" * 50 + rnd[20000:] + rnd[:500]   # matches into (and across the end of) stored runs
+    yield (bytes(rng.integers(0, 4, 65280, dtype=np.uint8) + 65))        # 2 bits of entropy per byte: long Huffman-only stretches
+    yield rng.integers(0, 256, 65280, dtype=np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_wave_decode_of_full_blocks(level):
+    for data in _big_payloads():
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        rc, out = _inflate(comp, len(data), wave=True)
+        assert rc == 0 and out == data, (level, len(data), rc)
+        rc, out = _inflate(comp, len(data))
+        assert rc == 0 and out == data
+        # a sync flush in the middle: an empty stored block between two dynamic ones
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(data[:30000]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(data[30000:]) + c.flush()
+        rc, out = _inflate(comp, len(data), wave=True)
+        assert rc == 0 and out == data
+
+
+def test_wave_decode_rejects_truncated_and_damaged_blocks():
+    rng = np.random.default_rng(23)
+    data = next(_big_payloads())
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    assert _inflate(comp[:len(comp) * 2 // 3], len(data), wave=True)[0] < 0
+    assert _inflate(comp, len(data) - 5000, wave=True)[0] < 0
+    bad = 0
+    for k in range(12):
+        b = bytearray(comp)
+        i = int(rng.integers(0, len(b)))
+        b[i] ^= 1 << int(rng.integers(0, 8))
+        rc, out = _inflate(bytes(b), len(data), wave=True)
+        bad += rc < 0 or out != data
+    assert bad >= 10
