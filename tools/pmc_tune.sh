@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: tools/pmc_tune.sh "<counters>" <kernel regex> [tune.py args...] -- one rocprofv3 PMC pass over tools/tune.py (stage subsets,
+# other workloads); prints the per-launch mean of every counter.  GPU box only.
+set -u
+export TMPDIR=/tmp
+ctrs="$1"; rx="$2"; shift; shift
+d=$(mktemp -d /tmp/pmc.XXXXXX)
+timeout 200 rocprofv3 --pmc $ctrs --kernel-include-regex "$rx" --output-format csv -d "$d" -- python3 tools/tune.py "$@" > /dev/null 2>&1
+python3 - "$d" <<'PY'
+import csv, glob, collections, sys
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    acc = collections.defaultdict(float); n = collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    for k in sorted(acc):
+        print(f"{k},{acc[k] / n[k]:.1f},{n[k]}")
+PY
+rm -rf "$d"
