@@ -280,6 +280,16 @@ extern "C" plo_status plo_sparse_seq_pack(const plo_batch_in *dense, uint32_t ma
     std::vector<uint32_t> first;
     if (!read_seg_ranges(n, dense->n_segs, dense->seg_read, first))
         return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: seg_read must be non-decreasing and below n_reads");
+    if (n && (!dense->read_seq_len || !dense->read_seq_off || !dense->read_is_reverse || !dense->seq))
+        return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: NULL read array");
+    if (dense->n_segs && (!dense->seg_is_fwd_strand || !dense->seg_cigar_off || !dense->cigar))
+        return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: NULL segment array");
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t nb = ((uint64_t)dense->read_seq_len[i] + 1) / 2, off = dense->read_seq_off[i];
+        if (off > dense->seq_bytes || nb > dense->seq_bytes - off) return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: a read's bases lie outside `seq`");
+    }
+    for (uint32_t s = 0; s < dense->n_segs; ++s)
+        if (dense->seg_cigar_off[s + 1] < dense->seg_cigar_off[s]) return fail(PLO_ERR_INVALID_ARG, "plo_sparse_seq_pack: seg_cigar_off is not monotonic");
     std::vector<uint64_t> woff((size_t)n + 1, 0), boff((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; ++i) woff[i + 1] = woff[i] + sparse_words(dense->read_seq_len[i]);
     std::vector<uint32_t> masks(woff[n] + 1);

@@ -89,6 +89,16 @@ def test_packer_rejects_unordered_segments():
             bam.sparse_pack(bad, 32)
 
 
+def test_packer_rejects_bases_outside_the_buffer():
+    from portello_amd import api
+    w = workload(10, seed=4)
+    b = w.batch_data()
+    off = b.read_seq_off.copy()
+    off[-1] = b.seq.nbytes - 3
+    with pytest.raises(api.PortelloError):
+        bam.sparse_pack(dataclasses.replace(b, read_seq_off=off), 32)
+
+
 @pytest.mark.parametrize("margin,allow_miss", [(0, True), (32, True), (1 << 20, False)])
 def test_emulated_device_algorithm_on_sparse_bases(oracle, margin, allow_miss):
     w = workload(150, seed=7)
