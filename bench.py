@@ -341,14 +341,91 @@ def main():
             dt = float(t.item())
         return dt
 
-    run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
-    dt = timed(lambda n: run_steps(n, True), args.steps)
-    if dist is not None:
+    def make_result(dt_, gather_desc):
+        tm = eng.timing()
+        kms = {"k_lift_mid": float(np.mean(times["mid"])), "k_lift_tiles": float(np.mean(times["lift"])), "k_lift_big": float(np.mean(times["big"])),
+               "k_lift_retry": float(np.mean(times["retry"]))}
+        dominant = max(kms, key=kms.get)
+        dom_ms = kms[dominant]
+        # the name rocprofv3 lists it under: the tile kernel of batches without heavy items has its slice capacity compiled in
+        dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
+        # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
+        # attribute them to the dominant kernel in proportion to its share of the lift time
+        share = dom_ms / max(1e-9, sum(kms.values()))
+        achieved = (tm.algo_bytes * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                tr = json.load(open(prof))
+                traffic = tr.get(cfg.name, {}).get(dom_name, tr.get(cfg.name, {}).get(dominant))
+            except Exception:
+                traffic = None
+
+        result = {
+            "metric": "lifted HiFi reads/sec (whole node)",
+            "value": total_reads * args.steps / dt_,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_ / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": cfg.name, "reads_total": int(total_reads), "reads_this_rank": my_reads, "read_len_mean": cfg.read_len_mean,
+                       "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
+                       "large_items_per_gpu": int(tm.n_big_items), "mid_items_per_gpu": int(tm.n_mid_items),
+                       "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4",
+                       "tile_geometry": {"slice_elements": int(tm.tile_cap), "window": int(tm.tile_window)},
+                       "parallelism": (f"one read set, 20 Mb windows dealt to {world} ranks by input ops" if strong else f"{world} independent read sets"),
+                       "host_workers_per_gpu": n_workers,
+                       "gather": gather_desc},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
+                         "enumerate_ms": float(np.mean(times["enum"])), "lift_tiles_ms": kms["k_lift_tiles"],
+                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"]},
+        }
+        return result
+
+    dt_ng = None
+    if dist is None:
+        run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
+        dt = timed(lambda n: run_steps(n, True), args.steps)
+        total_reads = float(my_reads)
+        result = make_result(dt, "none")
+    else:
         nr = torch.tensor([my_reads], dtype=torch.float64, device=dev)
         dist.all_reduce(nr, op=dist.ReduceOp.SUM)
         total_reads = float(nr.item())
-    else:
-        total_reads = float(my_reads)
+        # First the same K steps without the record gather (no collective on the data path): a complete measurement that rank 0 can
+        # print whatever happens to the exchange afterwards.  Then the headline: every step's records gathered on rank 0.
+        run_steps(max(args.warmup, n_workers), False, gather=False)
+        dt_ng = timed(lambda n: run_steps(n, True, gather=False), args.steps)
+        fallback = make_result(dt_ng, "none: the record gather to rank 0 did not complete in this run (see stderr); every rank keeps its shard")
+
+        def gather_bail():
+            log("[bench] the record gather over RCCL did not finish in time: printing the measurement without it")
+            if rank == 0:
+                print(json.dumps(fallback), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "300")), gather_bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            run_steps(max(args.warmup, n_workers), False)
+            for v_ in times.values():
+                v_.clear()
+            dt = timed(lambda n: run_steps(n, True), args.steps)
+            result = make_result(dt, "rccl send/recv to rank 0")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] the record gather over RCCL failed: {e!r}; the headline is the measurement without it")
+            result = fallback
+        wd.cancel()
 
     overlap = None
     if dist is None and n_workers == 1 and args.overlap_workers > 1:
@@ -376,53 +453,6 @@ def main():
         for e in o_engs:
             e.close()
 
-    tm = eng.timing()
-    kms = {"k_lift_mid": float(np.mean(times["mid"])), "k_lift_tiles": float(np.mean(times["lift"])), "k_lift_big": float(np.mean(times["big"])),
-           "k_lift_retry": float(np.mean(times["retry"]))}
-    dominant = max(kms, key=kms.get)
-    dom_ms = kms[dominant]
-    # the name rocprofv3 lists it under: the tile kernel of batches without heavy items has its slice capacity compiled in
-    dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
-    # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
-    # attribute them to the dominant kernel in proportion to its share of the lift time
-    share = dom_ms / max(1e-9, sum(kms.values()))
-    achieved = (tm.algo_bytes * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof):
-        try:
-            tr = json.load(open(prof))
-            traffic = tr.get(cfg.name, {}).get(dom_name, tr.get(cfg.name, {}).get(dominant))
-        except Exception:
-            traffic = None
-
-    result = {
-        "metric": "lifted HiFi reads/sec (whole node)",
-        "value": total_reads * args.steps / dt,
-        "unit": "reads/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
-        "vs_baseline": None,
-        "dtype": "int32",
-        "data": "synthetic",
-        "config": {"workload": cfg.name, "reads_total": int(total_reads), "reads_this_rank": my_reads, "read_len_mean": cfg.read_len_mean,
-                   "items_per_gpu": int(tm.n_items), "in_ops_per_gpu": int(tm.n_in_ops), "out_ops_per_gpu": int(tm.n_out_ops),
-                   "large_items_per_gpu": int(tm.n_big_items), "mid_items_per_gpu": int(tm.n_mid_items),
-                   "retry_items_per_gpu": int(tm.n_retry_items), "seq_fmt": "bam4",
-                   "tile_geometry": {"slice_elements": int(tm.tile_cap), "window": int(tm.tile_window)},
-                   "parallelism": (f"one read set, 20 Mb windows dealt to {world} ranks by input ops" if strong else f"{world} independent read sets"),
-                   "host_workers_per_gpu": n_workers,
-                   "gather": "rccl send/recv to rank 0" if dist is not None else "none"},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
-                     "enumerate_ms": float(np.mean(times["enum"])), "lift_tiles_ms": kms["k_lift_tiles"],
-                     "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"]},
-    }
     # Everything from here on is supplementary.  At N > 1 it runs more collectives (gather variants, verification): if any of that
     # does not finish, every rank gives up after a while and rank 0 still prints the headline measurement made above.
     watchdog = None
@@ -441,7 +471,6 @@ def main():
         no_gather = async_gather = verify = None
         # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
         if dist is not None:
-            dt_ng = timed(lambda n: run_steps(n, False, gather=False), args.steps)
             no_gather = {"value": total_reads * args.steps / dt_ng, "unit": "reads/s", "ms_per_step": dt_ng / args.steps * 1e3,
                          "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
             if n_workers == 1:
