@@ -392,6 +392,7 @@ def main():
         return result
 
     dt_ng = None
+    gather_modes = None
     if dist is None:
         run_steps(max(args.warmup, n_workers), False)  # every context sizes its buffers outside the timed region
         dt = timed(lambda n: run_steps(n, True), args.steps)
@@ -407,25 +408,82 @@ def main():
         dt_ng = timed(lambda n: run_steps(n, True, gather=False), args.steps)
         fallback = make_result(dt_ng, "none: the record gather to rank 0 did not complete in this run (see stderr); every rank keeps its shard")
 
+        pending_print = [fallback]  # what rank 0 prints if the next RCCL section does not come back
+
         def gather_bail():
-            log("[bench] the record gather over RCCL did not finish in time: printing the measurement without it")
+            log("[bench] an RCCL record gather did not finish in time: printing the last complete measurement")
             if rank == 0:
-                print(json.dumps(fallback), flush=True)
+                print(json.dumps(pending_print[0]), flush=True)
             os._exit(0)
 
-        wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "300")), gather_bail)
-        wd.daemon = True
-        wd.start()
-        try:
+        def guarded(fn):
+            wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "150")), gather_bail)
+            wd.daemon = True
+            wd.start()
+            try:
+                return fn()
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] RCCL record gather failed: {e!r}")
+                return None
+            finally:
+                wd.cancel()
+
+        # (a) every step's records gathered on rank 0 before the next step starts
+        def sync_run():
             run_steps(max(args.warmup, n_workers), False)
-            for v_ in times.values():
-                v_.clear()
-            dt = timed(lambda n: run_steps(n, True), args.steps)
-            result = make_result(dt, "rccl send/recv to rank 0")
-        except Exception as e:  # noqa: BLE001
-            log(f"[bench] the record gather over RCCL failed: {e!r}; the headline is the measurement without it")
-            result = fallback
-        wd.cancel()
+            return timed(lambda n: run_steps(n, False), args.steps)
+
+        dt_sync = guarded(sync_run)
+        result = fallback
+        if dt_sync is not None:
+            result = make_result(dt_sync, "rccl send/recv to rank 0 after every step")
+            pending_print[0] = result
+        # (b) the gather of batch i overlapped with the compute of batch i+1: two contexts alternate, so that the exchange reads one
+        # context's buffers while the other computes.  Both the posting and the wait happen under the owning engine's stream: RCCL
+        # starts the sends behind the compaction kernel, and the engine's next kernels start behind the sends that read its buffers.
+        dt_async = None
+        if n_workers == 1 and dt_sync is not None:
+            def async_run():
+                s2 = torch.cuda.Stream(device=dev)
+                a_streams = [streams[0], s2]
+                a_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
+                a_engs[1].liftover_batch_dev(desc)  # sizes its buffers
+                a_engs[1].sync()
+
+                def run_async(n_steps):
+                    pending = [None, None]
+                    for i in range(n_steps):
+                        k = i & 1
+                        if pending[k] is not None:
+                            with torch.cuda.stream(a_streams[k]):
+                                pending[k].wait()
+                            pending[k] = None
+                        out_k = a_engs[k].liftover_batch_dev(desc)
+                        a_engs[k].compact_output_dev(out_k)
+                        with torch.cuda.stream(a_streams[k]):
+                            pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
+                    for k, p_ in enumerate(pending):
+                        if p_ is not None:
+                            with torch.cuda.stream(a_streams[k]):
+                                p_.wait()
+
+                run_async(2)
+                d_ = timed(run_async, args.steps)
+                a_engs[1].close()
+                engs[0].liftover_batch_dev(desc)  # (this rank's own result back in the first context)
+                engs[0].sync()
+                return d_
+
+            dt_async = guarded(async_run)
+        gather_modes = {}  # reads/s of the whole job with the records of every step on rank 0 when the clock stops
+        if dt_sync is not None:
+            gather_modes["after_every_step"] = {"value": total_reads * args.steps / dt_sync, "unit": "reads/s", "ms_per_step": dt_sync / args.steps * 1e3}
+        if dt_async is not None:
+            gather_modes["overlapped_with_next_step"] = {"value": total_reads * args.steps / dt_async, "unit": "reads/s",
+                                                         "ms_per_step": dt_async / args.steps * 1e3}
+            if dt_async < dt_sync:  # the headline is the faster complete pipeline: K steps, all K record sets on rank 0 when the clock stops
+                result = make_result(dt_async, "rccl send/recv to rank 0, the exchange of batch i overlapped with the compute of batch i+1 "
+                                               "(two contexts alternate)")
 
     overlap = None
     if dist is None and n_workers == 1 and args.overlap_workers > 1:
@@ -468,43 +526,11 @@ def main():
         watchdog.daemon = True
         watchdog.start()
     try:
-        no_gather = async_gather = verify = None
+        no_gather = verify = None
         # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
         if dist is not None:
             no_gather = {"value": total_reads * args.steps / dt_ng, "unit": "reads/s", "ms_per_step": dt_ng / args.steps * 1e3,
                          "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
-            if n_workers == 1:
-                # the exchange of batch i stays in flight while batch i+1 is computed into a second context's buffers.  Both the
-                # posting and the wait happen under the owning engine's stream: RCCL then starts the sends behind the compaction
-                # kernel, and the engine's next kernels start behind the sends that still read its buffers.
-                s2 = torch.cuda.Stream(device=dev)
-                a_streams = [streams[0], s2]
-                a_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
-                a_engs[1].liftover_batch_dev(desc)  # sizes its buffers
-                a_engs[1].sync()
-
-                def run_async(n_steps):
-                    pending = [None, None]
-                    for i in range(n_steps):
-                        k = i & 1
-                        if pending[k] is not None:
-                            with torch.cuda.stream(a_streams[k]):
-                                pending[k].wait()
-                            pending[k] = None
-                        out_k = a_engs[k].liftover_batch_dev(desc)
-                        a_engs[k].compact_output_dev(out_k)
-                        with torch.cuda.stream(a_streams[k]):
-                            pending[k] = plo_gather.gather_results_async(out_k, dev, dist, rank, world)
-                    for k, p_ in enumerate(pending):
-                        if p_ is not None:
-                            with torch.cuda.stream(a_streams[k]):
-                                p_.wait()
-
-                run_async(2)
-                dt_a = timed(run_async, args.steps)
-                async_gather = {"value": total_reads * args.steps / dt_a, "unit": "reads/s", "ms_per_step": dt_a / args.steps * 1e3,
-                                "note": "record gather of batch i overlapped with the compute of batch i+1 (two contexts alternate)"}
-                a_engs[1].close()
             # one more synchronous step whose gathered records rank 0 compares with its own result of the WHOLE read set
             step(0)
             torch.cuda.synchronize()
@@ -529,7 +555,7 @@ def main():
         log(f"[bench] supplementary distributed measurements failed: {e!r}")
     if watchdog is not None:
         watchdog.cancel()
-    for name, obj in (("shard", shard_info), ("overlap", overlap), ("no_gather", no_gather), ("async_gather", async_gather),
+    for name, obj in (("shard", shard_info), ("overlap", overlap), ("no_gather", no_gather), ("gather_modes", gather_modes),
                       ("verify", verify)):
         if obj is not None:
             result[name] = obj
