@@ -149,6 +149,35 @@ def test_emulated_workgroup_per_item_on_sparse_bases(oracle):
             assert n_miss == 0
 
 
+def test_sparse_window_batch_equals_packing_the_dense_window_batch(tmp_path):
+    """plo_bam_window_batch_sparse (granules straight from the BAM records) == plo_sparse_seq_pack of the window's dense batch;
+    seq_full / read_seq_full_off point at the records' own packed bases"""
+    import ctypes as C
+    from portello_amd import bamsynth
+    w = workload(300, seed=9)
+    path = str(tmp_path / "reads.bam")
+    bamsynth.write_read_bam(w, path, 0, w.n_reads, level=1, n_threads=2)
+    rd = bam.BamReader(path, 2)
+    try:
+        win = rd.read_window(100000)
+        dense = win.batch_data()
+        want = bam.sparse_pack(dense, 32, n_threads=2)
+        d = win.batch_desc(sparse_margin=32)
+        n = int(d.n_reads)
+        assert int(d.seq_fmt) == abi.SEQ_BAM4_SPARSE and n == dense.n_reads and int(d.seq_bytes) == want.seq.nbytes
+        got_seq = np.ctypeslib.as_array(d.seq, shape=(int(d.seq_bytes),))
+        got_off = np.ctypeslib.as_array(d.read_seq_off, shape=(n,))
+        assert (got_off == want.read_seq_off).all() and (got_seq == want.seq).all()
+        full_off = np.ctypeslib.as_array(d.read_seq_full_off, shape=(n,))
+        for r in (0, n // 2, n - 1):
+            nb = (int(dense.read_seq_len[r]) + 1) // 2
+            full = np.ctypeslib.as_array(C.cast(C.addressof(d.seq_full.contents) + int(full_off[r]), C.POINTER(C.c_uint8)), shape=(nb,))
+            assert (full == dense.seq[int(dense.read_seq_off[r]):int(dense.read_seq_off[r]) + nb]).all()
+        win.close()
+    finally:
+        rd.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("margin", [0, 32])
