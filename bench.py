@@ -209,10 +209,11 @@ def main():
                          "rayon worker); batches are dealt to them in turn, so one worker's enumerate pass and host syncs overlap the "
                          "other's tile kernel.  Default 1: the HIP-event kernel times of the roofline object then measure execution "
                          "only (with several streams they include the wait behind the other stream's kernel)")
-    ap.add_argument("--overlap-workers", type=int, default=0,
-                    help="after the timed region, repeat the same K steps with this many workers and report the rate as the "
-                         "supplementary object `overlap` (N = 1 only; 0/1 = skip, the default: the extra launches would enter a "
-                         "rocprofv3 kernel summary of the same command with their longer, overlapped durations)")
+    ap.add_argument("--overlap-workers", type=int, default=int(os.environ.get("PLO_BENCH_OVERLAP_WORKERS", "2")),
+                    help="after the timed region, repeat the same K steps with this many host workers (one context + HIP stream each, the "
+                         "arrangement INTEGRATION.md recommends) and report the rate as the supplementary object `overlap` (N = 1 only; "
+                         "0/1 = skip: traced runs -- tools/profile_round.sh -- skip it, its launches would enter a rocprofv3 kernel summary "
+                         "with their longer, overlapped durations)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -16,7 +16,7 @@ hdr, body = rows[0], rows[1:]
 tot = sum(int(r[2]) for r in body)
 eng = [r for r in body if r[0].startswith("k_")]
 with open(f"{pre}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --e2e-reads 0   (default workload wgs30x, 10 steps + 2 warm-up)\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0   (default workload wgs30x, 10 steps + 2 warm-up)\n")
     f.write(f"# rows of the engine kernels only (the other {len(body) - len(eng)} rows are torch kernels of the synthetic generator); total traced kernel time {tot} ns\n")
     w = csv.writer(f)
     w.writerow(hdr)
