@@ -737,6 +737,11 @@ struct plo_ctx {
         i_item_seg, i_item_cseg;
     HostBuf h_item_seg, h_item_cseg, h_status, h_flip, h_mapq, h_chrom, h_pos, h_coff, h_clen, h_cigar, h_counters, h_miss, h_side;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // plo_liftover_batch uploads the read bases on a stream of their own: the enumerate pass does not look at them, so that copy
+    // (most of the batch's bytes) runs under it; the first lift kernel waits for ev_seq
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_seq = nullptr;
+    bool seq_pending = false;
     bool ev_big = false, ev_mid = false;
     uint64_t dense_total = 0;
     plo_timing timing{};
@@ -1014,6 +1019,8 @@ void plo_ctx_destroy(plo_ctx *c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 5; ++i)
         if (c->fev[i]) (void)hipEventDestroy(c->fev[i]);
+    if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1331,6 +1338,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     size_t want_cigar = (size_t)all_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS;
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
+    if (c->seq_pending) {  // (plo_liftover_batch: the read bases arrive on the copy stream)
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_seq, 0));
+        c->seq_pending = false;
+    }
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
     uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0, n_miss = 0;
     float miss_ms = 0.f;
@@ -1887,7 +1898,6 @@ plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stage
     UP(c->i_read_rev, in->read_is_reverse, (size_t)nr);
     UP(c->i_read_len, in->read_seq_len, (size_t)nr * 4);
     UP(c->i_read_off, in->read_seq_off, (size_t)nr * 8);
-    UP(c->i_seq, in->seq, (size_t)in->seq_bytes);
     UP(c->i_seg_read, in->seg_read, (size_t)ns * 4);
     UP(c->i_seg_contig, in->seg_contig, (size_t)ns * 4);
     UP(c->i_seg_pos, in->seg_pos, (size_t)ns * 8);
@@ -1899,6 +1909,16 @@ plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stage
         HIP_TRY(c, hipMemsetAsync(c->i_seg_coff.p, 0, 4, st));
     }
     UP(c->i_cigar, in->cigar, (size_t)n_cigar * 4);
+    {   // the bases last, on the copy stream (the buffers are idle: the previous call on this context has been waited for)
+        if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->ev_seq) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_seq, hipEventDisableTiming));
+        HIP_TRY(c, c->i_seq.ensure(std::max<size_t>((size_t)in->seq_bytes, 16)));
+        if (in->seq_bytes) {
+            HIP_TRY(c, hipMemcpyAsync(c->i_seq.p, in->seq, (size_t)in->seq_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(c->ev_seq, c->copy_stream));
+            c->seq_pending = true;
+        }
+    }
     plo_batch_in din = *in;
     din.read_is_reverse = c->i_read_rev.as<uint8_t>();
     din.read_seq_len = c->i_read_len.as<uint32_t>();
@@ -1919,6 +1939,10 @@ plo_status plo_liftover_batch(plo_ctx *c, const plo_batch_in *in, uint32_t stage
 #undef UP
     plo_batch_out dout;
     plo_status s = plo_liftover_batch_dev(c, &din, stages, &dout);
+    if (c->seq_pending) {  // no lift kernel waited for the bases (an error, or a batch without items): the caller's buffer is still being read
+        (void)hipStreamSynchronize(c->copy_stream);
+        c->seq_pending = false;
+    }
     if (s != PLO_OK) return s;
     s = plo_compact_output_dev(c, &dout);  // no slab gaps over the bus
     if (s != PLO_OK) return s;
