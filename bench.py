@@ -172,8 +172,32 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
 
             dense = run(None)
             sparse = run(32)
+            # two callers, one context each (the arrangement of INTEGRATION.md): one's transfers run under the other's kernels
+            two = None
+            try:
+                import threading as _th
+                desc2 = win.batch_desc(sparse_margin=32)  # (the window's arrays as the last run(32) left them)
+                eng2 = api.Engine(index)
+                eng2.liftover_batch_host(desc2)
+                reps2 = 6
+                def _loop(e_):
+                    for _ in range(reps2):
+                        e_.liftover_batch_host(desc2)
+                ths = [_th.Thread(target=_loop, args=(e_,)) for e_ in (eng, eng2)]
+                t0 = time.perf_counter()
+                for t_ in ths:
+                    t_.start()
+                for t_ in ths:
+                    t_.join()
+                dt2 = time.perf_counter() - t0
+                two = {"value": 2 * reps2 * win.n_records / dt2, "unit": "reads/s", "ms_per_call_per_worker": dt2 / reps2 * 1e3,
+                       "note": "the host-buffer path is bound by the one PCIe link and the runtime's copy queue, which two callers share: a "
+                               "second context does not add throughput here (it does for device-resident batches: `overlap`)"}
+                eng2.close()
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] two-worker host-buffer measurement failed: {e!r}")
             pcie = dict(sparse)
-            pcie.update({"reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel)",
+            pcie.update({"two_workers": two, "reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel)",
                          "dense_bases": dense,
                          "note": "plo_liftover_batch on page-locked host arrays, one context, synchronous: H2D of read bases + CIGARs, kernels, "
                                  "second look at items whose comparisons left the granules sent, D2H of the dense result.  batch_build_ms = "
