@@ -4,7 +4,7 @@ segment selection (a8), strand glue (a9), record finishing and SA text -- comput
 oracle/pyrecords.py (written from the Rust, independently of the C oracle and of the engine).  Both the C oracle
 (tests, CPU) and the HIP engine (tests, -m gpu) are then checked against these vectors.  Run in the build container:
 
-    python tools/make_glue_fixtures.py
+    python tests/make_glue_fixtures.py
 
 Inputs are seeded synthetic workloads, stored in the fixture in compact form; the lifted alignments that record finishing
 starts from are part of the fixture's INPUT (they come from the C oracle's liftover, whose own parity is pinned by the

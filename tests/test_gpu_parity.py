@@ -292,7 +292,7 @@ def test_full_size_stress(oracle):
 
 def test_geometry_sweep(oracle):
     """every item of five workloads with different contig block-map densities / strand mixes (hence different per-batch tile
-    geometries, retry and large-item traffic) against the oracle (tools/soak.py at a size that finishes in a minute)"""
+    geometries, retry and large-item traffic) against the oracle (tests/soak.py at a size that finishes in a minute)"""
     import torch
 
     from portello_amd import devbatch
