@@ -81,6 +81,6 @@ if __name__ == "__main__":
     cases = [case(601, 60), case(602, 60, rev_contig_frac=1.0), case(603, 40, max_segments=5, n_contigs_per_hap=3)]
     out = os.path.join(ROOT, "tests", "golden", "glue_fixtures.json")
     with open(out, "w") as fh:
-        json.dump({"generator": "tools/make_glue_fixtures.py (oracle/pyrecords.py, pure Python from the Rust sources)", "cases": cases}, fh, indent=0,
+        json.dump({"generator": "tests/make_glue_fixtures.py (oracle/pyrecords.py, pure Python from the Rust sources)", "cases": cases}, fh, indent=0,
                   separators=(",", ":"))
     print(out, os.path.getsize(out), "bytes;", sum(len(c["items"]) for c in cases), "items")
