@@ -258,3 +258,37 @@ def test_gpu_sparse_window_batch_from_bam(tmp_path, oracle):
         rd.close()
         eng.close()
         index.close()
+
+
+@pytest.mark.gpu
+def test_gpu_garbage_granule_headers_stay_inside_the_buffer():
+    """headers are caller data: whatever they say, a probe reads inside `seq` or reports the bases absent -- the call returns
+    (statuses may be anything the garbage implies), the engine stays usable and a clean batch afterwards gives the oracle's result"""
+    from portello_amd import api
+    rng = np.random.default_rng(77)
+    w = workload(1500, seed=31)
+    ixd, b = w.index_data(), w.batch_data()
+    sp = bam.sparse_pack(b, 32)
+    index = api.Index(ixd, 0)
+    eng = api.Engine(index)
+    try:
+        for trial in range(4):
+            seq = sp.seq.copy()
+            for r in range(sp.n_reads):  # overwrite every header with random masks / ranks (the last trial: huge ranks)
+                n = int(sp.read_seq_len[r])
+                off = int(sp.read_seq_off[r])
+                nw = (n + 1023) >> 10
+                g = rng.integers(0, 2**32, 2 * nw, dtype=np.uint64).astype(np.uint32)
+                if trial == 3:
+                    g[1::2] = 0xFFFFFFF0
+                seq[off:off + 8 * nw] = g.view(np.uint8)
+            bad = dataclasses.replace(sp, seq=seq, seq_full=None, read_seq_full_off=None)
+            out = abi.result_from_out(eng.liftover_batch_host(bad.to_desc()))
+            assert out.n_items > 0
+        got = abi.result_from_out(eng.liftover_batch_host(sp.to_desc())).canonical()
+        from oracle import pyoracle
+        pyoracle.build()
+        assert got == pyoracle.liftover_batch(ixd, b, abi.STAGES_ALL, 8).canonical()
+    finally:
+        eng.close()
+        index.close()
