@@ -216,9 +216,10 @@ struct BgzfIn {
         }
         const size_t cpos0 = cpos;
         if (device < 0) {
-            // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 6.6 GB/s (a 64 KiB block takes a lone wave ~20 ms:
-            // ~65 k symbols at ~300 ns each of branchy scalar code; 2 560 blocks in flight), which with the transfers is no faster
-            // than 16 host cores of libdeflate (7 GB/s) -- see DESIGN.md for what it needs to get ahead
+            // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 15 GB/s (17.5 ms per 268 MB chunk), twice what 16 host
+            // cores do with libdeflate -- but staging the compressed bytes in page-locked memory and checking the CRCs afterwards cost
+            // those cores nearly as much as inflating, and the steps run one after the other: the reader is not faster with it yet
+            // 
             const char *e = getenv("PLO_BGZF_DEVICE");
             device = (e && atoi(e) != 0) ? 1 : 0;
             if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays

@@ -586,6 +586,13 @@ struct InfWave {  // wave primitives of the decoder's I/O policy (InfWaveIO, inf
     }
     PLO_DEV uint32_t uniform(uint32_t v) const { return wv::bcast_first(v); }
     PLO_DEV uint32_t scalar(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    PLO_DEV uint32_t read_lane(uint32_t v, uint32_t l) const {  // l wave-uniform
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
+    }
+    PLO_DEV int popcount64(unsigned long long v) const { return __builtin_popcountll(v); }
+    PLO_DEV uint32_t rank_below(unsigned long long mask) const {  // set bits of mask below this lane
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    }
     PLO_DEV long long clock() const { return wv::clock(); }
     // a byte this wave wrote back earlier: read at device scope (L2), never from a line the CU's vector cache fetched while the
     // line was still being filled
@@ -608,8 +615,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
         int rc = k.ulen ? inflate_block(io, comp + k.coff, k.clen, out + k.uoff, k.ulen, lds.ws, &w) : 0;
 #ifdef PLO_INF_TIMING
         if (b == 7 && wv::lane() == 0)
-            printf("[inflate] block %u: %u -> %u bytes, %lld cycles: input chunks %d (%lld), write-backs %d (%lld), matches %d (%lld), far %d (%lld)\n", b, k.clen, k.ulen,
-                   wv::clock() - tb, io.n_load, io.t_load, io.n_flush, io.t_flush, io.n_match, io.t_match, io.n_far, io.t_far);
+            printf("[inflate] block %u: %u -> %u bytes, %lld cycles: input chunks %d (%lld), write-backs %d (%lld), matches %d (%lld), far %d (%lld), tables %d (%lld), literals in runs %d (%lld)\n", b, k.clen, k.ulen,
+                   wv::clock() - tb, io.n_load, io.t_load, io.n_flush, io.t_flush, io.n_match, io.t_match, io.n_far, io.t_far, io.n_table, io.t_table, io.n_run, io.t_run);
 #endif
         if (rc == 0 && w != k.ulen) rc = -9;  // the stream ended before ISIZE bytes
         if (wv::lane() == 0) status[b] = rc;

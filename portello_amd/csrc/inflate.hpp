@@ -4,16 +4,20 @@
 // ~0.4 GB/s each, the device takes every block of a 256 MB chunk at once.
 //
 // Decoding a Huffman stream is sequential, so all lanes of the wave run the SAME decode on the same bits -- uniform control
-// flow, table look-ups that are LDS broadcasts -- and the wave spreads only the data movement.  What bounds such a decoder is
-// the latency of one symbol (look-up -> shift -> next look-up) times the number of blocks a CU can work on at once, which is
-// an LDS budget.  Hence the I/O policy of the wave (InfWaveIO):
+// flow, table look-ups that are LDS broadcasts, the decode state pinned to scalar registers -- and the wave spreads the data
+// movement and, for runs of literals, the look-ups (InfWaveIO):
 //   * the compressed bytes pass through a 2 KiB LDS window filled 1 KiB at a time with coalesced loads (first version: every
 //     refill of the bit buffer was a dependent global load);
 //   * the output goes to an 8 KiB LDS ring that is written back 4 KiB at a time with coalesced stores; matches whose source is
-//     still in the ring (distance <= 7 680) are LDS-to-LDS copies by up to 64 lanes at once; the rare far ones (read names and
-//     tags of the previous record) read the bytes this wave wrote back earlier from global memory (first version: every match
-//     did);
-//   * 16 KiB of LDS per block in all (tables 5.7 KiB): ten blocks in flight per CU.
+//     still in the ring (distance <= 7 680) are LDS-to-LDS copies by up to 64 lanes at once; the far ones (read names and tags
+//     of the previous record) read the bytes this wave wrote back earlier from global memory;
+//   * runs of literals -- most symbols of a BAM block are base qualities -- are decoded 64 bit offsets at a time: lane i looks
+//     up the code that would start i bits after the current position, and the scalar unit follows the chain of code lengths
+//     through the lanes (literal_run).  A lone wave issues an instruction every four cycles at best and waits ~130 cycles for
+//     a dependent LDS look-up: ~300 cycles per symbol for a serial loop, ~160 (at most ~40 instructions) this way;
+//   * 16 KiB of LDS per block in all (tables 5.8 KiB): ten blocks in flight per CU.
+// Measured on MI355X, 268 MB chunks of a level-1 BAM (4 113 blocks): 48.6 ms first version, 40.8 ms with the LDS windows and
+// scalar state, 17.5 ms with the lane-parallel literal runs (15 GB/s; 16 host cores with libdeflate: 7 GB/s).
 // Codes of up to 10 bits (nearly all) cost one table look-up; longer ones fall back to canonical decoding by code length.
 // Input and output are bounds-checked: the decoder returns 0 or a negative error code and never reads or writes outside
 // [in, in + in_len) / [out, out + out_len).
@@ -40,6 +44,13 @@ struct InfWork {
     uint16_t offs[16], next[16];         // running offsets / next codes by length while tables are built (indexed arrays in LDS:
                                          // as locals they would be scratch, i.e. global memory)
     uint8_t lengths[320];
+};
+
+// decoder state of the bit reader (64-bit buffer refilled with aligned 32-bit words, see inf_refill)
+struct InfBits {
+    uint32_t in_len, ipos;  // ipos: byte position of the next word to fetch (a multiple of 4)
+    unsigned long long buf;
+    int cnt;  // valid bits in buf
 };
 
 // ---- I/O policies ---------------------------------------------------------------------------------------------------------------
@@ -77,6 +88,7 @@ struct InfSerial {
     }
     PLO_HD void advance(uint32_t) {}
     PLO_HD void end(uint32_t) {}
+    PLO_HD long long literal_run(unsigned long long, uint32_t &, uint32_t, const uint16_t *) { return -1; }
 };
 
 // LDS of one wave's I/O (besides InfWork)
@@ -106,9 +118,10 @@ struct InfWaveIO {
     uint32_t in_len = 0, in_hi = 0;  // input bytes [in_hi - INF_IN_RING, in_hi) are in the window (as far as they exist)
     uint32_t flushed = 0;            // output bytes [0, flushed) are in global memory
     uint32_t ring_from = 0;          // output bytes [ring_from, pos) are in the ring (unless older than INF_RING)
+    uint32_t skip_runs = 0;          // literal_run attempts to skip (adaptive, see there)
 #ifdef PLO_INF_TIMING
-    long long t_load = 0, t_flush = 0, t_match = 0, t_far = 0;
-    int n_load = 0, n_flush = 0, n_match = 0, n_far = 0;
+    long long t_load = 0, t_flush = 0, t_match = 0, t_far = 0, t_table = 0, t_run = 0;
+    int n_load = 0, n_flush = 0, n_match = 0, n_far = 0, n_table = 0, n_run = 0;
 #define INF_T0 long long t0_ = prim.clock();
 #define INF_T1(acc, cnt) acc += prim.clock() - t0_; ++cnt;
 #else
@@ -133,6 +146,7 @@ struct InfWaveIO {
         in_hi = 0;
         flushed = 0;
         ring_from = 0;
+        skip_runs = 0;
     }
     PLO_HD void load_chunk() {  // the next INF_IN_CHUNK input bytes into the window: 16 coalesced byte loads per lane
         INF_T0
@@ -155,6 +169,81 @@ struct InfWaveIO {
     }
     PLO_HD void put_literal(uint32_t pos, uint32_t v) {
         if (prim.lane() == 0) m->oring[pos & (INF_RING - 1)] = (uint8_t)v;
+    }
+    // Runs of literals (most symbols of a BAM block: base qualities), SIXTY-FOUR BIT OFFSETS AT A TIME.  A serial decoder pays
+    // one dependent LDS round trip (~130 cycles, ~300 with the loop around it) per symbol.  Here lane i looks up the code that
+    // would start i bits after the current position -- straight from the input window, no bit buffer: two LDS round trips for
+    // all 64 offsets -- and the scalar unit then only follows the chain of code lengths through the lanes (v_readlane, no memory):
+    // ~8 literals per pair of round trips.  The lanes at which symbols start store them in one instruction, each at its rank
+    // (v_mbcnt over the start mask).  Returns the bit position reached (the first symbol that is not a fast-table literal, or a
+    // boundary: end of the loaded input window, the last byte before a write-back boundary of the ring, the end of the output),
+    // or -1 without having touched anything.
+    PLO_HD long long literal_run(unsigned long long bit0, uint32_t &pos, uint32_t out_len, const uint16_t *lfast) {
+        if (skip_runs) {  // the last runs were short (a stretch of matches): the general path is cheaper there
+            --skip_runs;
+            return -1;
+        }
+        INF_T0
+        const uint32_t l = (uint32_t)prim.lane();
+        unsigned long long bp = bit0;
+        uint32_t p = prim.scalar(pos);
+        const uint32_t p0 = p;
+        const uint32_t hi = prim.scalar(in_hi), ilen = prim.scalar(in_len);
+        const uint32_t stop = (uint32_t)((((unsigned long long)p | (INF_CHUNK - 1)) < out_len ? (p | (INF_CHUNK - 1)) : out_len));  // p < stop
+        while (p < stop) {
+            // (bp and p are the same in every lane: said once per round, so that the loop around the chain is scalar code too)
+            bp = (unsigned long long)prim.scalar((uint32_t)bp) | ((unsigned long long)prim.scalar((uint32_t)(bp >> 32)) << 32);
+            p = prim.scalar(p);
+            const uint32_t byte0 = (uint32_t)(bp >> 3);
+            if (byte0 + 16 > hi || (byte0 + 16 + 512 > hi && hi < ilen)) break;  // the general path moves the window
+            // bits [bp + l, bp + l + 10) of the input: two aligned words of the window, funnel-shifted
+            const uint32_t b = (uint32_t)(bp & 31u) + l, w = (uint32_t)(bp >> 5) + (b >> 5);
+            const uint32_t *ring32 = (const uint32_t *)m->iring;
+            const uint32_t lo = ring32[w & (INF_IN_RING / 4 - 1)], hi32 = ring32[(w + 1) & (INF_IN_RING / 4 - 1)];
+            const uint32_t idx = (uint32_t)((((unsigned long long)hi32 << 32) | lo) >> (b & 31u)) & ((1u << INF_FAST_BITS) - 1u);
+            const uint32_t E = lfast[idx];  // (symbol << 4) | length of the code starting at this lane's offset, 0 = long code
+            // where the symbol after this lane's starts: lane + length (< 128) for a fast-table literal, 128 + lane for anything else
+            const uint32_t NEXT = (E != 0 && (E >> 4) < 256u) ? l + (E & 15u) : 128u + l;
+            // follow the chain: one v_readlane and a handful of scalar instructions per literal
+            unsigned long long starts = 0;
+            uint32_t cur = 0;
+            const uint32_t room = stop - p;
+            if (room >= 64) {
+                for (;;) {
+                    const uint32_t nx = prim.read_lane(NEXT, cur);
+                    if (nx >= 128u) break;  // the symbol at `cur` is not ours
+                    starts |= 1ull << cur;
+                    cur = nx;
+                    if (cur >= 64u) break;
+                }
+            } else {  // close to a boundary of the output: count as well
+                uint32_t n_ = 0;
+                for (;;) {
+                    const uint32_t nx = prim.read_lane(NEXT, cur);
+                    if (nx >= 128u || n_ >= room) break;
+                    starts |= 1ull << cur;
+                    cur = nx;
+                    ++n_;
+                    if (cur >= 64u) break;
+                }
+            }
+            if (starts == 0) break;
+            if ((starts >> l) & 1ull) m->oring[(p + prim.rank_below(starts)) & (INF_RING - 1)] = (uint8_t)(E >> 4);
+            p += (uint32_t)prim.popcount64(starts);
+            bp += cur;
+            if (cur < 64u) break;  // stopped at a symbol that is not ours (or at the boundary)
+        }
+        INF_T1(t_run, n_run)
+        if (p == p0) {
+            skip_runs = 3;
+            return -1;
+        }
+        if (p - p0 < 4) skip_runs = 2;
+#ifdef PLO_INF_TIMING
+        n_run += (int)(p - p0) - 1;
+#endif
+        pos = p;
+        return (long long)bp;
     }
     // byte k of the match = byte (k mod dist) of the `dist` bytes before pos (an overlapping match repeats them): all sources
     // are older than pos, so the lanes copy independently
@@ -204,11 +293,6 @@ struct InfWaveIO {
 };
 
 // ---- bit reader: 64-bit buffer refilled with aligned 32-bit words ---------------------------------------------------------------
-struct InfBits {
-    uint32_t in_len, ipos;  // ipos: byte position of the next word to fetch (a multiple of 4)
-    unsigned long long buf;
-    int cnt;  // valid bits in buf
-};
 template <class Par>
 PLO_HD void inf_refill(Par &par, InfBits &s) {  // at least 33 bits afterwards (zeros beyond the end of the input)
     if (s.cnt <= 32) {
@@ -348,6 +432,9 @@ PLO_HD int inflate_block(Par &par, const uint8_t *in, uint32_t in_len, uint8_t *
             continue;
         }
         if (type == 3) return INF_ERR_BTYPE;
+#ifdef PLO_INF_TIMING
+        long long tt0_ = par.prim.clock();
+#endif
         par.sync();  // the previous block's tables are no longer read
         if (type == 1) {  // fixed codes
             for (int sym = lane; sym < 288; sym += width) ws.lengths[sym] = (uint8_t)(sym < 144 ? 8 : (sym < 256 ? 9 : (sym < 280 ? 7 : 8)));
@@ -427,8 +514,21 @@ PLO_HD int inflate_block(Par &par, const uint8_t *in, uint32_t in_len, uint8_t *
             inf_fill_fast(par, ws.lfast, ws.code, ws.lcount, ws.lengths, nlen, ws.next);
             inf_fill_fast(par, ws.dfast, ws.code, ws.dcount, ws.lengths + nlen, ndist, ws.next);
         }
+#ifdef PLO_INF_TIMING
+        par.t_table += par.prim.clock() - tt0_;
+        ++par.n_table;
+#endif
         // literal / length + distance symbols until the end-of-block code
         for (;;) {
+            {   // a run of literals, if one starts here: the policy decodes it and says at which bit the general path goes on
+                par.sync();
+                const long long bp = par.literal_run((unsigned long long)((long long)s.ipos * 8 - s.cnt), pos, out_len, ws.lfast);
+                if (bp >= 0) {
+                    inf_seek(par, s, (uint32_t)(bp >> 3));
+                    inf_take(s, (int)(bp & 7));
+                    par.advance(pos);
+                }
+            }
             inf_pin(par, s, pos);
             par.pin();
             inf_refill(par, s);

@@ -459,6 +459,9 @@ struct InfEmuWave {
     void sync() const { wv::sync(); }
     uint32_t uniform(uint32_t v) const { return (uint32_t)wv::bcast_first((int)v); }
     uint32_t scalar(uint32_t v) const { return v; }
+    uint32_t read_lane(uint32_t v, uint32_t l) const { return (uint32_t)wv::shfl((int)v, (int)(l & 63)); }
+    int popcount64(unsigned long long v) const { return __builtin_popcountll(v); }
+    uint32_t rank_below(unsigned long long mask) const { return (uint32_t)__builtin_popcountll(mask & ((1ull << wv::lane()) - 1ull)); }
     uint8_t load_written(const uint8_t *p) const { return *p; }
 };
 }  // namespace
