@@ -23,6 +23,11 @@
 
 void plo_bam_set_error(const std::string &msg);
 // engine.hip: all BGZF blocks of a chunk inflated on the device (one thread per block); < 0 = not done, inflate on the host
+extern "C" uint32_t plo_internal_bgzf_slots(void);  // blocks the device inflates at once (one per resident wave); 0 without a device
+extern "C" void plo_internal_bgzf_acquire(void);
+extern "C" void plo_internal_bgzf_release(void);
+extern "C" int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);
+extern "C" int plo_internal_bgzf_wait(int slot);
 extern "C" int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
 
 namespace {
@@ -167,10 +172,11 @@ struct BgzfIn {
     const uint8_t *map = nullptr;
     size_t size = 0, cpos = 0;
     RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
-    RawBuf cstage;  // device inflate: page-locked copy of a chunk's compressed bytes
+    RawBuf cstage2[2];  // device inflate: page-locked copies of two groups' compressed bytes
     size_t bpos = 0;
     int threads = 1;
     bool eof = false;
+    uint32_t dev_slots = 0;
     int device = -1;  // -1 undecided, 0 host inflate, 1 blocks of a chunk are inflated on the GPU (PLO_BGZF_DEVICE=1 switches it on)
     static constexpr size_t CHUNK = 256u << 20;
     struct DevBlk {  // engine.hip's BgzfBlk
@@ -216,10 +222,9 @@ struct BgzfIn {
         }
         const size_t cpos0 = cpos;
         if (device < 0) {
-            // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 15 GB/s (17.5 ms per 268 MB chunk), twice what 16 host
-            // cores do with libdeflate -- but staging the compressed bytes in page-locked memory and checking the CRCs afterwards cost
-            // those cores nearly as much as inflating, and the steps run one after the other: the reader is not faster with it yet
-            // 
+            // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 20 GB/s, three times what 16 host cores do with
+            // libdeflate -- but staging the compressed bytes in page-locked memory and checking the CRCs afterwards cost those cores
+            // nearly as much as inflating: pipelined with the device, a refill takes as long as on the host
             const char *e = getenv("PLO_BGZF_DEVICE");
             device = (e && atoi(e) != 0) ? 1 : 0;
             if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays
@@ -267,27 +272,57 @@ struct BgzfIn {
         if (!buf.resize(u)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the inflated BAM stream");
         std::atomic<int> bad{0};
         if (device == 1 && !blks.empty()) {
-            // the whole chunk on the GPU; CRCs on the host afterwards (libdeflate's CRC runs at memory speed)
-            std::vector<DevBlk> db(blks.size());
-            const size_t c0 = blks.front().coff, u0 = blks.front().uoff;
-            for (size_t i = 0; i < blks.size(); ++i) db[i] = DevBlk{blks[i].coff - c0, blks[i].uoff - u0, (uint32_t)blks[i].clen, (uint32_t)blks[i].ulen};
-            const size_t cbytes = blks.back().coff + blks.back().clen - c0, ubytes = u - u0;
-            // the compressed bytes go through a page-locked staging buffer: a large host-to-device copy straight from the file
-            // mapping makes the runtime pin file-backed pages, which is far slower than this parallel copy
-            int rc = -101;
-            cstage.pinned = true;
-            if (cstage.resize(cbytes + 16)) {
-                parallel_copy(cstage.data(), map + c0, cbytes, threads);
-                rc = plo_internal_bgzf_inflate(cstage.data(), cbytes, db.data(), (uint32_t)db.size(), buf.data() + u0, ubytes);
-            }
-            if (rc == 0) {
-                parallel_for(blks.size(), threads, [&](size_t i) {
-                    const Blk &b = blks[i];
+            // On the GPU, in groups of one block per resident wave (a group of exactly that many has no second, nearly empty round),
+            // two groups in flight: while the device inflates group g the host stages the compressed bytes of group g + 1 in
+            // page-locked memory (a large host-to-device copy straight from the file mapping would make the runtime pin file-backed
+            // pages, far slower than this parallel copy) and checks the CRCs of group g - 1 (libdeflate's CRC runs at memory speed).
+            if (!dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
+            const size_t ng = (blks.size() + dev_slots - 1) / dev_slots;
+            std::vector<DevBlk> db[2];
+            int rc = 0;
+            auto begin = [&](size_t g) -> int {
+                const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
+                const size_t c0 = blks[lo].coff, u0 = blks[lo].uoff;
+                std::vector<DevBlk> &d = db[g & 1];
+                d.resize(hi - lo);
+                for (size_t i = lo; i < hi; ++i) d[i - lo] = DevBlk{blks[i].coff - c0, blks[i].uoff - u0, (uint32_t)blks[i].clen, (uint32_t)blks[i].ulen};
+                const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0, ubytes = blks[hi - 1].uoff + blks[hi - 1].ulen - u0;
+                RawBuf &cs = cstage2[g & 1];
+                cs.pinned = true;
+                if (!cs.resize(cbytes + 16)) return -101;
+                parallel_copy(cs.data(), map + c0, cbytes, threads);
+                return plo_internal_bgzf_begin((int)(g & 1), cs.data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes);
+            };
+            auto finish = [&](size_t g) -> int {
+                int r = plo_internal_bgzf_wait((int)(g & 1));
+                if (r) return r;
+                const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
+                parallel_for(hi - lo, threads, [&](size_t i) {
+                    const Blk &b = blks[lo + i];
                     if (b.ulen && fast_crc32(buf.data() + b.uoff, b.ulen) != b.crc) bad = 1;
                 });
+                return 0;
+            };
+            plo_internal_bgzf_acquire();
+            rc = begin(0);
+            for (size_t g = 0; g < ng && rc == 0; ++g) {
+                int rn = g + 1 < ng ? begin(g + 1) : 0;
+                rc = finish(g);
+                if (rc == 0 && rn != 0) {
+                    (void)plo_internal_bgzf_wait((int)((g + 1) & 1));
+                    rc = rn;
+                }
+            }
+            if (rc != 0) {  // leave nothing in flight
+                (void)plo_internal_bgzf_wait(0);
+                (void)plo_internal_bgzf_wait(1);
+            }
+            plo_internal_bgzf_release();
+            if (rc == 0) {
                 if (bad) return fail(PLO_ERR_IO, "BGZF block CRC mismatch after device inflate");
                 return PLO_OK;
             }
+            bad = 0;
             if (rc <= -100 && rc > -200) device = 0;  // no usable device: stay on the host from now on
             // a block the device rejects is inflated again on the host, which reports what is wrong with it
         }

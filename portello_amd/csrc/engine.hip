@@ -602,11 +602,15 @@ struct InfLds {
     InfWork ws;
     InfWaveMem io;
 };
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfBlk *blks, uint32_t n, uint8_t *out, int *status) {
-    __shared__ InfLds lds;  // 15.9 KB: ten blocks in flight per CU
+// Four waves per workgroup, each on its own block with its own LDS: the workgroup's waves sit on the four SIMDs of the CU, which
+// one-wave workgroups do not (the decoder is bound by instruction issue once a SIMD holds several of them).
+constexpr int INF_WAVES = 4;
+__global__ __launch_bounds__(INF_WAVES * 64) void k_bgzf_inflate(const uint8_t *comp, const BgzfBlk *blks, uint32_t n, uint8_t *out, int *status) {
+    __shared__ InfLds lds_all[INF_WAVES];  // 4 x 15.9 KB: two workgroups, eight blocks in flight per CU
+    InfLds &lds = lds_all[wv::wave_id()];
     InfWaveIO<InfWave> io;
     io.m = &lds.io;
-    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x * INF_WAVES + (uint32_t)wv::wave_id(); b < n; b += gridDim.x * INF_WAVES) {
         const BgzfBlk k = blks[b];
         uint32_t w = 0;
 #ifdef PLO_INF_TIMING
@@ -1788,48 +1792,91 @@ plo_status plo_compact_output_dev(plo_ctx *c, plo_batch_out *out) {
 // chunk's compressed bytes (host, pageable or pinned), `blks` = BgzfBlk[n] with offsets inside comp / out, `out` = host
 // destination (page-locked for a direct DMA).  Returns 0, or a negative number when the device is unusable / a block is corrupt
 // (the caller then inflates on the host, which also produces the diagnostics).  Not part of the public ABI.
-int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
-    static std::mutex mu;
-    static DevBuf d_comp, d_out, d_blk, d_st;
-    static hipStream_t st = nullptr;
-    static int dev_ok = -1;
-    std::lock_guard<std::mutex> g(mu);
-    if (dev_ok < 0) {
+static uint32_t bgzf_workgroups() {  // resident workgroups of k_bgzf_inflate on the current device
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (uint32_t)std::max(1, cus) * (uint32_t)std::max<size_t>(1, (160u << 10) / (sizeof(InfLds) * INF_WAVES));
+}
+uint32_t plo_internal_bgzf_slots(void) { return bgzf_workgroups() * INF_WAVES; }
+// Two slots (stream + device buffers each), so that the caller stages the next group of blocks and checks the CRCs of the previous
+// one while the device inflates: begin() enqueues upload, kernel and download of a group, wait() returns when its bytes are in
+// `out`.  acquire() / release() bracket a sequence of begin / wait calls (one user at a time).
+namespace {
+struct InfSlot {
+    DevBuf d_comp, d_out, d_blk, d_st;
+    HostBuf h_blk, h_st;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n = 0;
+    size_t comp_bytes = 0, out_bytes = 0;
+    bool busy = false;
+};
+InfSlot g_inf[2];
+std::mutex g_inf_mu;
+int g_inf_ok = -1;
+}  // namespace
+void plo_internal_bgzf_acquire(void) { g_inf_mu.lock(); }
+void plo_internal_bgzf_release(void) { g_inf_mu.unlock(); }
+int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
+    if (slot < 0 || slot > 1) return -101;
+    if (g_inf_ok < 0) {
         int nd = 0;
-        dev_ok = (hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) ? 1 : 0;
+        g_inf_ok = (hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && hipStreamCreateWithFlags(&g_inf[0].st, hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&g_inf[1].st, hipStreamNonBlocking) == hipSuccess)
+                       ? 1
+                       : 0;
     }
-    if (!dev_ok) return -100;
+    if (!g_inf_ok) return -100;
+    InfSlot &q = g_inf[slot];
+    q.n = n;
+    q.busy = false;
     if (!n) return 0;
-    if (d_comp.ensure(comp_bytes + 16) != hipSuccess || d_out.ensure(out_bytes + 16) != hipSuccess || d_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess ||
-        d_st.ensure((size_t)n * 4) != hipSuccess)
+    if (q.d_comp.ensure(comp_bytes + 16) != hipSuccess || q.d_out.ensure(out_bytes + 16) != hipSuccess || q.d_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess ||
+        q.d_st.ensure((size_t)n * 4) != hipSuccess || q.h_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess || q.h_st.ensure((size_t)n * 4) != hipSuccess)
         return -101;
-    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool dbg = getenv("PLO_DEBUG_INFLATE") != nullptr;
-    if (dbg && !ev[0])
-        for (auto &e : ev) (void)hipEventCreate(&e);
-    if (dbg) (void)hipEventRecord(ev[0], st);
-    if (hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
-    if (hipMemcpyAsync(d_blk.p, blks, (size_t)n * sizeof(BgzfBlk), hipMemcpyHostToDevice, st) != hipSuccess) return -102;
-    if (dbg) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>(n, 256u * (uint32_t)std::min<size_t>(16, (160u << 10) / sizeof(InfLds)))), dim3(64), 0, st, (const uint8_t *)d_comp.p, (const BgzfBlk *)d_blk.p, n,
-                       (uint8_t *)d_out.p, (int *)d_st.p);
+    if (dbg && !q.ev[0])
+        for (auto &e : q.ev) (void)hipEventCreate(&e);
+    memcpy(q.h_blk.p, blks, (size_t)n * sizeof(BgzfBlk));  // (the caller's array may go away before the copy runs)
+    hipStream_t st = q.st;
+    if (dbg) (void)hipEventRecord(q.ev[0], st);
+    if (hipMemcpyAsync(q.d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
+    if (hipMemcpyAsync(q.d_blk.p, q.h_blk.p, (size_t)n * sizeof(BgzfBlk), hipMemcpyHostToDevice, st) != hipSuccess) return -102;
+    if (dbg) (void)hipEventRecord(q.ev[1], st);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>((n + INF_WAVES - 1) / INF_WAVES, bgzf_workgroups())), dim3(INF_WAVES * 64), 0, st,
+                       (const uint8_t *)q.d_comp.p, (const BgzfBlk *)q.d_blk.p, n, (uint8_t *)q.d_out.p, (int *)q.d_st.p);
     if (hipGetLastError() != hipSuccess) return -103;
-    if (dbg) (void)hipEventRecord(ev[2], st);
-    if (hipMemcpyAsync(out, d_out.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
-    std::vector<int> stv(n);
-    if (hipMemcpyAsync(stv.data(), d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
-    if (dbg) (void)hipEventRecord(ev[3], st);
-    if (hipStreamSynchronize(st) != hipSuccess) return -105;
-    if (dbg) {
+    if (dbg) (void)hipEventRecord(q.ev[2], st);
+    if (hipMemcpyAsync(out, q.d_out.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
+    if (hipMemcpyAsync(q.h_st.p, q.d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
+    if (dbg) (void)hipEventRecord(q.ev[3], st);
+    q.comp_bytes = comp_bytes;
+    q.out_bytes = out_bytes;
+    q.busy = true;
+    return 0;
+}
+int plo_internal_bgzf_wait(int slot) {
+    if (slot < 0 || slot > 1) return -101;
+    InfSlot &q = g_inf[slot];
+    if (!q.busy) return 0;
+    q.busy = false;
+    if (hipStreamSynchronize(q.st) != hipSuccess) return -105;
+    if (getenv("PLO_DEBUG_INFLATE") && q.ev[0]) {
         float a = 0, b = 0, c2 = 0;
-        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
-        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
-        (void)hipEventElapsedTime(&c2, ev[2], ev[3]);
-        fprintf(stderr, "[plo] device inflate: %u blocks, %.1f MB -> %.1f MB: H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", n, comp_bytes / 1e6, out_bytes / 1e6, a, b, c2);
+        (void)hipEventElapsedTime(&a, q.ev[0], q.ev[1]);
+        (void)hipEventElapsedTime(&b, q.ev[1], q.ev[2]);
+        (void)hipEventElapsedTime(&c2, q.ev[2], q.ev[3]);
+        fprintf(stderr, "[plo] device inflate: %u blocks, %.1f MB -> %.1f MB: H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", q.n, q.comp_bytes / 1e6, q.out_bytes / 1e6, a, b, c2);
     }
-    for (uint32_t i = 0; i < n; ++i)
+    const int *stv = q.h_st.as<int>();
+    for (uint32_t i = 0; i < q.n; ++i)
         if (stv[i] != 0) return -200;
     return 0;
+}
+int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
+    std::lock_guard<std::mutex> g(g_inf_mu);
+    int rc = plo_internal_bgzf_begin(0, comp, comp_bytes, blks, n, out, out_bytes);
+    return rc ? rc : plo_internal_bgzf_wait(0);
 }
 
 plo_status plo_host_alloc(size_t bytes, void **out) {

@@ -16,8 +16,10 @@
 //     through the lanes (literal_run).  A lone wave issues an instruction every four cycles at best and waits ~130 cycles for
 //     a dependent LDS look-up: ~300 cycles per symbol for a serial loop, ~160 (at most ~40 instructions) this way;
 //   * 16 KiB of LDS per block in all (tables 5.8 KiB): ten blocks in flight per CU.
-// Measured on MI355X, 268 MB chunks of a level-1 BAM (4 113 blocks): 48.6 ms first version, 40.8 ms with the LDS windows and
-// scalar state, 17.5 ms with the lane-parallel literal runs (15 GB/s; 16 host cores with libdeflate: 7 GB/s).
+//   * a match whose codes are in the fast tables is taken inside that loop (one scalar look-up for the distance, the copy by the
+//     lanes); the symbol-by-symbol general path is left with long codes, block ends and write-back boundaries.
+// Measured on MI355X on a level-1 BAM: 5.5 GB/s first version, 6.6 GB/s with the LDS windows and scalar state, 15 GB/s with the
+// lane-parallel literal runs, 20 GB/s with matches in the run and one wave per SIMD (16 host cores with libdeflate: 7 GB/s).
 // Codes of up to 10 bits (nearly all) cost one table look-up; longer ones fall back to canonical decoding by code length.
 // Input and output are bounds-checked: the decoder returns 0 or a negative error code and never reads or writes outside
 // [in, in + in_len) / [out, out + out_len).
@@ -88,7 +90,7 @@ struct InfSerial {
     }
     PLO_HD void advance(uint32_t) {}
     PLO_HD void end(uint32_t) {}
-    PLO_HD long long literal_run(unsigned long long, uint32_t &, uint32_t, const uint16_t *) { return -1; }
+    PLO_HD long long literal_run(unsigned long long, uint32_t &, uint32_t, const uint16_t *, const uint16_t *) { return -1; }
 };
 
 // LDS of one wave's I/O (besides InfWork)
@@ -178,8 +180,16 @@ struct InfWaveIO {
     // (v_mbcnt over the start mask).  Returns the bit position reached (the first symbol that is not a fast-table literal, or a
     // boundary: end of the loaded input window, the last byte before a write-back boundary of the ring, the end of the output),
     // or -1 without having touched anything.
-    PLO_HD long long literal_run(unsigned long long bit0, uint32_t &pos, uint32_t out_len, const uint16_t *lfast) {
-        if (skip_runs) {  // the last runs were short (a stretch of matches): the general path is cheaper there
+    PLO_HD unsigned long long peek64(unsigned long long bitpos) {  // 64 input bits from a bit position inside the window (scalar)
+        const uint32_t *ring32 = (const uint32_t *)m->iring;
+        const uint32_t w = (uint32_t)(bitpos >> 5), sh = (uint32_t)(bitpos & 31u);
+        const uint32_t a = prim.scalar(ring32[w & (INF_IN_RING / 4 - 1)]), b = prim.scalar(ring32[(w + 1) & (INF_IN_RING / 4 - 1)]);
+        const uint32_t c = prim.scalar(ring32[(w + 2) & (INF_IN_RING / 4 - 1)]);
+        const unsigned long long lo = ((unsigned long long)b << 32) | a;
+        return sh ? (lo >> sh) | ((unsigned long long)c << (64 - sh)) : lo;
+    }
+    PLO_HD long long literal_run(unsigned long long bit0, uint32_t &pos, uint32_t out_len, const uint16_t *lfast, const uint16_t *dfast) {
+        if (skip_runs) {  // the last runs got nowhere (long codes): the general path is cheaper there
             --skip_runs;
             return -1;
         }
@@ -188,14 +198,19 @@ struct InfWaveIO {
         unsigned long long bp = bit0;
         uint32_t p = prim.scalar(pos);
         const uint32_t p0 = p;
-        const uint32_t hi = prim.scalar(in_hi), ilen = prim.scalar(in_len);
+        const uint32_t ilen = prim.scalar(in_len);
         const uint32_t stop = (uint32_t)((((unsigned long long)p | (INF_CHUNK - 1)) < out_len ? (p | (INF_CHUNK - 1)) : out_len));  // p < stop
         while (p < stop) {
             // (bp and p are the same in every lane: said once per round, so that the loop around the chain is scalar code too)
             bp = (unsigned long long)prim.scalar((uint32_t)bp) | ((unsigned long long)prim.scalar((uint32_t)(bp >> 32)) << 32);
             p = prim.scalar(p);
             const uint32_t byte0 = (uint32_t)(bp >> 3);
-            if (byte0 + 16 > hi || (byte0 + 16 + 512 > hi && hi < ilen)) break;  // the general path moves the window
+            uint32_t hi = prim.scalar(in_hi);
+            while (hi < ilen && byte0 + 32 + 512 > hi) {  // keep the window ahead of the round (literal chain + one match: < 32 bytes)
+                load_chunk();
+                hi = prim.scalar(in_hi);
+            }
+            if (byte0 + 32 > hi) break;  // the last bytes of the input: the general path pads with zeros
             // bits [bp + l, bp + l + 10) of the input: two aligned words of the window, funnel-shifted
             const uint32_t b = (uint32_t)(bp & 31u) + l, w = (uint32_t)(bp >> 5) + (b >> 5);
             const uint32_t *ring32 = (const uint32_t *)m->iring;
@@ -208,10 +223,11 @@ struct InfWaveIO {
             unsigned long long starts = 0;
             uint32_t cur = 0;
             const uint32_t room = stop - p;
+            bool full = false;  // stopped because the output boundary was reached, not at a symbol of another kind
             if (room >= 64) {
                 for (;;) {
                     const uint32_t nx = prim.read_lane(NEXT, cur);
-                    if (nx >= 128u) break;  // the symbol at `cur` is not ours
+                    if (nx >= 128u) break;  // the symbol at `cur` is not a literal
                     starts |= 1ull << cur;
                     cur = nx;
                     if (cur >= 64u) break;
@@ -220,25 +236,51 @@ struct InfWaveIO {
                 uint32_t n_ = 0;
                 for (;;) {
                     const uint32_t nx = prim.read_lane(NEXT, cur);
-                    if (nx >= 128u || n_ >= room) break;
+                    if (nx >= 128u) break;
+                    if (n_ >= room) {
+                        full = true;
+                        break;
+                    }
                     starts |= 1ull << cur;
                     cur = nx;
                     ++n_;
                     if (cur >= 64u) break;
                 }
             }
-            if (starts == 0) break;
-            if ((starts >> l) & 1ull) m->oring[(p + prim.rank_below(starts)) & (INF_RING - 1)] = (uint8_t)(E >> 4);
-            p += (uint32_t)prim.popcount64(starts);
-            bp += cur;
-            if (cur < 64u) break;  // stopped at a symbol that is not ours (or at the boundary)
+            if (starts != 0) {
+                if ((starts >> l) & 1ull) m->oring[(p + prim.rank_below(starts)) & (INF_RING - 1)] = (uint8_t)(E >> 4);
+                p += (uint32_t)prim.popcount64(starts);
+                bp += cur;
+            }
+            if (cur >= 64u) continue;  // literals all the way: next round
+            if (full) break;
+            // the chain stopped at a symbol that is not a literal.  A match whose codes are in the fast tables is taken right here
+            // (one scalar look-up for the distance, the copy by the lanes); everything else is the general path's
+            const uint32_t e0 = prim.read_lane(E, cur), sym = e0 >> 4;
+            if (e0 == 0 || sym < 257u || sym > 285u) break;  // long code, end of block, invalid
+            const unsigned long long bits = peek64(bp);
+            const uint32_t c = sym - 257u, ll = e0 & 15u;
+            const uint32_t le = c < 8u || c == 28u ? 0u : (c - 4u) >> 2;
+            const uint32_t lb = c < 8u ? 3u + c : (c == 28u ? 258u : 3u + ((4u + (c & 3u)) << le));
+            const uint32_t len = lb + ((uint32_t)(bits >> ll) & ((1u << le) - 1u));
+            uint32_t used = ll + le;
+            const uint32_t de = prim.scalar(dfast[(uint32_t)(bits >> used) & ((1u << INF_FAST_BITS) - 1u)]);
+            const uint32_t ds = de >> 4, dl = de & 15u;
+            if (de == 0 || ds >= 30u) break;
+            const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
+            const uint32_t db = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+            const uint32_t dist = db + ((uint32_t)(bits >> (used + dl)) & ((1u << dx) - 1u));
+            used += dl + dx;  // at most 10 + 5 + 10 + 13 bits
+            if (dist > p || p + len > stop) break;  // an error, or a copy across a write-back boundary: the general path's
+            put_match(p, dist, len);
+            p += len;
+            bp += used;
         }
         INF_T1(t_run, n_run)
         if (p == p0) {
             skip_runs = 3;
             return -1;
         }
-        if (p - p0 < 4) skip_runs = 2;
 #ifdef PLO_INF_TIMING
         n_run += (int)(p - p0) - 1;
 #endif
@@ -522,7 +564,7 @@ PLO_HD int inflate_block(Par &par, const uint8_t *in, uint32_t in_len, uint8_t *
         for (;;) {
             {   // a run of literals, if one starts here: the policy decodes it and says at which bit the general path goes on
                 par.sync();
-                const long long bp = par.literal_run((unsigned long long)((long long)s.ipos * 8 - s.cnt), pos, out_len, ws.lfast);
+                const long long bp = par.literal_run((unsigned long long)((long long)s.ipos * 8 - s.cnt), pos, out_len, ws.lfast, ws.dfast);
                 if (bp >= 0) {
                     inf_seek(par, s, (uint32_t)(bp >> 3));
                     inf_take(s, (int)(bp & 7));
