@@ -191,8 +191,9 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                     t_.join()
                 dt2 = time.perf_counter() - t0
                 two = {"value": 2 * reps2 * win.n_records / dt2, "unit": "reads/s", "ms_per_call_per_worker": dt2 / reps2 * 1e3,
-                       "note": "the host-buffer path is bound by the one PCIe link and the runtime's copy queue, which two callers share: a "
-                               "second context does not add throughput here (it does for device-resident batches: `overlap`)"}
+                       "note": "two callers share the one PCIe link and the runtime's copy queue: depending on how their transfers "
+                               "interleave a second context changes the rate by -25 % to +45 % from run to run (29-53 M reads/s measured); "
+                               "the steady gain of several contexts is with device-resident batches (`overlap`)"}
                 eng2.close()
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] two-worker host-buffer measurement failed: {e!r}")
