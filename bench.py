@@ -225,7 +225,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("PLO_BENCH_E2E_READS", "60000")),
                     help="N = 1: size of the BAM-to-BAM end-to-end sample (0 = skip the end_to_end / pcie_inclusive objects)")
-    ap.add_argument("--e2e-window", type=int, default=15000, help="primary records per window of the end-to-end run")
+    ap.add_argument("--e2e-window", type=int, default=7500,
+                    help="primary records per window of the end-to-end run (the 60 k-read sample is 8 windows: with fewer, larger ones the "
+                         "three-stage pipeline spends most of the run filling and draining)")
     ap.add_argument("--e2e-workers", type=int, default=2, help="lift worker threads (contexts) of the end-to-end run")
     ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip rank 0's comparison of the gathered records "
                                                              "with its own single-GPU result (after the timed region)")
@@ -589,7 +591,7 @@ def main():
     if rank == 0 and world == 1 and dist is None and args.e2e_reads > 0:
         try:
             ixd_host = w.index_data()
-            e2e, pcie = end_to_end(w, index, ixd_host, args.e2e_reads, args.e2e_window, args.e2e_workers, max(2, min(64, pipeline_cpus())))
+            e2e, pcie = end_to_end(w, index, ixd_host, args.e2e_reads, args.e2e_window, args.e2e_workers, int(os.environ.get("PLO_BENCH_IO_THREADS", "0")) or max(2, min(64, pipeline_cpus())))
             result["end_to_end"] = e2e
             if pcie is not None:
                 result["pcie_inclusive"] = pcie
