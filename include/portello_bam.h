@@ -47,6 +47,9 @@ typedef struct plo_bam_writer plo_bam_writer;
 typedef struct plo_bam_window plo_bam_window;
 
 plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out);
+/* the same with the choice of plo_bam_set_device_inflate made before the first block is read: device >= 0 that GPU, -1 the host,
+   -2 as plo_bam_open (host unless the environment says PLO_BGZF_DEVICE=1) */
+plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_bam_reader **out);
 void plo_bam_close(plo_bam_reader *r);
 /* header text and the @SQ list as stored in the BAM header (ChromList::from_bam_header, chrom_list.rs:27-37).
    The pointers stay valid until plo_bam_close. */
@@ -59,6 +62,12 @@ plo_status plo_bam_header(const plo_bam_reader *r, const char **text, uint32_t *
  *   supplementary flag set                -> skipped (:404)
  *   everything else                       -> a primary read of the batch
  * The window owns copies of the record bytes. */
+/* Inflate the BGZF blocks on GPU `device` (one wavefront per block, groups of blocks pipelined with the host's staging and CRC passes)
+ * instead of on the reader's threads, from the next refill on.  The kernel inflates about three times what 16
+ * host cores do; the refill as a whole takes as long either way (the host still stages the compressed bytes and checks the CRCs),
+ * but it leaves the cores to the other stages of a pipeline.  Falls back to the host when no device is usable; the environment
+ * variable PLO_BGZF_DEVICE=0/1 overrides. */
+void plo_bam_set_device_inflate(plo_bam_reader *r, int device); /* HIP device index, or -1: inflate on the host */
 plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_window **out);
 void plo_bam_window_free(plo_bam_window *w);
 uint32_t plo_bam_window_n_records(const plo_bam_window *w);

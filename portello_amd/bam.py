@@ -48,6 +48,10 @@ def lib():
         L.plo_bam_window_unmapped.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.plo_bam_window_batch.restype = C.c_int
         L.plo_bam_window_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
+        L.plo_bam_open_device.restype = C.c_int
+        L.plo_bam_open_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        L.plo_bam_set_device_inflate.restype = None
+        L.plo_bam_set_device_inflate.argtypes = [vp, C.c_int]
         L.plo_bam_window_batch_sparse.restype = C.c_int
         L.plo_bam_window_batch_sparse.argtypes = [vp, C.c_uint32, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
         L.plo_sparse_seq_bound.restype = C.c_uint64
@@ -176,9 +180,12 @@ class Window:
 
 
 class BamReader:
-    def __init__(self, path: str, n_threads: int = 4):
+    def __init__(self, path: str, n_threads: int = 4, device_inflate: Optional[int] = None):
+        """device_inflate: HIP device index = BGZF blocks are inflated on that GPU (plo_bam_set_device_inflate), -1 / False = on the
+        host; None = the environment (PLO_BGZF_DEVICE) decides, host inflate by default"""
         h = C.c_void_p()
-        _check(lib().plo_bam_open(path.encode(), n_threads, C.byref(h)), f"plo_bam_open({path})")
+        dev = -2 if device_inflate is None else (-1 if device_inflate is False else int(device_inflate))
+        _check(lib().plo_bam_open_device(path.encode(), n_threads, dev, C.byref(h)), f"plo_bam_open({path})")
         self.handle = h
         text, lt, n = C.c_char_p(), C.c_uint32(), C.c_uint32()
         names, lens = C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint32)()

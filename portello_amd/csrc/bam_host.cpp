@@ -48,11 +48,18 @@ extern "C" {
 
 const char *plo_bam_last_error(void) { return g_bam_err.c_str(); }
 
-plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out) {
+plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out) { return plo_bam_open_device(path, n_threads, -2, out); }
+plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_bam_reader **out) {
     if (!path || !out) return PLO_ERR_INVALID_ARG;
     *out = nullptr;
     plo_bam_reader *r = new plo_bam_reader();
     r->threads = std::max(1, n_threads);
+    if (device >= 0) {  // BGZF blocks on that GPU from the first refill on (plo_bam_set_device_inflate)
+        r->in.device = -2;
+        r->in.dev_id = device;
+    } else if (device == -1) {
+        r->in.device = 0;
+    }
     plo_status st = r->in.open(path, r->threads);
     auto bail = [&](plo_status s) {
         r->in.close();
@@ -173,6 +180,11 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     return PLO_OK;
 }
 
+void plo_bam_set_device_inflate(plo_bam_reader *r, int device) {
+    if (!r) return;
+    r->in.device = device >= 0 ? -2 : 0;  // decided at the next refill (PLO_BGZF_DEVICE in the environment overrides)
+    r->in.dev_id = device >= 0 ? device : 0;
+}
 void plo_bam_window_free(plo_bam_window *w) { delete w; }
 uint32_t plo_bam_window_n_records(const plo_bam_window *w) { return w ? w->n_records() : 0; }
 void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records) {

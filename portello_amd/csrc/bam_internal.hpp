@@ -26,6 +26,7 @@ void plo_bam_set_error(const std::string &msg);
 extern "C" uint32_t plo_internal_bgzf_slots(void);  // blocks the device inflates at once (one per resident wave); 0 without a device
 extern "C" void plo_internal_bgzf_acquire(void);
 extern "C" void plo_internal_bgzf_release(void);
+extern "C" int plo_internal_bgzf_set_device(int dev);
 extern "C" int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);
 extern "C" int plo_internal_bgzf_wait(int slot);
 extern "C" int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
@@ -177,7 +178,8 @@ struct BgzfIn {
     int threads = 1;
     bool eof = false;
     uint32_t dev_slots = 0;
-    int device = -1;  // -1 undecided, 0 host inflate, 1 blocks of a chunk are inflated on the GPU (PLO_BGZF_DEVICE=1 switches it on)
+    int dev_id = 0;  // HIP device of the device inflate
+    int device = -1;  // -1 undecided (environment), -2 undecided (requested), 0 host inflate, 1 blocks are inflated on the GPU
     static constexpr size_t CHUNK = 256u << 20;
     struct DevBlk {  // engine.hip's BgzfBlk
         unsigned long long coff, uoff;
@@ -225,13 +227,18 @@ struct BgzfIn {
             // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 20 GB/s, three times what 16 host cores do with
             // libdeflate -- but staging the compressed bytes in page-locked memory and checking the CRCs afterwards cost those cores
             // nearly as much as inflating: pipelined with the device, a refill takes as long as on the host
-            const char *e = getenv("PLO_BGZF_DEVICE");
-            device = (e && atoi(e) != 0) ? 1 : 0;
+            const char *e = getenv("PLO_BGZF_DEVICE");  // the environment has the last word; -2: asked for through plo_bam_set_device_inflate
+            device = e ? (atoi(e) != 0 ? 1 : 0) : (device == -2 ? 1 : 0);
             if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays
                 void *q = nullptr;
-                if (buf.p == nullptr && plo_host_alloc(CHUNK + CHUNK / 2, &q) == PLO_OK && q) {
+                const size_t cap0 = std::max<size_t>(CHUNK + CHUNK / 2, buf.n);
+                if (buf.pinned) {
+                    // (already page-locked)
+                } else if (plo_host_alloc(cap0, &q) == PLO_OK && q) {
+                    if (buf.n) memcpy(q, buf.p, buf.n);  // (switched on after the header was read)
+                    free(buf.p);
                     buf.p = (uint8_t *)q;
-                    buf.cap = CHUNK + CHUNK / 2;
+                    buf.cap = cap0;
                     buf.pinned = true;
                 } else {
                     device = 0;
@@ -304,7 +311,8 @@ struct BgzfIn {
                 return 0;
             };
             plo_internal_bgzf_acquire();
-            rc = begin(0);
+            rc = plo_internal_bgzf_set_device(dev_id);
+            if (rc == 0) rc = begin(0);
             for (size_t g = 0; g < ng && rc == 0; ++g) {
                 int rn = g + 1 < ng ? begin(g + 1) : 0;
                 rc = finish(g);

@@ -1815,7 +1815,15 @@ InfSlot g_inf[2];
 std::mutex g_inf_mu;
 int g_inf_ok = -1;
 }  // namespace
+static int g_inf_dev = -1;  // the device the slots live on (the first one asked for)
 void plo_internal_bgzf_acquire(void) { g_inf_mu.lock(); }
+int plo_internal_bgzf_set_device(int dev) {  // under acquire(): makes `dev` the calling thread's device; -100 if the slots live elsewhere
+    if (dev < 0) dev = 0;
+    if (g_inf_dev >= 0 && g_inf_dev != dev) return -100;
+    if (hipSetDevice(dev) != hipSuccess) return -100;
+    g_inf_dev = dev;
+    return 0;
+}
 void plo_internal_bgzf_release(void) { g_inf_mu.unlock(); }
 int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
     if (slot < 0 || slot > 1) return -101;

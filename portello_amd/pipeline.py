@@ -67,12 +67,14 @@ class PipelineStats:
 def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: abi.IndexData, contig_names: Sequence[str],
                    ref_names: Sequence[str], ref_lens: Sequence[int], window_reads: int = 50_000, n_workers: int = 2,
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
-                   cmdline: str = "", sparse_margin: Optional[int] = 32) -> PipelineStats:
+                   cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True) -> PipelineStats:  # noqa: E501
     """sparse_margin: the windows' read bases go to the device as PLO_SEQ_BAM4_SPARSE (granules within that many bases of an indel;
-    the complete bases stay in the window's records for the engine's second look); None = dense bases"""
+    the complete bases stay in the window's records for the engine's second look); None = dense bases.  device_inflate: the BGZF
+    blocks of the input are inflated on the GPU (leaves the host cores to record assembly and output; falls back to the host without
+    a device), None = as the environment says"""
     st = PipelineStats()
     ixd = index_data.to_desc()
-    rd = bam.BamReader(in_path, io_threads)
+    rd = bam.BamReader(in_path, io_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
     wr = bam.BamWriter(out_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level, n_threads=io_threads)
