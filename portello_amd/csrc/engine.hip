@@ -35,6 +35,7 @@
 #include "index_pack.hpp"
 #include "inflate.hpp"
 #include "lift_core.hpp"
+#include "lane_core.hpp"
 
 using namespace plo;
 
@@ -389,6 +390,39 @@ __global__ __launch_bounds__(TILE_WAVES * 64) PLO_TILE_OCC void k_lift_tiles_sp(
                                                                   uint32_t n_tiles, int window, int big_thresh, int cap,
                                                                   uint32_t lds_per_wave) {
     lift_tiles_kernel<true, 0>(ix, bt, wk, stages, n_tiles, window, big_thresh, cap, lds_per_wave);
+}
+
+// ---- the lane-per-item kernel (lane_core.hpp): DOMINANT on HiFi batches -------------------------------------------------
+// Persistent waves over groups of 64 items of the two lane classes (light items without / with the shift stage), one lane per
+// item, every wave with its own LDS slice of capw dwords.
+constexpr int LANE_WAVES = 4;
+#ifndef PLO_LANE_WPE
+#define PLO_LANE_WPE 3
+#endif
+template <bool SP>
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6;
+    // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
+    const uint32_t nb = gridDim.x, per = nb >> 3, b = blockIdx.x;
+    const uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
+    const uint32_t tw = blockDim.x >> 6;
+    const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
+    WaveCtx ctx;
+    if (wk.slab_pre) {
+        ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
+        ctx.slab_left = SLAB_OPS;
+    }
+    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
+    wave_ctx_flush(wk, ctx, wave);
+}
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                   uint32_t n1, int capw) {
+    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw);
+}
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                      uint32_t n1, int capw) {
+    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
@@ -766,10 +800,11 @@ struct plo_ctx {
     int n_cus = 256;
     int tile_waves = TILE_WAVES;
     bool small_window_tight = false;  // the 256-element slice re-ran too many items with the wide window: keep 64 elements of allowance
-    // (a lane-per-item kernel for short CIGARs was measured in round 1: forward items 1.6x faster than the tile kernel of that
-    // time, reverse items 0.8x -- per-lane homology probes serialise HBM latency -- a net loss; removed.  The class order
-    // it needed stays: tiles are strand-homogeneous.)
-    int lane_max_in = -1;
+    // lane-per-item kernel (lane_core.hpp): items up to lane_max_w (item_weight) take it, 64 per wave, every wave with an LDS
+    // slice of lane_capw dwords; heavier items take the wave-cooperative kernels below.  (Round 1's first attempt at one lane
+    // per item -- 36 KB of LDS per wave, synchronous probes -- was a net loss and had been removed; this is a different kernel.)
+    int lane_max_w = 192;
+    int lane_capw = 3072;
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1001,6 +1036,11 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     }
     if (const char *e = getenv("PLO_MID_CAP")) c->mid_cap_max = std::min(4096, std::max(256, atoi(e) & ~63));
     (void)hipFuncSetAttribute((const void *)k_lift_retry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
+    if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e)));
+    if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e)), c->adaptive = false;
     if (const char *e = getenv("PLO_BIG_THRESH")) c->big_thresh = std::max(1, atoi(e)), c->adaptive = false;
@@ -1186,7 +1226,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.item_cls = c->item_cls.as<uint32_t>();
     wk.perm = c->perm.as<uint32_t>();
     wk.retry_list = c->retry_list.as<uint32_t>();
-    wk.lane_max_in = c->lane_max_in;
+    wk.lane_max_w = c->lane_max_w;
     wk.item_op_prefix = c->op_prefix.as<uint32_t>();
     wk.d.in_off = c->d_in_off.as<uint32_t>();
     wk.d.n_in = c->d_n_in.as<uint32_t>();
@@ -1254,7 +1294,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                         (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>(),
                                         c->cls1.as<uint32_t>(), c->cls2.as<uint32_t>());
         plo_status s = PLO_OK;
-        if (c->lane_max_in < 0) {
+        if (c->lane_max_w < 0) {
             // lane kernel off: every item is "large" (classes 2 and 3 only), the ranks of classes 0 and 1 are all zero
             HIP_TRY(c, hipMemsetAsync(c->rank0.p, 0, ((size_t)n_items + 1) * 4, st));
             HIP_TRY(c, hipMemsetAsync(c->rank1.p, 0, ((size_t)n_items + 1) * 4, st));
@@ -1274,7 +1314,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
     }
-    uint32_t total_ops = 0, max_nin = 0, n_small = 0;
+    uint32_t total_ops = 0, max_nin = 0, n_small = 0, h_cls[2] = {0, 0};
     unsigned long long all_ops = 0;
     {
         HIP_TRY(c, c->misc.ensure(256));
@@ -1301,6 +1341,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         total_ops = h[0];  // weight of the tiled items
         max_nin = h[1];
         n_small = n_items ? h[2] + h[3] : 0;
+        h_cls[0] = n_items ? h[2] : 0;
+        h_cls[1] = n_items ? h[3] : 0;
         all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
         if (all_ops > 0x7fffffffull) {  // op indices are int: the weights bound the ops of every stage, output included
             c->err = "batch too large: the item weights (CIGAR ops + 2 x block-map entries) sum to more than 2^31; split the batch";
@@ -1346,7 +1388,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.n_small = n_small;
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
-    size_t want_cigar = (size_t)all_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS;
+    size_t want_cigar = (size_t)all_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS +
+                        (n_small ? (size_t)std::min<uint32_t>((n_small >> 8) + 8, (uint32_t)c->n_cus * 16) * LANE_WAVES * SLAB_OPS : 0);
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     if (c->seq_pending) {  // (plo_liftover_batch: the read bases arrive on the copy stream)
@@ -1361,6 +1404,24 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.out_cap = c->o_cigar.cap / 4;
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
         if (attempt == 0) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+        wk.slab_pre = 0;
+        wk.slab_offset = 0;
+        if (n_small) {
+            const uint32_t n0 = h_cls[0], n1 = h_cls[1];
+            const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
+            const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
+            int occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lds) != hipSuccess || occ < 1)
+                occ = 1;
+            uint32_t nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
+            nblk = (nblk + 7u) & ~7u;
+            wk.slab_pre = 1u;  // first slab by wave id
+            wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
+            PLO_STAT_RANGE(nblk * LANE_WAVES);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
+            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
+            HIP_TRY(c, hipGetLastError());
+        }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
         if (n_items > n_small) {
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
@@ -1376,7 +1437,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             nblk = std::min<uint32_t>(nblk, (uint32_t)(c->n_cus * occ));
             nblk = (nblk + 7u) & ~7u;
             wk.slab_pre = n_small == 0 ? 1u : 0u;  // nothing has been reserved yet (the lane kernel did not run)
-            wk.slab_offset = wk.slab_pre ? (unsigned long long)nblk * tw * SLAB_OPS : 0ull;
+            if (wk.slab_pre) wk.slab_offset = (unsigned long long)nblk * tw * SLAB_OPS;  // (else: the lane kernel's waves own the first slabs)
             PLO_STAT_RANGE(nblk * tw);
             if (sp)
                 hipLaunchKernelGGL(k_lift_tiles_sp, dim3(nblk), dim3(tw * 64), lds_per_wave * tw, st, ix, bt, wk, stages, n_tiles, c->window,
@@ -1392,8 +1453,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         } else {
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
         }
-        if (n_items > n_small) {
-            // Items of tiles whose intermediates overflowed the slice, one per wave with a slice of twice the threshold (the shift /
+        if (n_items) {
+            // Items of tiles whose intermediates overflowed the slice (and items the lane kernel handed on), one per wave with a slice of twice the threshold (the shift /
             // simplify stages at most double an item's ops).  Launched without asking the host how many there are: the kernel reads
             // the count the tile kernel left (mostly zero -- a few microseconds -- and a host round trip less when it is not).
             const int retry_cap = std::min(4096, std::max(c->cap, (2 * c->big_thresh + 64 + 63) & ~63));

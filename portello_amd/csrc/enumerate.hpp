@@ -182,7 +182,7 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     wk.item_cseg[i] = cseg;
     wk.item_nin[i] = (uint32_t)item_weight((int)n_in, w0, w1, kv1);  // tiling weight
     wk.item_cls[i] = (((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u) |
-                     ((wk.lane_max_in < 0 || n_in > (uint32_t)wk.lane_max_in) ? 2u : 0u);
+                     ((wk.lane_max_w < 0 || item_weight((int)n_in, w0, w1, kv1) > wk.lane_max_w) ? 2u : 0u);
     wk.d.in_off[i] = in_off;
     wk.d.n_in[i] = n_in;
     wk.d.pos1[i] = (int)pos1;

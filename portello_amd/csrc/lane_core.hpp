@@ -1,0 +1,842 @@
+// lane_core.hpp -- the lane-per-item formulation of the liftover pipeline: 64 items per wave, one LANE per item.
+//
+// lift_core.hpp spreads the ops of a tile over the lanes and recasts the reference's sequential state as wave scans: ~26
+// wave-instructions per input op, a dozen passes over the op stream.  HiFi read->contig CIGARs have ~30 ops, and 64 of them fit
+// a wave's LDS slice comfortably -- so here every lane walks ITS item sequentially, exactly as the reference's loops do, and the
+// wave only cooperates where items meet: LDS allocation (one add-scan), output allocation (one add-scan), loop bounds (ballots).
+// What makes that cheap on CDNA4, where a straightforward per-lane transliteration is not (round 1: 36 KB of LDS per wave, i.e.
+// 4 waves per CU; a memory round trip per indel cluster in the middle of the walk):
+//   * one compact LDS region per item (weight + slack dwords, ~180 B), used IN PLACE by every stage: the liftover reads its
+//     input at the region's upper end and writes its output from the bottom -- pieces <= ops + 2 per block crossed, and the
+//     gap in front of the input is exactly that allowance; 64 regions ~ 11 KB per wave -> 12-13 waves per CU;
+//   * clean_up_cigar_edge_indels + compress_cigar as a STREAMING writer (LaneOut): leading edge and run merging while the ops
+//     are produced, the (short) trailing edge fixed in place afterwards -- no extra passes, no second buffer;
+//   * the liftover as one FLAT loop over (op x block) pieces with a three-entry cursor into the block map (current block, next
+//     block, the one after it in flight), so that a crossing costs no search and no wait;
+//   * the left shift's homology probes ISSUED at the end of an indel cluster and CONSUMED at the next one (the emission of a
+//     cluster is deferred until then): the HBM round trip runs under the walk of the following ops.
+// Items whose region overflows, or that are too heavy for a region, go to the wave-cooperative code of lift_core.hpp (retry /
+// large-item lists), which remains the general path.
+//
+// All citations are relative to /root/reference.
+#pragma once
+#include <plo_wave.hpp>
+#include <stdint.h>
+
+#include "lift_core.hpp"
+
+#ifdef PLO_EMULATOR
+#define PLO_MARK(s)
+#else
+#define PLO_MARK(s) asm volatile("; " s)  // a comment in the ISA listing (tools: hipcc -S), no code
+#endif
+
+namespace plo {
+
+constexpr int LANE_SLACK = 2;  // dwords on top of an item's weight (the shift stage may add an op per cluster in odd cases)
+
+// -------------------------------------------------------------------------------------------------------------------
+// Streaming clean_up_cigar_edge_indels + compress_cigar (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:265-291, 204-228).
+// Ops are pushed in order; the writer applies the LEADING edge rule on the fly (before the first alignment match: D -> S(0),
+// its length added to the position shift; I -> S), drops zero-length ops and merges equal neighbours (accumulator = last_elem,
+// starting as Match(0), :206).  lane_out_finish() flushes the accumulator and applies the TRAILING edge rule to the ops behind
+// the last match (they are few), merging again.  Merging before the trailing rule instead of after it gives the same result:
+// the rule maps every I of the tail to S and removes every D of the tail, whatever runs they were merged into.
+// "The last match op" is tracked as the last match op WRITTEN.  No stage emits a zero-length match op, but the simplify stage
+// copies what it is given: a zero-length M / = / X in its input (raw CIGARs, stage subsets without the liftover) would mark an
+// edge without being written -- such an item is handed to the wave-cooperative code (`ovf`).
+//
+// Code shape: the per-lane state is integers and lane_push() is straight-line code (selects, one predicated LDS store).
+// Lane-divergent branches around it cost more than the work they skip: every boolean that is live across a divergent join
+// becomes a lane mask in scalar registers that the compiler merges with three scalar instructions per join (the first version
+// of this file spent more scalar than vector instructions).
+// -------------------------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) Ops4 {  // four CIGAR ops, loaded / stored as one 16-byte access at any 4-byte address
+    uint32_t x, y, z, w;
+};
+struct LaneOut {
+    uint32_t *R = nullptr;  // the lane's region
+    int no = 0;             // ops written
+    uint32_t acc = 0;       // the open run, (len << 4) | type; starts as Match(0)
+    int last_m = -1;        // index of the last match op written
+    int lead_shift = 0;
+    int seen_m = 0;
+    int pairs = 0;          // two neighbouring I / D ops were written: an indel cluster of more than one op
+    int ovf = 0;            // a write would have passed `wlim`
+};
+PLO_DEV int wrap_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+PLO_DEV int i_is_match(int t) { return (0x181 >> t) & 1; }   // M = X
+PLO_DEV int i_is_indel(int t) { return (0x006 >> t) & 1; }   // I D
+PLO_DEV int i_ref_cons(int t) { return (0x18D >> t) & 1; }   // M D N = X
+PLO_DEV int i_read_cons(int t) { return (0x1B3 >> t) & 1; }  // M I S H = X
+// `on`: 0 / 1.  `wlim`: first index that must not be written (the reader's position when the region is used in place)
+PLO_DEV void lane_push(LaneOut &o, int on, int t, int L, int wlim) {
+    const int lead = on & (o.seen_m ^ 1);
+    const int drop_d = lead & (int)(t == OP_D);
+    o.lead_shift += drop_d ? L : 0;
+    t = (lead & (int)(t == OP_I)) ? (int)OP_S : t;
+    const int ismt = i_is_match(t);
+    o.seen_m |= on & ismt;
+    o.ovf |= on & ismt & (int)(L == 0);
+    const int live = on & (drop_d ^ 1) & (int)(L > 0);
+    const int at = (int)(o.acc & 15u);
+    const int same = live & (int)(t == at);
+    const int flush = live & (same ^ 1) & (int)(o.acc >= 16u);
+    const int ok = (int)(o.no < wlim);
+    if (flush & ok) o.R[o.no] = o.acc;
+    o.ovf |= flush & (ok ^ 1);
+    o.pairs |= flush & i_is_indel(at) & i_is_indel(t);
+    o.last_m = (flush & i_is_match(at)) ? o.no : o.last_m;
+    o.no += flush;
+    // Pad is absent from the summing pattern (:210-212): a Pad following a Pad adds nothing
+    const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
+    o.acc = same ? o.acc + add : (live ? mk_op(t, L) : o.acc);
+}
+// wave-uniform call (the tail loop is bounded by a ballot); `on`: lanes that own a writer
+PLO_DEV void lane_out_finish(LaneOut &o, int on, int wlim) {
+    {
+        const int flush = on & (int)(o.acc >= 16u);
+        const int ok = (int)(o.no < wlim);
+        if (flush & ok) o.R[o.no] = o.acc;
+        o.ovf |= flush & (ok ^ 1);
+        o.last_m = (flush & i_is_match((int)(o.acc & 15u))) ? o.no : o.last_m;
+        o.no += flush;
+    }
+    // trailing edge: ops behind the last match (none was written: everything went through the leading rule already)
+    const int fix = on & (o.ovf ^ 1) & o.seen_m & (int)(o.last_m + 1 < o.no);
+    int i = o.last_m + 1, w = o.last_m + 1;
+    uint32_t run = 0;  // open run of the rewritten tail (0: none)
+    while (wv::ballot(fix && i < o.no) != 0ull) {
+        const int act = fix & (int)(i < o.no);
+        const uint32_t c = o.R[act ? i : 0];
+        int t = op_type(c);
+        const int L = op_len(c);
+        i += act;
+        const int keep = act & (int)(t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
+        t = (t == OP_I) ? (int)OP_S : t;
+        const int same = keep & (int)(run >= 16u) & (int)(t == (int)(run & 15u));
+        const int flush = keep & (same ^ 1) & (int)(run >= 16u);
+        if (flush) o.R[w] = run;
+        w += flush;
+        const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
+        run = same ? run + add : (keep ? mk_op(t, L) : run);
+    }
+    {
+        const int flush = fix & (int)(run >= 16u);
+        if (flush) o.R[w] = run;
+        w += flush;
+        o.no = fix ? w : o.no;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// xor_window16 (lift_core.hpp) in two halves for the dense sequence formats: the loads now, the decode later.
+// -------------------------------------------------------------------------------------------------------------------
+struct XW16 {
+    unsigned wr[5], wq[5];
+    int rsh, qsh, jmin;
+};
+PLO_DEV bool xw16_issue(const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, XW16 &w) {
+    if (rd.fmt == PLO_SEQ_BAM4_SPARSE) return false;  // granule look-ups first: those batches probe synchronously
+    if (r0 < 0 || q0 < 0 || q0 > rd.len - 16) return false;
+    const int rsh = (int)(((unsigned)(uintptr_t)ref + (unsigned)r0) & 3u);
+    if (r0 - rsh < 0 || r0 - rsh > ref_len - 20) return false;
+    const int jmin = rd.flip ? rd.len - q0 - 16 : q0;
+    const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
+    const int b0 = bam4 ? (jmin >> 1) : jmin;
+    const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
+    const int qwords = bam4 ? 3 : 5;
+    if (b0 - qsh < rd.lo || b0 - qsh + 4 * qwords > rd.hi) return false;
+    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ref + (r0 - rsh));
+    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(rd.p + (b0 - qsh));
+#pragma unroll
+    for (int u = 0; u < 5; ++u) w.wr[u] = pr[u];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) w.wq[u] = u < qwords ? pq[u] : 0u;
+    w.rsh = rsh;
+    w.qsh = qsh;
+    w.jmin = jmin;
+    return true;
+}
+PLO_DEV void xw16_decode(const ReadSeq &rd, const XW16 &w, unsigned X[4]) {
+    const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
+    unsigned D[4];
+    if (bam4) {
+        unsigned S[5];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            unsigned Q = wv::align_bytes(w.wq[q + 1], w.wq[q], (unsigned)w.qsh);
+            unsigned H = (Q >> 4) & 0x0f0f0f0fu, L = Q & 0x0f0f0f0fu;
+            S[2 * q] = wv::perm_bytes(L, H, 0x05010400u);
+            if (2 * q + 1 < 5) S[2 * q + 1] = wv::perm_bytes(L, H, 0x07030602u);
+        }
+        const unsigned par = (unsigned)(w.jmin & 1);
+        const unsigned long long lo = rd.flip ? 0x4e4e4e434e47544eull : 0x565352474d43413dull;
+        const unsigned long long hi = rd.flip ? 0x4e4e4e4e4e4e4e41ull : 0x4e42444b48595754ull;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            unsigned T = wv::align_bytes(S[v + 1], S[v], par);
+            unsigned idx = T & 0x07070707u;
+            unsigned dl = wv::perm_bytes((unsigned)(lo >> 32), (unsigned)lo, idx);
+            unsigned dh = wv::perm_bytes((unsigned)(hi >> 32), (unsigned)hi, idx);
+            unsigned mk = ((T >> 3) & 0x01010101u) * 0xffu;
+            D[v] = (dh & mk) | (dl & ~mk);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            D[v] = wv::align_bytes(w.wq[v + 1], w.wq[v], (unsigned)w.qsh);
+            if (rd.flip) D[v] = comp4(D[v]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned R = wv::align_bytes(w.wr[u + 1], w.wr[u], (unsigned)w.rsh);
+        unsigned B = rd.flip ? wv::perm_bytes(0u, D[3 - u], 0x00010203u) : D[u];
+        X[u] = R ^ B;
+    }
+}
+
+// The left breakend homology of one indel cluster (left_homology, lift_core.hpp), split in two: lane_probe_issue() does the
+// index checks of indel_breakend_homology.rs:32-39 and sends the loads of the first 16-base window; lane_probe_finish() turns
+// them into the match run and continues window by window (synchronously) in the rare case that all 16 bases agree.
+struct LaneProbe {
+    XW16 w;
+    int re = 0, qe = 0, maxk = 0;
+    int async_ok = 0;
+};
+// `on`: the lanes whose cluster ends (0 / 1); sets their `panic` where the reference's slice index would
+PLO_DEV void lane_probe_issue(LaneProbe &p, int on, const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins,
+                              int bound, int &panic) {
+    const int re = rs + del, qe = qs + ins;
+    const int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
+    int maxk = wv::imin(max_left, bound);
+    const int bad = (int)(max_left > 0) & ((int)(re - 1 >= ref_len) | (int)(qe - 1 >= rd.len));  // slice-index panic (:38-39)
+    panic |= on & bad;
+    maxk = bad ? 0 : maxk;
+    int ok = 0;
+    if (on && maxk > 0) ok = xw16_issue(ref, ref_len, re - 16, rd, qe - 16, p.w) ? 1 : 0;
+    p.re = on ? re : p.re;
+    p.qe = on ? qe : p.qe;
+    p.maxk = on ? maxk : p.maxk;
+    p.async_ok = on ? ok : p.async_ok;
+}
+PLO_DEV int match_run_back_from(const uint8_t *ref, int ref_len, int re, ReadSeq &rd, int qe, int maxk, int k, int &probes) {
+    while (k < maxk) {
+        unsigned X[4];
+        if (!xor_window16(ref, ref_len, re - k - 16, rd, qe - k - 16, X)) break;
+        int n = wv::imin(16, maxk - k);
+        int m = wv::imin(zero_bytes_from_top(X), n);
+        probes += wv::imin(m + 1, n);
+        k += m;
+        if (m < n) return k;
+    }
+    while (k < maxk) {
+        int n = wv::imin(8, maxk - k);
+        int a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int jj = j < n ? j : 0;
+            a[j] = ((const PLO_GLOBAL uint8_t *)ref)[re - 1 - k - jj];
+            b[j] = read_base(rd, qe - 1 - k - jj);
+        }
+        int adv = n;
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+            if (j < n && a[j] != b[j]) adv = j;
+        probes += wv::imin(adv + 1, n);
+        k += adv;
+        if (adv < n) break;
+    }
+    return k;
+}
+PLO_DEV int top_zero_bytes(const unsigned X[4]) {  // zero_bytes_from_top without branches
+    const unsigned long long hi = ((unsigned long long)X[3] << 32) | X[2], lo = ((unsigned long long)X[1] << 32) | X[0];
+    const int zh = hi ? (__builtin_clzll(hi) >> 3) : 8, zl = lo ? (__builtin_clzll(lo) >> 3) : 8;
+    return hi ? zh : 8 + zl;
+}
+// wave-uniform call; `on`: the lanes whose pending cluster is resolved now
+PLO_DEV int lane_probe_finish(const LaneProbe &p, int on, const uint8_t *ref, int ref_len, ReadSeq &rd, int &probes) {
+    unsigned X[4];
+    xw16_decode(rd, p.w, X);  // (registers only: harmless where nothing was loaded)
+    const int n = wv::imin(16, p.maxk);
+    const int m = wv::imin(top_zero_bytes(X), n);
+    const int live = on & (int)(p.maxk > 0);
+    const int fast = live & p.async_ok;
+    int h = fast ? m : 0;
+    probes += fast ? wv::imin(m + 1, n) : 0;
+    // the window lay outside a buffer (first / last bases of a sequence), the batch is sparse, or all 16 bases agree and the
+    // match run allows more: window by window from there
+    const int more = live & ((p.async_ok ^ 1) | ((int)(m == n) & (int)(n < p.maxk)));
+    if (wv::ballot(more != 0) != 0ull) {
+        if (more) h = match_run_back_from(ref, ref_len, p.re, rd, p.qe, p.maxk, h, probes);
+    }
+    return h;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords (+ one spare dword behind it).
+// -------------------------------------------------------------------------------------------------------------------
+template <bool SP>
+PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
+                       uint32_t *lds, int capw, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre) {
+    const int lane = wv::lane();
+    const bool has = lane < nit;
+    const uint32_t g = have_g ? g_pre : (has ? list[item_begin + (uint32_t)lane] : 0u);
+#ifdef PLO_PHASE_TIMING
+    long long tlast = wv::clock();
+#define PLO_LT(k)                     \
+    {                                 \
+        long long now_ = wv::clock(); \
+        ctx.tph[k] += now_ - tlast;   \
+        tlast = now_;                 \
+    }
+#else
+#define PLO_LT(k)
+#endif
+
+    // ---- descriptors (build_item_desc, enumerate.hpp) ----
+    int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0, shift_ref_len = 0;
+    bool len_bad = false, rev = false, do_shift = false, flip = false;
+    unsigned long long seq_off = 0, shift_ref = 0;
+    if (has) {
+        in_off = (int)wk.d.in_off[g];
+        n_in = (int)wk.d.n_in[g];
+        W0 = (int)wk.d.w0[g];
+        W1 = (int)wk.d.w1[g];
+        kv0 = (int)wk.d.kv0[g];
+        kv1 = (int)wk.d.kv1[g];
+        const uint32_t fl = wk.d.flags[g];
+        pos1 = wk.d.pos1[g];
+        seq_len = (int)wk.d.seq_len[g];
+        const uint32_t read_len_in = wk.d.read_len[g];
+        len_bad = read_len_in == 0xffffffffu || (uint32_t)seq_len != read_len_in;  // LENGTH CHECK, see lift_tile
+        seq_off = wk.d.seq_off[g];
+        shift_ref = wk.d.shift_ref[g];
+        shift_ref_len = wk.d.shift_ref_len[g];
+        rev = (fl & ITF_REV) != 0;
+        flip = (fl & ITF_FLIP) != 0;
+        const bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
+        do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
+    }
+    const int nblk = has ? wv::imax(0, wv::imin(W1 + 1, kv1) - W0) : 0;
+    const int gap = 2 * nblk;               // room in front of a stage's input: what the liftover may add to it
+    const int W = n_in + gap + LANE_SLACK;  // the item's region, dwords
+
+    // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
+    bool pending = has;
+    {
+        const bool defer = has && W > capw;
+        const unsigned long long dm = wv::ballot(defer);
+        if (dm != 0ull) {
+            int slot = 0;
+            if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NRETRY], (unsigned long long)__builtin_popcountll(dm));
+            slot = wv::bcast_first(slot);
+            if (defer) {
+                wk.retry_list[slot + __builtin_popcountll(dm & ((1ull << lane) - 1ull))] = g;
+                wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+                pending = false;
+            }
+        }
+    }
+
+    // ---- rounds: the longest prefix of the pending items whose regions fit the slice (nearly always all of them) ----
+    while (wv::ballot(pending) != 0ull) {
+        const int wv_ = pending ? W : 0;
+        const int incl = wv::scan_add(wv_);
+        const bool act0 = pending && incl <= capw;
+        pending = pending && !act0;
+        uint32_t *const R = lds + (act0 ? incl - wv_ : 0);
+        wv::sync();  // the previous round's regions are dead
+
+        int status = PLO_ITEM_LIFTED;
+        bool alive = act0;
+        int shift_on = (act0 && do_shift) ? 1 : 0;
+        if (shift_on && shift_ref == 0ull) {  // rev_contig_seq.unwrap() on None (src/read_alignment_scanner.rs:174)
+            status = PLO_ITEM_PANIC;
+            alive = false;
+            shift_on = 0;
+        }
+        int ovf = 0, panic = 0;
+        unsigned algo = 0;
+        int cur_off = 0, n = 0;  // the item's current CIGAR: R[cur_off .. cur_off + n)
+        int pos = pos1;
+        ReadSeq rd = item_read_seq<SP>(bt, seq_off, seq_len, flip ? 1 : 0);
+        PLO_LT(0)
+
+        // ---- LOAD: input ops -> LDS, reversed for reverse-mapped contig segments (:167) --------------------------------------
+        // Items of the shift stage: at the region's upper end (the shift writes from `gap` upwards behind its own reading
+        // position).  The others: at `gap`, where the liftover expects its input.  Neighbouring alignment-match ops (= X M) are
+        // merged into one M on the way when the next stage treats the three alike and merges what comes of them anyway: the
+        // shift builder (add_match: match_run += len, emitted as M, cigar_indel_shifter.rs:150-153,136) and the liftover (:102-109
+        // turn every match piece into M, compress_cigar :220 merges the pieces of neighbouring ops).  Same result, a third fewer
+        // ops to walk -- and the ops of a shifted item then alternate match / cluster, which is what keeps its scans short.
+        {
+            const int ld = act0 ? 1 : 0;
+            const int merge = ld & (shift_on | ((stages & PLO_STAGE_LIFTOVER) ? 1 : 0));
+            const int inb = shift_on ? W - n_in : gap;
+            const int nmax = wv::reduce_max(ld ? n_in : 0);
+            uint32_t run = 0;
+            int has_run = 0, w = 0;
+            // 16 bytes per load and lane (every lane reads its own CIGAR: four ops per request instead of one), two in flight
+            for (int k0 = 0; k0 < nmax; k0 += 8) {
+                uint32_t r[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int kq = k0 + 4 * q;
+                    uint32_t a[4] = {0u, 0u, 0u, 0u};
+                    if (ld && kq + 3 < n_in) {  // the ops kq .. kq+3 in walking order are four neighbours in memory
+                        const Ops4 v = *(const PLO_GLOBAL Ops4 *)(bt.cigar + (in_off + (rev ? n_in - 4 - kq : kq)));
+                        a[0] = rev ? v.w : v.x;
+                        a[1] = rev ? v.z : v.y;
+                        a[2] = rev ? v.y : v.z;
+                        a[3] = rev ? v.x : v.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ld && kq + j < n_in) a[j] = bt.cigar[in_off + (rev ? (n_in - 1 - kq - j) : kq + j)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[4 * q + j] = a[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int have = ld & (int)(k0 + j < n_in);
+                    const uint32_t c = r[j];
+                    const int ism = i_is_match(op_type(c));
+                    const int join = merge & have & has_run & ism & i_is_match(op_type(run));
+                    const int flush = have & has_run & (join ^ 1);
+                    if (flush) R[inb + w] = run;
+                    w += flush;
+                    run = join ? ((run & ~15u) + (c & ~15u)) | (uint32_t)OP_M : (have ? c : run);
+                    has_run |= have;
+                }
+            }
+            if (ld & has_run) R[inb + w] = run;
+            w += ld & has_run;
+            n = ld ? w : 0;
+            cur_off = ld ? inb : 0;
+        }
+        wv::sync();
+
+        PLO_LT(1)
+        // ---- LEFT SHIFT (left_shift_indels.rs:17-39 + cigar_indel_shifter.rs:10-165) -------------------------------------------
+        // EVENT-ALIGNED walk: a round = every lane scans its ops (cheap) up to its next event -- the end of an indel cluster, an
+        // op that flushes the builder's match run (:155-165), or the end of the CIGAR -- and then all lanes run the event code
+        // together, so that the expensive part (probe decode, emission) executes with most lanes active instead of with the
+        // fifth that sits on a cluster end at any given op index.
+        // The emission of a cluster (M I D, :132-147) needs its homology; the probe is sent when the cluster ends and the cluster
+        // stays `pend`ing -- match bases that follow collect in `msince` -- until the lane's next event: its probe's HBM round trip
+        // runs under the scan in between.
+        if (wv::ballot(shift_on != 0) != 0ull) {
+            const uint8_t *const sref = (const uint8_t *)(uintptr_t)shift_ref;
+            LaneOut o;
+            o.R = R + gap;
+            const int wl0 = cur_off - gap;  // the writer may use what lies below the reader: index < wl0 + ops consumed
+            int k = 0, fin = shift_on ^ 1;
+            int ref_head = pos1, read_head = 0, match = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0, in_blk = 0;
+            int pend = 0, p_match = 0, p_ins = 0, p_del = 0, msince = 0, probes = 0;
+            LaneProbe pr;
+            PLO_MARK("SHIFT LOOP BEGIN");
+            while (wv::ballot(fin == 0) != 0ull) {
+                // scan to the next event (not consumed)
+                int stop = fin, ev_t = 0, ev_L = 0, ev_other = 0, ev_end = 0;
+                while (wv::ballot(stop == 0) != 0ull) {
+                    const int act = stop ^ 1;
+                    const int have = (int)(k < n);
+                    const uint32_t c = R[cur_off + (have ? k : 0)];
+                    const int t = op_type(c), L = op_len(c);
+                    const int indel = have & i_is_indel(t);
+                    const int ism = have & i_is_match(t);
+                    const int other = have & (indel ^ 1) & (ism ^ 1);
+                    const int atend = have ^ 1;
+                    const int ev = act & ((in_blk & (ism | other | atend)) | other | atend);
+                    const int take = act & (ev ^ 1);
+                    const int memb = take & indel & (int)(L > 0);  // add_del / add_ins (:73-85, len > 0 only)
+                    const int open = memb & (in_blk ^ 1);
+                    blk_ref = open ? ref_head : blk_ref;
+                    blk_read = open ? read_head : blk_read;
+                    in_blk |= memb;
+                    del += (memb & (int)(t == OP_D)) ? L : 0;
+                    ins += (memb & (int)(t == OP_I)) ? L : 0;
+                    const int tm = take & ism;  // add_match (:150-153)
+                    msince += (tm & pend) ? L : 0;
+                    match += (tm & (pend ^ 1)) ? L : 0;
+                    read_head += (take & i_read_cons(t)) ? L : 0;
+                    ref_head += (take & i_ref_cons(t)) ? L : 0;
+                    k += take;
+                    ev_t = ev ? t : ev_t;
+                    ev_L = ev ? L : ev_L;
+                    ev_other = ev ? other : ev_other;
+                    ev_end = ev ? atend : ev_end;
+                    stop |= ev;
+                }
+                // the event
+                const int evl = fin ^ 1;             // lanes with an event
+                const int endc = evl & in_blk;       // end_indel (:101-148)
+                const int flushing = evl & (ev_other | ev_end);
+                const int wl = wl0 + k;
+                auto resolve = [&](int on) {  // end_indel's emission for the pending cluster (:132-147)
+                    int h = lane_probe_finish(pr, on, sref, shift_ref_len, rd, probes);
+                    h = rd.miss ? 0 : h;
+                    const int sh = wv::imin(p_match, h);  // actual_shift_len (:132)
+                    lane_push(o, on & (int)(p_match - sh > 0), OP_M, p_match - sh, wl);
+                    lane_push(o, on & (int)(p_ins > 0), OP_I, p_ins, wl);
+                    lane_push(o, on & (int)(p_del > 0), OP_D, p_del, wl);
+                    match = on ? sh + msince : match;
+                    msince = on ? 0 : msince;
+                    pend &= on ^ 1;
+                };
+                // Pass 0: the pending cluster first (every event needs the builder's match run), then this cluster's probe -- the match
+                // run is exact there, nothing is pending.  Pass 1 (rare): a cluster directly in front of a flushing op or of the end has
+                // no ops to hide its probe under and is resolved at once.  One copy of the code for both (the probe's slow paths are large).
+#pragma nounroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int res = (pass == 0 ? evl : flushing) & pend;
+                    if (wv::ballot(res != 0) != 0ull) resolve(res);
+                    if (pass == 1) break;
+                    if (wv::ballot(endc != 0) != 0ull) {
+                        lane_probe_issue(pr, endc, sref, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, panic);
+                        p_match = endc ? match : p_match;
+                        p_ins = endc ? ins : p_ins;
+                        p_del = endc ? del : p_del;
+                        ins = endc ? 0 : ins;
+                        del = endc ? 0 : del;
+                        in_blk &= endc ^ 1;
+                        pend |= endc;
+                    }
+                    if (wv::ballot((flushing & pend) != 0) == 0ull) break;
+                }
+                if (wv::ballot(flushing != 0) != 0ull) {  // add_other (:155-165); at the end: get_cigar()'s add_other(None) (:54-60)
+                    lane_push(o, flushing & (int)(match > 0), OP_M, match, wl);
+                    match = flushing ? 0 : match;
+                    const int oth = flushing & ev_other;
+                    lane_push(o, oth, ev_t, ev_L, wl + 1);
+                    read_head += (oth & i_read_cons(ev_t)) ? ev_L : 0;
+                    ref_head += (oth & i_ref_cons(ev_t)) ? ev_L : 0;
+                    k += oth;
+                    fin |= flushing & ev_end;
+                }
+            }
+            PLO_MARK("SHIFT LOOP END");
+            lane_out_finish(o, shift_on, wl0 + n);  // :35-38 clean_up_cigar_edge_indels + compress
+            if (shift_on) {
+                algo += 2u * (unsigned)probes;
+                n = o.no;
+                cur_off = gap;
+                pos += o.lead_shift;
+                ovf |= o.ovf;
+            }
+        }
+        if (act0 && (panic || rd.miss)) {  // absent bases (sparse batches) come first: what the probes saw then is not the read
+            status = rd.miss ? PLO_ITEM_NEED_BASES : PLO_ITEM_PANIC;
+            alive = false;
+        }
+        wv::sync();
+        PLO_LT(2)
+
+        // ---- LIFTOVER (src/liftover_read_alignment.rs:35-223) ---------------------------------------------------------------------
+        // One iteration = one (op x block) piece (update_ref2_cigar_segment, :35-133) or one copied op, straight-line.  Block
+        // cursor: {kb, vb} the block that holds block_pos (bvalid: there is one), {kn, vn} the next entry of the map, {kf, vf}
+        // the one after it, requested at the previous crossing.
+        int pairs = 1;
+        if (stages & PLO_STAGE_LIFTOVER) {
+            const int lo_on = (alive && !ovf) ? 1 : 0;
+            if (lo_on) {
+                int nb = kv1 - kv0, lg = 0;
+                while ((1 << lg) < nb) ++lg;
+                algo += 16u * (unsigned)(W1 - W0) + 8u * (unsigned)lg;
+            }
+            LaneOut o;
+            o.R = R;
+            int k = 0, in_op = 0, ism = 0, bvalid = 0, has_start = 0, has_end = 0;
+            int t = 0, seg_start = pos, seg_end = 0, block_pos = 0, r2s = 0, r2e = 0;
+            int kb = 0, vb = NONE32, kn = IMAX, vn = NONE32, kf = IMAX, vf = NONE32;
+            int ni = W0 + 2;  // index of the entry to request at the next crossing
+            if (lo_on) {
+                if (W0 < kv1) {
+                    const KV e = ix.kv[W0];
+                    kn = e.key;
+                    vn = e.val;
+                }
+                if (W0 + 1 < kv1) {
+                    const KV e = ix.kv[W0 + 1];
+                    kf = e.key;
+                    vf = e.val;
+                }
+            }
+            PLO_MARK("LIFTOVER LOOP BEGIN");
+            while (wv::ballot(lo_on && (k < n || in_op)) != 0ull) {
+                // the next op, unless one is being cut into pieces
+                const int fetch = lo_on & (in_op ^ 1) & (int)(k < n);
+                const uint32_t c = R[cur_off + (fetch ? k : 0)];
+                k += fetch;
+                const int tf = op_type(c), Lf = op_len(c);
+                const int copy = fetch & ((0x32 >> tf) & 1);  // I S H: :157-160 copied through; Pad (:213) emits nothing
+                const int start = fetch & i_ref_cons(tf) & (int)(Lf > 0);
+                t = start ? tf : t;
+                ism = start ? i_is_match(tf) : ism;
+                seg_end = start ? seg_start + Lf : seg_end;
+                block_pos = start ? seg_start : block_pos;
+                in_op |= start;
+                // the piece starts in the next block (get_ref_range walks on, read_to_ref_map.rs:79-84)
+                const int adv = in_op & (int)(kn <= block_pos);
+                int fk = IMAX, fv = NONE32;
+                if (adv && ni < kv1) {
+                    const KV e = ix.kv[ni];
+                    fk = e.key;
+                    fv = e.val;
+                }
+                kb = adv ? kn : kb;
+                vb = adv ? vn : vb;
+                bvalid |= adv;
+                kn = adv ? kf : kn;
+                vn = adv ? vf : vn;
+                kf = adv ? fk : kf;
+                vf = adv ? fv : vf;
+                ni += adv;
+                // (kn <= block_pos still: the shift stage moved the start past another key; the walk goes on next iteration)
+                const int piece = in_op & (int)(kn > block_pos);
+                const int pend = wv::imin(seg_end, kn);  // :62-67
+                const int plen = pend - block_pos;
+                const int mapped = bvalid & (int)(vb != NONE32);
+                const int mp = piece & mapped;
+                const int set_start = mp & ism & (has_start ^ 1);  // :84-88
+                r2s = set_start ? wrap_add(vb, block_pos - kb) : r2s;
+                has_start |= set_start;
+                const int d = wrap_add(vb, -r2e);  // :91-96 (wrapping: vb is NONE32 where the piece is not mapped, and then unused)
+                const int e0 = mp & has_end & (int)(d > 0) & has_start;
+                has_end |= mp;
+                r2e = mp ? wrap_add(vb, pend - kb) : r2e;  // :98-100
+                // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
+                const int e1p = piece & (mapped ? (ism | has_start) : ism);
+                const int t1p = mapped ? (t == OP_D ? (int)OP_D : (t == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
+                block_pos = piece ? pend : block_pos;
+                const int done = piece & (int)(pend >= seg_end);
+                in_op &= done ^ 1;
+                seg_start = done ? seg_end : seg_start;
+                const int wl = cur_off + k;  // ops below R[cur_off + k] have been read
+                lane_push(o, e0, OP_D, d, wl);
+                lane_push(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
+            }
+            PLO_MARK("LIFTOVER LOOP END");
+            PLO_LT(3)
+            lane_out_finish(o, lo_on, cur_off + n);  // :219-220
+            if (lo_on) {
+                ovf |= o.ovf;
+                if (!has_start) {  // :218 ref2_start_pos.map(...) on None
+                    status = PLO_ITEM_NO_LIFTOVER;
+                    alive = false;
+                } else {
+                    n = o.no;
+                    cur_off = 0;
+                    pos = r2s + o.lead_shift;  // :221
+                }
+                pairs = o.pairs;
+            }
+            wv::sync();
+        }
+
+        PLO_LT(4)
+        // ---- LENGTH CHECK (src/read_alignment_scanner.rs:204-229), decided from the descriptors (see lift_tile) ----
+        bool simp = alive && !ovf;
+        if ((stages & PLO_STAGE_LENCHECK) && simp && len_bad) {
+            status = PLO_ITEM_LEN_MISMATCH;
+            simp = false;
+        }
+
+        // ---- SIMPLIFY (src/simplify_alignment_indels.rs:5-156), in place ---------------------------------------------------------
+        // On a CIGAR the liftover has just cleaned and compressed the function is the identity unless some indel cluster has more
+        // than one op (see lift_tile); such items -- most -- take no part.
+        if (stages & PLO_STAGE_SIMPLIFY) {
+            const int s_on = (simp && (!(stages & PLO_STAGE_LIFTOVER) || pairs)) ? 1 : 0;
+            if (wv::ballot(s_on != 0) != 0ull) {
+                unsigned long long chrom_ref = 0;
+                int chrom_ref_len = 0;
+                if (s_on) {
+                    chrom_ref = wk.d.chrom_ref[g];
+                    chrom_ref_len = wk.d.chrom_ref_len[g];
+                }
+                const uint8_t *const cref = (const uint8_t *)(uintptr_t)chrom_ref;
+                LaneOut o;
+                o.R = R;
+                int ref_head = pos, read_head = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0, cmp = 0;
+                int in_blk = 0, spanic = 0;
+                const int nmax = wv::reduce_max(s_on ? n : 0);
+                for (int k = 0; k <= nmax; ++k) {
+                    const int valid = s_on & (int)(k < n);
+                    const int atend = s_on & (int)(k == n);
+                    const uint32_t c = R[cur_off + (valid ? k : 0)];
+                    const int t = op_type(c), L = op_len(c);
+                    const int indel = valid & i_is_indel(t);
+                    const int wl = cur_off + wv::imin(k + 1, n);
+                    const int endc = in_blk & (indel ^ 1) & (valid | atend);
+                    if (wv::ballot(endc != 0) != 0ull) {  // CigarBlockInfo::end_indel (:35-111)
+                        // :41-44 one kind only (nothing for 0 / 0); :45-48 1 / 1 -> M(1); else the base comparisons
+                        const int single = endc & ((int)(del == 0) | (int)(ins == 0));
+                        const int one_one = endc & (int)(del == 1) & (int)(ins == 1);
+                        const int cplx = endc & (single ^ 1) & (one_one ^ 1);
+                        int pre = one_one, post = 0;
+                        if (wv::ballot(cplx != 0) != 0ull) {
+                            if (cplx) {
+                                if (blk_ref < 0 || blk_ref + del - 1 >= chrom_ref_len || blk_read + ins - 1 >= rd.len) {
+                                    spanic = 1;  // slice index out of bounds: the reference panics (:58-60)
+                                    del = 0;
+                                    ins = 0;
+                                } else {
+                                    // :55-68 trailing bases shared by the inserted and the deleted sequence, then :71-85 leading ones
+                                    post = match_run_back(cref, chrom_ref_len, blk_ref + del, rd, blk_read + ins, wv::imin(del, ins), cmp);
+                                    del -= post;
+                                    ins -= post;
+                                    pre = match_run_fwd(cref, chrom_ref_len, blk_ref, rd, blk_read, wv::imin(del, ins), cmp);
+                                    del -= pre;
+                                    ins -= pre;
+                                    if (del == 1 && ins == 1) {  // :88-92
+                                        del = 0;
+                                        ins = 0;
+                                        ++post;
+                                    }
+                                }
+                            }
+                        }
+                        const int emit_id = endc & (one_one ^ 1);
+                        lane_push(o, endc & (int)(pre > 0), OP_M, pre, wl);  // :101-104
+                        lane_push(o, emit_id & (int)(ins > 0), OP_I, ins, wl);
+                        lane_push(o, emit_id & (int)(del > 0), OP_D, del, wl);
+                        lane_push(o, endc & (int)(post > 0), OP_M, post, wl);
+                        del = endc ? 0 : del;
+                        ins = endc ? 0 : ins;
+                        in_blk &= endc ^ 1;
+                    }
+                    const int open = indel & (in_blk ^ 1);  // _add_indel (:16-22)
+                    blk_ref = open ? ref_head : blk_ref;
+                    blk_read = open ? read_head : blk_read;
+                    in_blk |= indel;
+                    del += (indel & (int)(t == OP_D)) ? L : 0;
+                    ins += (indel & (int)(t == OP_I)) ? L : 0;
+                    lane_push(o, valid & (indel ^ 1), t, L, wl);  // :144-147
+                    read_head += (valid & i_read_cons(t)) ? L : 0;
+                    ref_head += (valid & i_ref_cons(t)) ? L : 0;
+                }
+                lane_out_finish(o, s_on, cur_off + n);  // :153-154
+                if (s_on) {
+                    algo += 2u * (unsigned)cmp;
+                    ovf |= o.ovf;
+                    n = o.no;
+                    cur_off = 0;
+                    pos += o.lead_shift;  // :155
+                    if (rd.miss || spanic) {
+                        status = rd.miss ? PLO_ITEM_NEED_BASES : PLO_ITEM_PANIC;
+                        alive = false;
+                    }
+                }
+                wv::sync();
+            }
+        }
+
+        PLO_LT(5)
+        // ---- OUTPUT ----------------------------------------------------------------------------------------------------------------
+        {   // regions that overflowed: the wave-cooperative code takes the item (retry list)
+            const bool re = act0 && ovf;
+            const unsigned long long om = wv::ballot(re);
+            if (om != 0ull) {
+                int slot = 0;
+                if (lane == 0) slot = (int)wv::atomic_add_global(&wk.counters[CNT_NRETRY], (unsigned long long)__builtin_popcountll(om));
+                slot = wv::bcast_first(slot);
+                if (re) {
+                    wk.retry_list[slot + __builtin_popcountll(om & ((1ull << lane) - 1ull))] = g;
+                    wk.status[g] = (uint8_t)ITEM_NEED_BIG;
+                }
+            }
+        }
+        const bool done = act0 && !ovf;
+        const bool emit_cigar = done && (status == PLO_ITEM_LIFTED || status == PLO_ITEM_LEN_MISMATCH);
+        const int oc = emit_cigar ? n : 0;
+        const int inco = wv::scan_add(oc);
+        const int oS = inco - oc;
+        const int total = wv::bcast_last(inco);
+        if ((unsigned long long)total > ctx.slab_left) {  // wave-uniform: reserve a new slab
+            const unsigned long long want = (unsigned long long)total > SLAB_OPS ? (unsigned long long)total : SLAB_OPS;
+            unsigned long long nb = 0;
+            if (lane == 0) nb = wv::atomic_add_global(&wk.counters[CNT_CIGAR], want) + wk.slab_offset;
+            ctx.slab_base = wv::bcast_first(nb);
+            ctx.slab_left = want;
+        }
+        const unsigned long long gbase = ctx.slab_base;
+        ctx.slab_base += (unsigned long long)total;
+        ctx.slab_left -= (unsigned long long)total;
+        const bool fits = gbase + (unsigned long long)total <= wk.out_cap;
+        if (!fits && lane == 0) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
+        {
+            const int ocmax = wv::reduce_max(fits ? oc : 0);
+            uint32_t *const dst = wk.out_cigar + gbase + (unsigned long long)oS;
+            const uint32_t *const srcp = R + cur_off;
+            for (int k = 0; k < ocmax; k += 4) {  // 16 bytes per store and lane
+                if (fits && k + 3 < oc) {
+                    Ops4 v;
+                    v.x = srcp[k];
+                    v.y = srcp[k + 1];
+                    v.z = srcp[k + 2];
+                    v.w = srcp[k + 3];
+                    *(PLO_GLOBAL Ops4 *)(dst + k) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (fits && k + j < oc) dst[k + j] = srcp[k + j];
+                }
+            }
+        }
+        if (done) {
+            if (status == PLO_ITEM_NEED_BASES) wk.miss_list[wv::atomic_add_global(&wk.counters[CNT_NMISS], 1ull)] = g;  // rare
+            wk.status[g] = (uint8_t)status;
+            wk.pos[g] = emit_cigar ? (int64_t)pos : (int64_t)-1;
+            wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
+            wk.cig_len[g] = (uint32_t)oc;
+            ctx.algo_bytes += algo + 40u + 4u * (unsigned)n_in + 24u + 4u * (unsigned)oc;
+            ctx.in_ops += (unsigned)n_in;
+            ctx.out_ops += (unsigned)oc;
+        }
+        PLO_LT(6)
+    }
+#undef PLO_LT
+}
+
+// Persistent wave over the groups of the lane classes: class c (0: no shift stage, 1: shift stage) occupies positions
+// [c_begin, c_end) of the class order and is cut into groups of 64 from its start, so that groups are strand-homogeneous.
+// Group indices: class 0 first.  The item indices of the next group are fetched one group ahead.
+template <bool SP>
+PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
+                                   uint32_t n0, uint32_t n1, uint32_t *lds, int capw, WaveCtx &ctx) {
+    const uint32_t lane = (uint32_t)wv::lane();
+    const uint32_t t0 = (n0 + 63u) >> 6, t1 = (n1 + 63u) >> 6;
+    auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
+        if (t < t0) {
+            lo = t * 64u;
+            hi = lo + 64u < n0 ? lo + 64u : n0;
+        } else {
+            lo = n0 + (t - t0) * 64u;
+            hi = lo + 64u < n0 + n1 ? lo + 64u : n0 + n1;
+        }
+    };
+    uint32_t t = first;
+    uint32_t g_next = 0;
+    if (t < t0 + t1) {
+        uint32_t lo, hi;
+        group(t, lo, hi);
+        g_next = lo + lane < hi ? wk.perm[lo + lane] : 0u;
+    }
+    for (; t < t0 + t1; t += stride) {
+        uint32_t lo, hi;
+        group(t, lo, hi);
+        const uint32_t g = g_next;
+        if (t + stride < t0 + t1) {
+            uint32_t lo2, hi2;
+            group(t + stride, lo2, hi2);
+            g_next = lo2 + lane < hi2 ? wk.perm[lo2 + lane] : 0u;
+        }
+        lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, ctx, wk.perm, true, g);
+        wv::sync();
+    }
+}
+
+}  // namespace plo

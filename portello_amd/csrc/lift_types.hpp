@@ -81,13 +81,13 @@ struct DevWork {
     uint32_t *item_cseg;
     uint32_t *item_nin;              // input op count per item
     uint32_t *item_cls;              // bit0: the item goes through the left-shift stage (reverse-mapped contig segment),
-                                     // bit1: too many ops for the lane-per-item path
+                                     // bit1: too heavy for the lane-per-item path
     // Work is cut from the items in *class order* (class 0, 1, 2, 3, each in input order): the first n_small positions
     // (classes 0-1) go to the lane-per-item kernel in groups of 64, the rest to the tile kernel; groups and tiles are
     // strand-homogeneous so that forward ones skip the shift stage altogether.  Outputs keep the input order.
     const uint32_t *perm;            // [n_items] class order -> item index
     uint32_t n_small;                // positions [0, n_small) of perm: lane-per-item kernel
-    int lane_max_in;                 // largest input op count routed to the lane-per-item kernel
+    int lane_max_w;                  // heaviest item (item_weight) routed to the lane-per-item kernel (lane_core.hpp); < 0: none
     const uint32_t *item_op_prefix;  // [n_items+1] exclusive prefix, in class order, of the op counts of the large items
     const uint32_t *tile_lo;         // [n_tiles+1] first class-order position (>= n_small) of every tile
     uint32_t *retry_list;            // items of the lane kernel whose intermediates overflowed: re-run by the tile code

@@ -10,6 +10,7 @@
 #include "../../portello_amd/csrc/index_pack.hpp"
 #include "../../portello_amd/csrc/inflate.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
+#include "../../portello_amd/csrc/lane_core.hpp"
 
 using namespace plo;
 
@@ -23,8 +24,10 @@ struct Out {
 }  // namespace
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
-                                  int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, plo_batch_out *out,
-                                  unsigned long long *counters_out) {
+                                  int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, int lane_max_w, int lane_capw,
+                                  plo_batch_out *out, unsigned long long *counters_out) {
+    // lane_max_w >= 0: items up to that weight run through the lane-per-item code (lane_core.hpp) with an LDS slice of lane_capw
+    // dwords per wave; what it cannot hold goes to the retry list like on the GPU
     // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
     // code (lift_tile<NW>, LEVEL_MID) with an LDS capacity of mid_cap elements, under the multi-wave emulator
     PackedIndex pk;
@@ -100,7 +103,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     DevWork wk;
     memset(&wk, 0, sizeof(wk));
     wk.n_items = n_items;
-    wk.lane_max_in = -1;
+    wk.lane_max_w = lane_max_w;
     wk.item_seg = o->item_seg.data();
     wk.item_cseg = o->item_cseg.data();
     wk.item_nin = item_nin.data();
@@ -188,6 +191,20 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         wk.out_cap = out_cap;
         std::vector<unsigned char> lds(tile_mem_bytes(cap) + 64);
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
+        if (n_small) {  // k_lift_lanes: persistent waves over the groups of 64 of the two lane classes
+            std::vector<uint32_t> llds((size_t)lane_capw + 16, 0xdeadbeefu);
+            for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
+                w.run([&]() {
+                    WaveCtx ctx;
+                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
+                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
+                    wave_ctx_flush(wk, ctx, 0);
+                });
+                sum_stats();
+            }
+        }
         for (uint32_t wv_id = 0; wv_id < n_waves && n_large; ++wv_id) {
             wv::EmuWave w;
             w.order_seed = order_seed ? order_seed + wv_id : 0;
@@ -286,7 +303,10 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         if (counters[CNT_OVERFLOW] == 0) break;
         out_cap = counters[CNT_CIGAR] + 8 * SLAB_OPS;
     }
-    if (counters_out) memcpy(counters_out, counters, sizeof(counters));
+    if (counters_out) {
+        memcpy(counters_out, counters, sizeof(counters));
+        counters_out[23] = n_small;  // items that took the lane-per-item path (test visibility)
+    }
 
     out->n_items = n_items;
     out->item_seg = o->item_seg.data();

@@ -144,3 +144,43 @@ def test_workgroup_per_item_stage_subsets(oracle):
         rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, big_thresh=8, mid_waves=4, mid_cap=1024)
         assert rc == 0 and cnt[2] > 0
         _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
+
+
+# ---- lane-per-item path (portello_amd/csrc/lane_core.hpp) ----------------------------------------------------------------------
+
+def test_lane_path_golden_vectors(golden):
+    check_golden(golden, emu_backend(lane_max_w=4096, lane_capw=8192))
+
+
+@pytest.mark.parametrize("stages", [abi.STAGES_ALL, abi.STAGES_ALL & ~abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LIFTOVER,
+                                    abi.STAGE_LSHIFT, abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LSHIFT])
+def test_lane_path_synthetic_tiny(oracle, stages):
+    w = synth.generate(synth.config("tiny", n_reads=150, split_read_frac=0.2, seed=131))
+    ix, b = w.index_data(), w.batch_data()
+    rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=400, lane_capw=3072)
+    assert rc == 0
+    _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
+
+
+def test_lane_path_small_slices_rounds_and_overflow(oracle):
+    """slices too small for 64 regions (several rounds per group), for some items (-> retry list), shuffled lane order; a weight
+    limit that splits the items between the lane path and the wave-cooperative one"""
+    w = synth.generate(synth.config("tiny", n_reads=120, seed=132, split_read_frac=0.2, read_len_mean=2500, read_len_sd=900))
+    ix, b = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1)
+    for max_w, capw, seed in ((4096, 600, 0), (4096, 96, 77), (40, 3072, 0), (4096, 3072, 4711)):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, lane_max_w=max_w, lane_capw=capw, order_seed=seed)
+        assert rc == 0
+        _assert_same(ref, res)
+
+
+def test_lane_path_indel_dense(oracle):
+    cfg = synth.config("tiny", n_reads=48, seed=133, read_len_mean=1500, read_len_sd=300,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    for stages in (abi.STAGES_ALL, abi.STAGE_SIMPLIFY, abi.STAGE_LSHIFT):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=100000, lane_capw=60000)
+        assert rc == 0
+        _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)

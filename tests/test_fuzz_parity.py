@@ -31,6 +31,11 @@ def test_fuzz_emulated_device_algorithm(oracle, seed):
             rc, got, _ = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096)
             assert rc == 0
             _diff(ref, got, b, f"seed {seed} alpha {alpha} stages {stages}")
+            # the same through the lane-per-item path (lane_core.hpp); what it hands on takes the path above
+            rc, got, cnt = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096, lane_max_w=60,
+                                                  lane_capw=1024 if seed % 2 else 160)
+            assert rc == 0 and cnt[23] > 0
+            _diff(ref, got, b, f"lane path: seed {seed} alpha {alpha} stages {stages}")
 
 
 @pytest.mark.gpu

@@ -55,18 +55,21 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         os.environ["PLO_TILE_WAVES"] = parts[3] if len(parts) > 3 else "4"
         os.environ["PLO_WINDOW"], os.environ["PLO_BIG_THRESH"], os.environ["PLO_CAP"] = win, thr, cap
     eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
-    ms, big, en, ln = [], [], [], []
+    ms, big, en, ln, la = [], [], [], [], []
     for i in range(args.steps + 1):
         eng.liftover_batch_dev(desc, stages)
         t = eng.timing()
         if i:
-            ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.mid_ms)
-    print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: mid {np.mean(ln):.3f} ms ({t.n_mid_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
-          f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big))/1e3:.1f} M items/s", flush=True)
+            ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.mid_ms); la.append(t.lanes_ms)
+    print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(la):.3f} ms ({t.n_lane_items} items)  mid {np.mean(ln):.3f} ms ({t.n_mid_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
+          f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big)+np.mean(la))/1e3:.1f} M items/s", flush=True)
     if args.timing:
         ph = (C.c_ulonglong * 12)()
         L.plo_ctx_phase_cycles(eng.handle, ph)
         tot = sum(ph) or 1
+        if t.n_lane_items:
+            names = ["desc+alloc", "load", "shift walk", "liftover", "lift finish", "simplify", "output", "-", "-", "-", "-", "-"]
+            print("   lane phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names) if n != "-") + f"   cycles/group {tot / max(1, t.n_lane_items / 64):.0f}", flush=True)
         names = ["desc", "load+lshiftA", "lshift cc", "lift:stage+passA", "lift:scatter+passB", "lift:cc", "lencheck", "simplify A+H+B", "simplify cc", "output", "lshift H", "lshift B"]
         print("   phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/tile-wave {tot/ max(1,(t.n_in_ops//(int(win) if win != 'auto' else 256)+1)):.0f}", flush=True)
     eng.close()
