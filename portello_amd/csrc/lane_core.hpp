@@ -51,9 +51,13 @@ constexpr int LANE_SLACK = 2;  // dwords on top of an item's weight (the shift s
 // becomes a lane mask in scalar registers that the compiler merges with three scalar instructions per join (the first version
 // of this file spent more scalar than vector instructions).
 // -------------------------------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) Ops4 {  // four CIGAR ops, loaded / stored as one 16-byte access at any 4-byte address
+#ifdef PLO_EMULATOR
+struct __attribute__((packed, aligned(4))) Ops4 {
     uint32_t x, y, z, w;
 };
+#else
+typedef uint32_t Ops4 __attribute__((ext_vector_type(4), aligned(4)));  // four CIGAR ops: one 16-byte access at any 4-byte address
+#endif
 struct LaneOut {
     uint32_t *R = nullptr;  // the lane's region
     int no = 0;             // ops written
