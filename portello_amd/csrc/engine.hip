@@ -202,6 +202,57 @@ __global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, co
     nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
 }
 
+// The lane-per-item kernel runs a group of 64 items for as long as its heaviest item takes; in read order that is about twice
+// the average (a group's longest CIGAR against its mean).  So the lane part of the class order is sorted by item weight -- but
+// only inside chunks of LANE_SORT_CHUNK consecutive positions: neighbours in the order are reads over the same stretch of a
+// contig, and the groups of a chunk run on one XCD at about the same time, which is what keeps the contig lines their homology
+// probes share in that XCD's L2 (a global sort would fetch them from HBM once per read instead of once).
+// One workgroup per chunk: counting sort in LDS (weights are bounded by the lane path's limit, <= 255 bins + clamp).
+constexpr uint32_t LANE_SORT_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_CHUNK / LANE_SORT_THREADS;
+__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t c0 = (n0 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK;
+    uint32_t lo, hi;
+    if (blockIdx.x < c0) {  // chunks do not straddle the two lane classes
+        lo = blockIdx.x * LANE_SORT_CHUNK;
+        hi = lo + LANE_SORT_CHUNK < n0 ? lo + LANE_SORT_CHUNK : n0;
+    } else {
+        lo = n0 + (blockIdx.x - c0) * LANE_SORT_CHUNK;
+        hi = lo + LANE_SORT_CHUNK < n0 + n1 ? lo + LANE_SORT_CHUNK : n0 + n1;
+    }
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t g[LANE_SORT_PER], k[LANE_SORT_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        g[j] = p < hi ? perm[p] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        uint32_t w = p < hi ? weight[g[j]] : 0u;
+        k[j] = w < 255u ? w : 255u;
+        if (p < hi) atomicAdd(&hist[k[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix of the 256 bins: thread t owns bin t
+    const uint32_t mine = hist[threadIdx.x];
+    const uint32_t inc = (uint32_t)wv::scan_add((int)mine);
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    hist[threadIdx.x] = before + inc - mine;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        if (p < hi) perm[lo + atomicAdd(&hist[k[j]], 1u)] = g[j];
+    }
+}
+
 // thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
 __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, const uint32_t *r0,
                               const uint32_t *r1, uint32_t *tile_lo) {
@@ -805,6 +856,7 @@ struct plo_ctx {
     // per item -- 36 KB of LDS per wave, synchronous probes -- was a net loss and had been removed; this is a different kernel.)
     int lane_max_w = 192;
     int lane_capw = 3072;
+    bool lane_sort = true;  // k_chunk_sort: groups of similar weight
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1039,6 +1091,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
+    if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e)));
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1408,6 +1461,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.slab_offset = 0;
         if (n_small) {
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
+            if (attempt == 0 && c->lane_sort) {
+                const uint32_t chunks = (n0 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK + (n1 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK;
+                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
+                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1);
+            }
             const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
             const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
             int occ = 1;

@@ -62,73 +62,83 @@ struct LaneOut {
     uint32_t *R = nullptr;  // the lane's region
     int no = 0;             // ops written
     uint32_t acc = 0;       // the open run, (len << 4) | type; starts as Match(0)
-    int last_m = -1;        // index of the last match op written
     int lead_shift = 0;
-    int seen_m = 0;
-    int pairs = 0;          // two neighbouring I / D ops were written: an indel cluster of more than one op
-    int ovf = 0;            // a write would have passed `wlim`
+    bool seen_m = false;
+    bool pairs = false;     // two neighbouring I / D ops were written: an indel cluster of more than one op
+    bool ovf = false;       // a write would have passed `wlim`
 };
 PLO_DEV int wrap_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-PLO_DEV int i_is_match(int t) { return (0x181 >> t) & 1; }   // M = X
-PLO_DEV int i_is_indel(int t) { return (0x006 >> t) & 1; }   // I D
-PLO_DEV int i_ref_cons(int t) { return (0x18D >> t) & 1; }   // M D N = X
-PLO_DEV int i_read_cons(int t) { return (0x1B3 >> t) & 1; }  // M I S H = X
-// `on`: 0 / 1.  `wlim`: first index that must not be written (the reader's position when the region is used in place)
-PLO_DEV void lane_push(LaneOut &o, int on, int t, int L, int wlim) {
-    const int lead = on & (o.seen_m ^ 1);
-    const int drop_d = lead & (int)(t == OP_D);
+PLO_DEV bool b_is_match(int t) { return ((0x181u >> t) & 1u) != 0u; }   // M = X
+PLO_DEV bool b_is_indel(int t) { return (unsigned)(t - 1) < 2u; }        // I D
+PLO_DEV bool b_ref_cons(int t) { return ((0x18Du >> t) & 1u) != 0u; }   // M D N = X
+PLO_DEV bool b_read_cons(int t) { return ((0x1B3u >> t) & 1u) != 0u; }  // M I S H = X
+// Flags are `bool`s combined with & | ^ (no short-circuit: the code must stay one basic block).
+// `wlim`: first index that must not be written (the reader's position when the region is used in place).  PAD: the stream may
+// hold Pad ops (absent from compress_cigar's summing pattern, :210-212: a Pad following a Pad adds nothing).
+template <bool PAD = true>
+PLO_DEV void lane_push(LaneOut &o, bool on, int t, int L, int wlim) {
+    const bool lead = on & !o.seen_m;
+    const bool drop_d = lead & (t == OP_D);
     o.lead_shift += drop_d ? L : 0;
-    t = (lead & (int)(t == OP_I)) ? (int)OP_S : t;
-    const int ismt = i_is_match(t);
-    o.seen_m |= on & ismt;
-    o.ovf |= on & ismt & (int)(L == 0);
-    const int live = on & (drop_d ^ 1) & (int)(L > 0);
+    t = (lead & (t == OP_I)) ? (int)OP_S : t;
+    o.seen_m = o.seen_m | (on & b_is_match(t));
+    const bool live = on & !drop_d & (L > 0);
     const int at = (int)(o.acc & 15u);
-    const int same = live & (int)(t == at);
-    const int flush = live & (same ^ 1) & (int)(o.acc >= 16u);
-    const int ok = (int)(o.no < wlim);
+    const bool same = live & (t == at);
+    const bool flush = live & !same & (o.acc >= 16u);
+    const bool ok = o.no < wlim;
     if (flush & ok) o.R[o.no] = o.acc;
-    o.ovf |= flush & (ok ^ 1);
-    o.pairs |= flush & i_is_indel(at) & i_is_indel(t);
-    o.last_m = (flush & i_is_match(at)) ? o.no : o.last_m;
-    o.no += flush;
-    // Pad is absent from the summing pattern (:210-212): a Pad following a Pad adds nothing
-    const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
+    o.ovf = o.ovf | (flush & !ok);
+    o.pairs = o.pairs | (flush & b_is_indel(at) & b_is_indel(t));
+    o.no += flush ? 1 : 0;
+    const uint32_t add = (PAD && t == OP_P) ? 0u : ((uint32_t)L << 4);
     o.acc = same ? o.acc + add : (live ? mk_op(t, L) : o.acc);
 }
-// wave-uniform call (the tail loop is bounded by a ballot); `on`: lanes that own a writer
-PLO_DEV void lane_out_finish(LaneOut &o, int on, int wlim) {
+// wave-uniform call (the loops are bounded by ballots); `on`: lanes that own a writer
+PLO_DEV void lane_out_finish(LaneOut &o, bool on, int wlim) {
     {
-        const int flush = on & (int)(o.acc >= 16u);
-        const int ok = (int)(o.no < wlim);
+        const bool flush = on & (o.acc >= 16u);
+        const bool ok = o.no < wlim;
         if (flush & ok) o.R[o.no] = o.acc;
-        o.ovf |= flush & (ok ^ 1);
-        o.last_m = (flush & i_is_match((int)(o.acc & 15u))) ? o.no : o.last_m;
-        o.no += flush;
+        o.ovf = o.ovf | (flush & !ok);
+        o.no += flush ? 1 : 0;
     }
-    // trailing edge: ops behind the last match (none was written: everything went through the leading rule already)
-    const int fix = on & (o.ovf ^ 1) & o.seen_m & (int)(o.last_m + 1 < o.no);
-    int i = o.last_m + 1, w = o.last_m + 1;
+    // trailing edge: the ops behind the last alignment match (if none was written, everything went through the leading rule
+    // already).  They are few: found by walking back from the end.
+    const bool fix0 = on & !o.ovf & o.seen_m;
+    int lm = o.no - 1;
+    {
+        bool look = fix0 & (lm >= 0);
+        while (wv::ballot(look) != 0ull) {
+            const uint32_t c = o.R[look ? lm : 0];
+            const bool hit = look & b_is_match(op_type(c));
+            look = look & !hit & (lm > 0);
+            lm -= (look) ? 1 : 0;
+            // (a lane leaves the loop on its last match, or at index 0 without one -- which seen_m rules out)
+        }
+    }
+    const bool fix = fix0 & (lm + 1 < o.no);
+    int i = lm + 1, w = lm + 1;
     uint32_t run = 0;  // open run of the rewritten tail (0: none)
-    while (wv::ballot(fix && i < o.no) != 0ull) {
-        const int act = fix & (int)(i < o.no);
+    while (wv::ballot(fix & (i < o.no)) != 0ull) {
+        const bool act = fix & (i < o.no);
         const uint32_t c = o.R[act ? i : 0];
         int t = op_type(c);
         const int L = op_len(c);
-        i += act;
-        const int keep = act & (int)(t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
+        i += act ? 1 : 0;
+        const bool keep = act & (t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
         t = (t == OP_I) ? (int)OP_S : t;
-        const int same = keep & (int)(run >= 16u) & (int)(t == (int)(run & 15u));
-        const int flush = keep & (same ^ 1) & (int)(run >= 16u);
+        const bool same = keep & (run >= 16u) & (t == (int)(run & 15u));
+        const bool flush = keep & !same & (run >= 16u);
         if (flush) o.R[w] = run;
-        w += flush;
+        w += flush ? 1 : 0;
         const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
         run = same ? run + add : (keep ? mk_op(t, L) : run);
     }
     {
-        const int flush = fix & (int)(run >= 16u);
+        const bool flush = fix & (run >= 16u);
         if (flush) o.R[w] = run;
-        w += flush;
+        w += flush ? 1 : 0;
         o.no = fix ? w : o.no;
     }
 }
@@ -207,19 +217,19 @@ PLO_DEV void xw16_decode(const ReadSeq &rd, const XW16 &w, unsigned X[4]) {
 struct LaneProbe {
     XW16 w;
     int re = 0, qe = 0, maxk = 0;
-    int async_ok = 0;
+    bool async_ok = false;
 };
-// `on`: the lanes whose cluster ends (0 / 1); sets their `panic` where the reference's slice index would
-PLO_DEV void lane_probe_issue(LaneProbe &p, int on, const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins,
-                              int bound, int &panic) {
+// `on`: the lanes whose cluster ends; sets their `panic` where the reference's slice index would
+PLO_DEV void lane_probe_issue(LaneProbe &p, bool on, const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins,
+                              int bound, bool &panic) {
     const int re = rs + del, qe = qs + ins;
     const int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
     int maxk = wv::imin(max_left, bound);
-    const int bad = (int)(max_left > 0) & ((int)(re - 1 >= ref_len) | (int)(qe - 1 >= rd.len));  // slice-index panic (:38-39)
-    panic |= on & bad;
+    const bool bad = (max_left > 0) & ((re - 1 >= ref_len) | (qe - 1 >= rd.len));  // slice-index panic (:38-39)
+    panic = panic | (on & bad);
     maxk = bad ? 0 : maxk;
-    int ok = 0;
-    if (on && maxk > 0) ok = xw16_issue(ref, ref_len, re - 16, rd, qe - 16, p.w) ? 1 : 0;
+    bool ok = false;
+    if (on && maxk > 0) ok = xw16_issue(ref, ref_len, re - 16, rd, qe - 16, p.w);
     p.re = on ? re : p.re;
     p.qe = on ? qe : p.qe;
     p.maxk = on ? maxk : p.maxk;
@@ -260,19 +270,19 @@ PLO_DEV int top_zero_bytes(const unsigned X[4]) {  // zero_bytes_from_top withou
     return hi ? zh : 8 + zl;
 }
 // wave-uniform call; `on`: the lanes whose pending cluster is resolved now
-PLO_DEV int lane_probe_finish(const LaneProbe &p, int on, const uint8_t *ref, int ref_len, ReadSeq &rd, int &probes) {
+PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, int ref_len, ReadSeq &rd, int &probes) {
     unsigned X[4];
     xw16_decode(rd, p.w, X);  // (registers only: harmless where nothing was loaded)
     const int n = wv::imin(16, p.maxk);
     const int m = wv::imin(top_zero_bytes(X), n);
-    const int live = on & (int)(p.maxk > 0);
-    const int fast = live & p.async_ok;
+    const bool live = on & (p.maxk > 0);
+    const bool fast = live & p.async_ok;
     int h = fast ? m : 0;
     probes += fast ? wv::imin(m + 1, n) : 0;
     // the window lay outside a buffer (first / last bases of a sequence), the batch is sparse, or all 16 bases agree and the
     // match run allows more: window by window from there
-    const int more = live & ((p.async_ok ^ 1) | ((int)(m == n) & (int)(n < p.maxk)));
-    if (wv::ballot(more != 0) != 0ull) {
+    const bool more = live & ((!p.async_ok) | ((m == n) & (n < p.maxk)));
+    if (wv::ballot(more) != 0ull) {
         if (more) h = match_run_back_from(ref, ref_len, p.re, rd, p.qe, p.maxk, h, probes);
     }
     return h;
@@ -295,8 +305,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         ctx.tph[k] += now_ - tlast;   \
         tlast = now_;                 \
     }
+#define PLO_LC(k, v) ctx.tph[k] += (v);  // loop trip counts (statistics of the timing build)
 #else
 #define PLO_LT(k)
+#define PLO_LC(k, v)
 #endif
 
     // ---- descriptors (build_item_desc, enumerate.hpp) ----
@@ -355,13 +367,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 
         int status = PLO_ITEM_LIFTED;
         bool alive = act0;
-        int shift_on = (act0 && do_shift) ? 1 : 0;
+        bool shift_on = act0 && do_shift;
         if (shift_on && shift_ref == 0ull) {  // rev_contig_seq.unwrap() on None (src/read_alignment_scanner.rs:174)
             status = PLO_ITEM_PANIC;
             alive = false;
-            shift_on = 0;
+            shift_on = false;
         }
-        int ovf = 0, panic = 0;
+        bool ovf = false, panic = false;
         unsigned algo = 0;
         int cur_off = 0, n = 0;  // the item's current CIGAR: R[cur_off .. cur_off + n)
         int pos = pos1;
@@ -376,14 +388,16 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // turn every match piece into M, compress_cigar :220 merges the pieces of neighbouring ops).  Same result, a third fewer
         // ops to walk -- and the ops of a shifted item then alternate match / cluster, which is what keeps its scans short.
         {
-            const int ld = act0 ? 1 : 0;
-            const int merge = ld & (shift_on | ((stages & PLO_STAGE_LIFTOVER) ? 1 : 0));
+            const bool ld = act0;
+            const bool merge = ld & (shift_on | ((stages & PLO_STAGE_LIFTOVER) != 0));
             const int inb = shift_on ? W - n_in : gap;
             const int nmax = wv::reduce_max(ld ? n_in : 0);
             uint32_t run = 0;
-            int has_run = 0, w = 0;
+            bool has_run = false;
+            int w = 0;
             // 16 bytes per load and lane (every lane reads its own CIGAR: four ops per request instead of one), two in flight
             for (int k0 = 0; k0 < nmax; k0 += 8) {
+                PLO_LC(10, 1)
                 uint32_t r[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -405,19 +419,18 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int have = ld & (int)(k0 + j < n_in);
+                    const bool have = ld & (k0 + j < n_in);
                     const uint32_t c = r[j];
-                    const int ism = i_is_match(op_type(c));
-                    const int join = merge & have & has_run & ism & i_is_match(op_type(run));
-                    const int flush = have & has_run & (join ^ 1);
+                    const bool join = merge & have & has_run & b_is_match(op_type(c)) & b_is_match(op_type(run));
+                    const bool flush = have & has_run & !join;
                     if (flush) R[inb + w] = run;
-                    w += flush;
+                    w += flush ? 1 : 0;
                     run = join ? ((run & ~15u) + (c & ~15u)) | (uint32_t)OP_M : (have ? c : run);
-                    has_run |= have;
+                    has_run = has_run | have;
                 }
             }
             if (ld & has_run) R[inb + w] = run;
-            w += ld & has_run;
+            w += (ld & has_run) ? 1 : 0;
             n = ld ? w : 0;
             cur_off = ld ? inb : 0;
         }
@@ -432,94 +445,99 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // The emission of a cluster (M I D, :132-147) needs its homology; the probe is sent when the cluster ends and the cluster
         // stays `pend`ing -- match bases that follow collect in `msince` -- until the lane's next event: its probe's HBM round trip
         // runs under the scan in between.
-        if (wv::ballot(shift_on != 0) != 0ull) {
+        if (wv::ballot(shift_on) != 0ull) {
             const uint8_t *const sref = (const uint8_t *)(uintptr_t)shift_ref;
             LaneOut o;
             o.R = R + gap;
             const int wl0 = cur_off - gap;  // the writer may use what lies below the reader: index < wl0 + ops consumed
-            int k = 0, fin = shift_on ^ 1;
-            int ref_head = pos1, read_head = 0, match = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0, in_blk = 0;
-            int pend = 0, p_match = 0, p_ins = 0, p_del = 0, msince = 0, probes = 0;
+            int k = 0;
+            bool fin = !shift_on;
+            int ref_head = pos1, read_head = 0, match = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0;
+            bool in_blk = false, pend = false;
+            int p_match = 0, p_ins = 0, p_del = 0, msince = 0, probes = 0;
             LaneProbe pr;
             PLO_MARK("SHIFT LOOP BEGIN");
-            while (wv::ballot(fin == 0) != 0ull) {
+            while (wv::ballot(!fin) != 0ull) {
+                PLO_LC(8, 1)
                 // scan to the next event (not consumed)
-                int stop = fin, ev_t = 0, ev_L = 0, ev_other = 0, ev_end = 0;
-                while (wv::ballot(stop == 0) != 0ull) {
-                    const int act = stop ^ 1;
-                    const int have = (int)(k < n);
+                bool stop = fin, ev_other = false, ev_end = false;
+                int ev_t = 0, ev_L = 0;
+                while (wv::ballot(!stop) != 0ull) {
+                    PLO_LC(9, 1)
+                    const bool act = !stop;
+                    const bool have = k < n;
                     const uint32_t c = R[cur_off + (have ? k : 0)];
                     const int t = op_type(c), L = op_len(c);
-                    const int indel = have & i_is_indel(t);
-                    const int ism = have & i_is_match(t);
-                    const int other = have & (indel ^ 1) & (ism ^ 1);
-                    const int atend = have ^ 1;
-                    const int ev = act & ((in_blk & (ism | other | atend)) | other | atend);
-                    const int take = act & (ev ^ 1);
-                    const int memb = take & indel & (int)(L > 0);  // add_del / add_ins (:73-85, len > 0 only)
-                    const int open = memb & (in_blk ^ 1);
+                    const bool indel = have & b_is_indel(t);
+                    const bool ism = have & b_is_match(t);
+                    const bool other = have & !indel & !ism;
+                    const bool atend = !have;
+                    const bool ev = act & ((in_blk & (ism | other | atend)) | other | atend);
+                    const bool take = act & !ev;
+                    const bool memb = take & indel & (L > 0);  // add_del / add_ins (:73-85, len > 0 only)
+                    const bool open = memb & !in_blk;
                     blk_ref = open ? ref_head : blk_ref;
                     blk_read = open ? read_head : blk_read;
-                    in_blk |= memb;
-                    del += (memb & (int)(t == OP_D)) ? L : 0;
-                    ins += (memb & (int)(t == OP_I)) ? L : 0;
-                    const int tm = take & ism;  // add_match (:150-153)
+                    in_blk = in_blk | memb;
+                    del += (memb & (t == OP_D)) ? L : 0;
+                    ins += (memb & (t == OP_I)) ? L : 0;
+                    const bool tm = take & ism;  // add_match (:150-153)
                     msince += (tm & pend) ? L : 0;
-                    match += (tm & (pend ^ 1)) ? L : 0;
-                    read_head += (take & i_read_cons(t)) ? L : 0;
-                    ref_head += (take & i_ref_cons(t)) ? L : 0;
-                    k += take;
+                    match += (tm & !pend) ? L : 0;
+                    read_head += (take & b_read_cons(t)) ? L : 0;
+                    ref_head += (take & b_ref_cons(t)) ? L : 0;
+                    k += take ? 1 : 0;
                     ev_t = ev ? t : ev_t;
                     ev_L = ev ? L : ev_L;
                     ev_other = ev ? other : ev_other;
                     ev_end = ev ? atend : ev_end;
-                    stop |= ev;
+                    stop = stop | ev;
                 }
                 // the event
-                const int evl = fin ^ 1;             // lanes with an event
-                const int endc = evl & in_blk;       // end_indel (:101-148)
-                const int flushing = evl & (ev_other | ev_end);
+                const bool evl = !fin;             // lanes with an event
+                const bool endc = evl & in_blk;    // end_indel (:101-148)
+                const bool flushing = evl & (ev_other | ev_end);
                 const int wl = wl0 + k;
-                auto resolve = [&](int on) {  // end_indel's emission for the pending cluster (:132-147)
+                auto resolve = [&](bool on) {  // end_indel's emission for the pending cluster (:132-147)
                     int h = lane_probe_finish(pr, on, sref, shift_ref_len, rd, probes);
                     h = rd.miss ? 0 : h;
                     const int sh = wv::imin(p_match, h);  // actual_shift_len (:132)
-                    lane_push(o, on & (int)(p_match - sh > 0), OP_M, p_match - sh, wl);
-                    lane_push(o, on & (int)(p_ins > 0), OP_I, p_ins, wl);
-                    lane_push(o, on & (int)(p_del > 0), OP_D, p_del, wl);
+                    lane_push<false>(o, on & (p_match - sh > 0), OP_M, p_match - sh, wl);
+                    lane_push<false>(o, on & (p_ins > 0), OP_I, p_ins, wl);
+                    lane_push<false>(o, on & (p_del > 0), OP_D, p_del, wl);
                     match = on ? sh + msince : match;
                     msince = on ? 0 : msince;
-                    pend &= on ^ 1;
+                    pend = pend & !on;
                 };
                 // Pass 0: the pending cluster first (every event needs the builder's match run), then this cluster's probe -- the match
                 // run is exact there, nothing is pending.  Pass 1 (rare): a cluster directly in front of a flushing op or of the end has
                 // no ops to hide its probe under and is resolved at once.  One copy of the code for both (the probe's slow paths are large).
 #pragma nounroll
                 for (int pass = 0; pass < 2; ++pass) {
-                    const int res = (pass == 0 ? evl : flushing) & pend;
-                    if (wv::ballot(res != 0) != 0ull) resolve(res);
+                    const bool res = (pass == 0 ? evl : flushing) & pend;
+                    if (wv::ballot(res) != 0ull) resolve(res);
                     if (pass == 1) break;
-                    if (wv::ballot(endc != 0) != 0ull) {
+                    if (wv::ballot(endc) != 0ull) {
                         lane_probe_issue(pr, endc, sref, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, panic);
                         p_match = endc ? match : p_match;
                         p_ins = endc ? ins : p_ins;
                         p_del = endc ? del : p_del;
                         ins = endc ? 0 : ins;
                         del = endc ? 0 : del;
-                        in_blk &= endc ^ 1;
-                        pend |= endc;
+                        in_blk = in_blk & !endc;
+                        pend = pend | endc;
                     }
-                    if (wv::ballot((flushing & pend) != 0) == 0ull) break;
+                    if (wv::ballot(flushing & pend) == 0ull) break;
                 }
-                if (wv::ballot(flushing != 0) != 0ull) {  // add_other (:155-165); at the end: get_cigar()'s add_other(None) (:54-60)
-                    lane_push(o, flushing & (int)(match > 0), OP_M, match, wl);
+                if (wv::ballot(flushing) != 0ull) {  // add_other (:155-165); at the end: get_cigar()'s add_other(None) (:54-60)
+                    lane_push<false>(o, flushing & (match > 0), OP_M, match, wl);
                     match = flushing ? 0 : match;
-                    const int oth = flushing & ev_other;
-                    lane_push(o, oth, ev_t, ev_L, wl + 1);
-                    read_head += (oth & i_read_cons(ev_t)) ? ev_L : 0;
-                    ref_head += (oth & i_ref_cons(ev_t)) ? ev_L : 0;
-                    k += oth;
-                    fin |= flushing & ev_end;
+                    const bool oth = flushing & ev_other;
+                    lane_push<true>(o, oth, ev_t, ev_L, wl + 1);
+                    read_head += (oth & b_read_cons(ev_t)) ? ev_L : 0;
+                    ref_head += (oth & b_ref_cons(ev_t)) ? ev_L : 0;
+                    k += oth ? 1 : 0;
+                    fin = fin | (flushing & ev_end);
                 }
             }
             PLO_MARK("SHIFT LOOP END");
@@ -529,7 +547,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 n = o.no;
                 cur_off = gap;
                 pos += o.lead_shift;
-                ovf |= o.ovf;
+                ovf = ovf | o.ovf;
             }
         }
         if (act0 && (panic || rd.miss)) {  // absent bases (sparse batches) come first: what the probes saw then is not the read
@@ -543,9 +561,9 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // One iteration = one (op x block) piece (update_ref2_cigar_segment, :35-133) or one copied op, straight-line.  Block
         // cursor: {kb, vb} the block that holds block_pos (bvalid: there is one), {kn, vn} the next entry of the map, {kf, vf}
         // the one after it, requested at the previous crossing.
-        int pairs = 1;
+        bool pairs = true;
         if (stages & PLO_STAGE_LIFTOVER) {
-            const int lo_on = (alive && !ovf) ? 1 : 0;
+            const bool lo_on = alive && !ovf;
             if (lo_on) {
                 int nb = kv1 - kv0, lg = 0;
                 while ((1 << lg) < nb) ++lg;
@@ -553,7 +571,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             }
             LaneOut o;
             o.R = R;
-            int k = 0, in_op = 0, ism = 0, bvalid = 0, has_start = 0, has_end = 0;
+            int k = 0;
+            bool in_op = false, ism = false, bvalid = false, has_start = false, has_end = false;
             int t = 0, seg_start = pos, seg_end = 0, block_pos = 0, r2s = 0, r2e = 0;
             int kb = 0, vb = NONE32, kn = IMAX, vn = NONE32, kf = IMAX, vf = NONE32;
             int ni = W0 + 2;  // index of the entry to request at the next crossing
@@ -570,21 +589,22 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
             }
             PLO_MARK("LIFTOVER LOOP BEGIN");
-            while (wv::ballot(lo_on && (k < n || in_op)) != 0ull) {
+            while (wv::ballot(lo_on & ((k < n) | in_op)) != 0ull) {
+                PLO_LC(7, 1)
                 // the next op, unless one is being cut into pieces
-                const int fetch = lo_on & (in_op ^ 1) & (int)(k < n);
+                const bool fetch = lo_on & !in_op & (k < n);
                 const uint32_t c = R[cur_off + (fetch ? k : 0)];
-                k += fetch;
+                k += fetch ? 1 : 0;
                 const int tf = op_type(c), Lf = op_len(c);
-                const int copy = fetch & ((0x32 >> tf) & 1);  // I S H: :157-160 copied through; Pad (:213) emits nothing
-                const int start = fetch & i_ref_cons(tf) & (int)(Lf > 0);
+                const bool copy = fetch & (((0x32u >> tf) & 1u) != 0u);  // I S H: :157-160 copied through; Pad (:213) emits nothing
+                const bool start = fetch & b_ref_cons(tf) & (Lf > 0);
                 t = start ? tf : t;
-                ism = start ? i_is_match(tf) : ism;
+                ism = start ? b_is_match(tf) : ism;
                 seg_end = start ? seg_start + Lf : seg_end;
                 block_pos = start ? seg_start : block_pos;
-                in_op |= start;
+                in_op = in_op | start;
                 // the piece starts in the next block (get_ref_range walks on, read_to_ref_map.rs:79-84)
-                const int adv = in_op & (int)(kn <= block_pos);
+                const bool adv = in_op & (kn <= block_pos);
                 int fk = IMAX, fv = NONE32;
                 if (adv && ni < kv1) {
                     const KV e = ix.kv[ni];
@@ -593,41 +613,41 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
                 kb = adv ? kn : kb;
                 vb = adv ? vn : vb;
-                bvalid |= adv;
+                bvalid = bvalid | adv;
                 kn = adv ? kf : kn;
                 vn = adv ? vf : vn;
                 kf = adv ? fk : kf;
                 vf = adv ? fv : vf;
-                ni += adv;
+                ni += adv ? 1 : 0;
                 // (kn <= block_pos still: the shift stage moved the start past another key; the walk goes on next iteration)
-                const int piece = in_op & (int)(kn > block_pos);
+                const bool piece = in_op & (kn > block_pos);
                 const int pend = wv::imin(seg_end, kn);  // :62-67
                 const int plen = pend - block_pos;
-                const int mapped = bvalid & (int)(vb != NONE32);
-                const int mp = piece & mapped;
-                const int set_start = mp & ism & (has_start ^ 1);  // :84-88
+                const bool mapped = bvalid & (vb != NONE32);
+                const bool mp = piece & mapped;
+                const bool set_start = mp & ism & !has_start;  // :84-88
                 r2s = set_start ? wrap_add(vb, block_pos - kb) : r2s;
-                has_start |= set_start;
+                has_start = has_start | set_start;
                 const int d = wrap_add(vb, -r2e);  // :91-96 (wrapping: vb is NONE32 where the piece is not mapped, and then unused)
-                const int e0 = mp & has_end & (int)(d > 0) & has_start;
-                has_end |= mp;
+                const bool e0 = mp & has_end & (d > 0) & has_start;
+                has_end = has_end | mp;
                 r2e = mp ? wrap_add(vb, pend - kb) : r2e;  // :98-100
                 // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
-                const int e1p = piece & (mapped ? (ism | has_start) : ism);
+                const bool e1p = piece & (mapped ? (ism | has_start) : ism);
                 const int t1p = mapped ? (t == OP_D ? (int)OP_D : (t == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
                 block_pos = piece ? pend : block_pos;
-                const int done = piece & (int)(pend >= seg_end);
-                in_op &= done ^ 1;
+                const bool done = piece & (pend >= seg_end);
+                in_op = in_op & !done;
                 seg_start = done ? seg_end : seg_start;
                 const int wl = cur_off + k;  // ops below R[cur_off + k] have been read
-                lane_push(o, e0, OP_D, d, wl);
-                lane_push(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
+                lane_push<false>(o, e0, OP_D, d, wl);
+                lane_push<false>(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
             }
             PLO_MARK("LIFTOVER LOOP END");
             PLO_LT(3)
             lane_out_finish(o, lo_on, cur_off + n);  // :219-220
             if (lo_on) {
-                ovf |= o.ovf;
+                ovf = ovf | o.ovf;
                 if (!has_start) {  // :218 ref2_start_pos.map(...) on None
                     status = PLO_ITEM_NO_LIFTOVER;
                     alive = false;
@@ -653,8 +673,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // On a CIGAR the liftover has just cleaned and compressed the function is the identity unless some indel cluster has more
         // than one op (see lift_tile); such items -- most -- take no part.
         if (stages & PLO_STAGE_SIMPLIFY) {
-            const int s_on = (simp && (!(stages & PLO_STAGE_LIFTOVER) || pairs)) ? 1 : 0;
-            if (wv::ballot(s_on != 0) != 0ull) {
+            const bool s_on = simp && (!(stages & PLO_STAGE_LIFTOVER) || pairs);
+            if (wv::ballot(s_on) != 0ull) {
                 unsigned long long chrom_ref = 0;
                 int chrom_ref_len = 0;
                 if (s_on) {
@@ -665,26 +685,26 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 LaneOut o;
                 o.R = R;
                 int ref_head = pos, read_head = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0, cmp = 0;
-                int in_blk = 0, spanic = 0;
+                bool in_blk = false, spanic = false, zero_m = false;
                 const int nmax = wv::reduce_max(s_on ? n : 0);
                 for (int k = 0; k <= nmax; ++k) {
-                    const int valid = s_on & (int)(k < n);
-                    const int atend = s_on & (int)(k == n);
+                    const bool valid = s_on & (k < n);
+                    const bool atend = s_on & (k == n);
                     const uint32_t c = R[cur_off + (valid ? k : 0)];
                     const int t = op_type(c), L = op_len(c);
-                    const int indel = valid & i_is_indel(t);
+                    const bool indel = valid & b_is_indel(t);
                     const int wl = cur_off + wv::imin(k + 1, n);
-                    const int endc = in_blk & (indel ^ 1) & (valid | atend);
-                    if (wv::ballot(endc != 0) != 0ull) {  // CigarBlockInfo::end_indel (:35-111)
+                    const bool endc = in_blk & !indel & (valid | atend);
+                    if (wv::ballot(endc) != 0ull) {  // CigarBlockInfo::end_indel (:35-111)
                         // :41-44 one kind only (nothing for 0 / 0); :45-48 1 / 1 -> M(1); else the base comparisons
-                        const int single = endc & ((int)(del == 0) | (int)(ins == 0));
-                        const int one_one = endc & (int)(del == 1) & (int)(ins == 1);
-                        const int cplx = endc & (single ^ 1) & (one_one ^ 1);
-                        int pre = one_one, post = 0;
-                        if (wv::ballot(cplx != 0) != 0ull) {
+                        const bool single = endc & ((del == 0) | (ins == 0));
+                        const bool one_one = endc & (del == 1) & (ins == 1);
+                        const bool cplx = endc & !single & !one_one;
+                        int pre = one_one ? 1 : 0, post = 0;
+                        if (wv::ballot(cplx) != 0ull) {
                             if (cplx) {
                                 if (blk_ref < 0 || blk_ref + del - 1 >= chrom_ref_len || blk_read + ins - 1 >= rd.len) {
-                                    spanic = 1;  // slice index out of bounds: the reference panics (:58-60)
+                                    spanic = true;  // slice index out of bounds: the reference panics (:58-60)
                                     del = 0;
                                     ins = 0;
                                 } else {
@@ -703,29 +723,31 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                                 }
                             }
                         }
-                        const int emit_id = endc & (one_one ^ 1);
-                        lane_push(o, endc & (int)(pre > 0), OP_M, pre, wl);  // :101-104
-                        lane_push(o, emit_id & (int)(ins > 0), OP_I, ins, wl);
-                        lane_push(o, emit_id & (int)(del > 0), OP_D, del, wl);
-                        lane_push(o, endc & (int)(post > 0), OP_M, post, wl);
+                        const bool emit_id = endc & !one_one;
+                        lane_push<false>(o, endc & (pre > 0), OP_M, pre, wl);  // :101-104
+                        lane_push<false>(o, emit_id & (ins > 0), OP_I, ins, wl);
+                        lane_push<false>(o, emit_id & (del > 0), OP_D, del, wl);
+                        lane_push<false>(o, endc & (post > 0), OP_M, post, wl);
                         del = endc ? 0 : del;
                         ins = endc ? 0 : ins;
-                        in_blk &= endc ^ 1;
+                        in_blk = in_blk & !endc;
                     }
-                    const int open = indel & (in_blk ^ 1);  // _add_indel (:16-22)
+                    const bool open = indel & !in_blk;  // _add_indel (:16-22)
                     blk_ref = open ? ref_head : blk_ref;
                     blk_read = open ? read_head : blk_read;
-                    in_blk |= indel;
-                    del += (indel & (int)(t == OP_D)) ? L : 0;
-                    ins += (indel & (int)(t == OP_I)) ? L : 0;
-                    lane_push(o, valid & (indel ^ 1), t, L, wl);  // :144-147
-                    read_head += (valid & i_read_cons(t)) ? L : 0;
-                    ref_head += (valid & i_ref_cons(t)) ? L : 0;
+                    in_blk = in_blk | indel;
+                    del += (indel & (t == OP_D)) ? L : 0;
+                    ins += (indel & (t == OP_I)) ? L : 0;
+                    const bool cp = valid & !indel;
+                    zero_m = zero_m | (cp & b_is_match(t) & (L == 0));  // an edge mark the writer would not see (LaneOut)
+                    lane_push<true>(o, cp, t, L, wl);  // :144-147
+                    read_head += (valid & b_read_cons(t)) ? L : 0;
+                    ref_head += (valid & b_ref_cons(t)) ? L : 0;
                 }
                 lane_out_finish(o, s_on, cur_off + n);  // :153-154
                 if (s_on) {
                     algo += 2u * (unsigned)cmp;
-                    ovf |= o.ovf;
+                    ovf = ovf | o.ovf | zero_m;
                     n = o.no;
                     cur_off = 0;
                     pos += o.lead_shift;  // :155
@@ -801,8 +823,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             ctx.out_ops += (unsigned)oc;
         }
         PLO_LT(6)
+        PLO_LC(11, 1)
     }
 #undef PLO_LT
+#undef PLO_LC
 }
 
 // Persistent wave over the groups of the lane classes: class c (0: no shift stage, 1: shift stage) occupies positions

@@ -2,6 +2,7 @@
 // wave64 emulator (tests/emu/plo_wave.hpp).  TEST INFRASTRUCTURE ONLY: never linked into the product library.
 #include <plo_wave.hpp>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -167,6 +168,16 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         nin_p[j] = item_cls[i] >= 2 ? item_nin[i] : 0;  // only the large items are tiled
     }
     const uint32_t n_small = r0[n_items] + r1[n_items], n_large = n_items - n_small;
+    {   // k_chunk_sort: the lane part of the class order sorted by weight inside chunks of 2048 positions (per class)
+        const uint32_t CH = 2048, n0 = r0[n_items], n1 = r1[n_items];
+        auto sort_range = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t a0 = lo; a0 < hi; a0 += CH)
+                std::stable_sort(perm.begin() + a0, perm.begin() + std::min(hi, a0 + CH),
+                                 [&](uint32_t x, uint32_t y) { return std::min(item_nin[x], 255u) < std::min(item_nin[y], 255u); });
+        };
+        sort_range(0, n0);
+        sort_range(n0, n0 + n1);
+    }
     wk.perm = perm.data();
     wk.n_small = n_small;
     wk.retry_list = retry_list.data();

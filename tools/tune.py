@@ -68,8 +68,11 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         L.plo_ctx_phase_cycles(eng.handle, ph)
         tot = sum(ph) or 1
         if t.n_lane_items:
-            names = ["desc+alloc", "load", "shift walk", "liftover", "lift finish", "simplify", "output", "-", "-", "-", "-", "-"]
-            print("   lane phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names) if n != "-") + f"   cycles/group {tot / max(1, t.n_lane_items / 64):.0f}", flush=True)
+            names = ["desc+alloc", "load", "shift walk", "liftover", "lift finish", "simplify", "output"]
+            tot = sum(ph[:7]) or 1
+            grp = max(1, ph[11])  # (rounds of groups; wave-uniform counters, flushed by lane 0)
+            print("   lane phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/group {tot / grp:.0f}", flush=True)
+            print(f"   trip counts per group: liftover iterations {ph[7]/grp:.1f}  shift rounds {ph[8]/grp:.1f}  scan iterations {ph[9]/grp:.1f}  load batches {ph[10]/grp:.1f}  (groups {grp})", flush=True)
         names = ["desc", "load+lshiftA", "lshift cc", "lift:stage+passA", "lift:scatter+passB", "lift:cc", "lencheck", "simplify A+H+B", "simplify cc", "output", "lshift H", "lshift B"]
         print("   phase share: " + "  ".join(f"{n} {100*ph[i]/tot:.1f}%" for i, n in enumerate(names)) + f"   cycles/tile-wave {tot/ max(1,(t.n_in_ops//(int(win) if win != 'auto' else 256)+1)):.0f}", flush=True)
     eng.close()
