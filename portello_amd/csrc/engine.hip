@@ -208,18 +208,18 @@ __global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, co
 // contig, and the groups of a chunk run on one XCD at about the same time, which is what keeps the contig lines their homology
 // probes share in that XCD's L2 (a global sort would fetch them from HBM once per read instead of once).
 // One workgroup per chunk: counting sort in LDS (weights are bounded by the lane path's limit, <= 255 bins + clamp).
-constexpr uint32_t LANE_SORT_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_CHUNK / LANE_SORT_THREADS;
-__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1) {
+constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_MAX_CHUNK / LANE_SORT_THREADS;
+__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
-    const uint32_t c0 = (n0 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK;
+    const uint32_t c0 = (n0 + chunk - 1) / chunk;
     uint32_t lo, hi;
     if (blockIdx.x < c0) {  // chunks do not straddle the two lane classes
-        lo = blockIdx.x * LANE_SORT_CHUNK;
-        hi = lo + LANE_SORT_CHUNK < n0 ? lo + LANE_SORT_CHUNK : n0;
+        lo = blockIdx.x * chunk;
+        hi = lo + chunk < n0 ? lo + chunk : n0;
     } else {
-        lo = n0 + (blockIdx.x - c0) * LANE_SORT_CHUNK;
-        hi = lo + LANE_SORT_CHUNK < n0 + n1 ? lo + LANE_SORT_CHUNK : n0 + n1;
+        lo = n0 + (blockIdx.x - c0) * chunk;
+        hi = lo + chunk < n0 + n1 ? lo + chunk : n0 + n1;
     }
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -450,8 +450,11 @@ constexpr int LANE_WAVES = 4;
 #ifndef PLO_LANE_WPE
 #define PLO_LANE_WPE 3
 #endif
+#ifndef PLO_LANE_WPE_MIN
+#define PLO_LANE_WPE_MIN PLO_LANE_WPE
+#endif
 template <bool SP>
-PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw) {
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw, uint32_t chunk_groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
@@ -464,16 +467,16 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
         ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
+    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, chunk_groups, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t n1, int capw) {
-    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw);
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                   uint32_t n1, int capw, uint32_t chunk_groups) {
+    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw, chunk_groups);
 }
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                      uint32_t n1, int capw) {
-    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw);
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                      uint32_t n1, int capw, uint32_t chunk_groups) {
+    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw, chunk_groups);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
@@ -856,7 +859,7 @@ struct plo_ctx {
     // per item -- 36 KB of LDS per wave, synchronous probes -- was a net loss and had been removed; this is a different kernel.)
     int lane_max_w = 192;
     int lane_capw = 3072;
-    bool lane_sort = true;  // k_chunk_sort: groups of similar weight
+    int lane_chunk_groups = 1;  // k_chunk_sort: groups of 64 per sorted chunk of the class order (1: no sorting)
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1091,8 +1094,8 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
-    if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
-    if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e)));
+    if (const char *e = getenv("PLO_LANE_CHUNK_GROUPS")) c->lane_chunk_groups = std::min(32, std::max(1, atoi(e)));
+    if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_WINDOW")) c->window = std::max(16, atoi(e)), c->adaptive = false;
@@ -1461,10 +1464,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.slab_offset = 0;
         if (n_small) {
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
-            if (attempt == 0 && c->lane_sort) {
-                const uint32_t chunks = (n0 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK + (n1 + LANE_SORT_CHUNK - 1) / LANE_SORT_CHUNK;
+            if (attempt == 0 && c->lane_chunk_groups > 1) {
+                const uint32_t ch = 64u * (uint32_t)c->lane_chunk_groups;
+                const uint32_t chunks = (n0 + ch - 1) / ch + (n1 + ch - 1) / ch;
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
-                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1);
+                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
             }
             const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
             const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
@@ -1476,8 +1480,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
-            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw, (uint32_t)c->lane_chunk_groups);
+            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw, (uint32_t)c->lane_chunk_groups);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));

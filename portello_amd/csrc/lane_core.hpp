@@ -33,6 +33,13 @@
 
 namespace plo {
 
+// 32 readable bytes in global memory: where the lanes without a usable probe window point their (unconditional) loads
+#ifdef PLO_EMULATOR
+static const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+static __device__ const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
 constexpr int LANE_SLACK = 2;  // dwords on top of an item's weight (the shift stage may add an op per cluster in odd cases)
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -146,33 +153,42 @@ PLO_DEV void lane_out_finish(LaneOut &o, bool on, int wlim) {
 // -------------------------------------------------------------------------------------------------------------------
 // xor_window16 (lift_core.hpp) in two halves for the dense sequence formats: the loads now, the decode later.
 // -------------------------------------------------------------------------------------------------------------------
+// (the words stay in the shape they are loaded in -- a 16-byte vector and a fifth word per side -- until xw16_decode: loop-carried
+// registers of another shape would be filled by copies from the load's destination, i.e. behind a wait for the load)
 struct XW16 {
-    unsigned wr[5], wq[5];
+    Ops4 r4, q4;
+    uint32_t r1, q1;
     int rsh, qsh, jmin;
 };
-PLO_DEV bool xw16_issue(const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, XW16 &w) {
-    if (rd.fmt == PLO_SEQ_BAM4_SPARSE) return false;  // granule look-ups first: those batches probe synchronously
-    if (r0 < 0 || q0 < 0 || q0 > rd.len - 16) return false;
+// Straight-line: every lane loads (lanes without a usable window from the start of `safe`, which must be readable for 20 bytes),
+// and nothing looks at the loaded words before xw16_decode -- a select on them would put the wait for the round trip right here.
+// Returns whether the lane's window is usable.
+PLO_DEV bool xw16_issue(bool on, const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, const uint8_t *safe, XW16 &w) {
+    bool ok = on & (rd.fmt != PLO_SEQ_BAM4_SPARSE);  // (granule look-ups first: those batches probe synchronously)
+    ok = ok & (r0 >= 0) & (q0 >= 0) & (q0 <= rd.len - 16);
     const int rsh = (int)(((unsigned)(uintptr_t)ref + (unsigned)r0) & 3u);
-    if (r0 - rsh < 0 || r0 - rsh > ref_len - 20) return false;
+    ok = ok & (r0 - rsh >= 0) & (r0 - rsh <= ref_len - 20);
     const int jmin = rd.flip ? rd.len - q0 - 16 : q0;
     const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
     const int b0 = bam4 ? (jmin >> 1) : jmin;
     const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
-    const int qwords = bam4 ? 3 : 5;
-    if (b0 - qsh < rd.lo || b0 - qsh + 4 * qwords > rd.hi) return false;
-    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ref + (r0 - rsh));
-    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(rd.p + (b0 - qsh));
-#pragma unroll
-    for (int u = 0; u < 5; ++u) w.wr[u] = pr[u];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) w.wq[u] = u < qwords ? pq[u] : 0u;
+    ok = ok & (b0 - qsh >= rd.lo) & (b0 - qsh + 20 <= rd.hi);  // five words, whatever the format needs
+    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ok ? ref + (r0 - rsh) : safe);
+    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(ok ? rd.p + (b0 - qsh) : safe);
+    w.r4 = *(const PLO_GLOBAL Ops4 *)pr;
+    w.r1 = pr[4];
+    w.q4 = *(const PLO_GLOBAL Ops4 *)pq;
+    w.q1 = pq[4];
     w.rsh = rsh;
     w.qsh = qsh;
     w.jmin = jmin;
-    return true;
+    return ok;
 }
-PLO_DEV void xw16_decode(const ReadSeq &rd, const XW16 &w, unsigned X[4]) {
+PLO_DEV void xw16_decode(const ReadSeq &rd, const XW16 &wx, unsigned X[4]) {
+    struct {
+        unsigned wr[5], wq[5];
+        int rsh, qsh, jmin;
+    } w = {{wx.r4.x, wx.r4.y, wx.r4.z, wx.r4.w, wx.r1}, {wx.q4.x, wx.q4.y, wx.q4.z, wx.q4.w, wx.q1}, wx.rsh, wx.qsh, wx.jmin};
     const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
     unsigned D[4];
     if (bam4) {
@@ -219,21 +235,20 @@ struct LaneProbe {
     int re = 0, qe = 0, maxk = 0;
     bool async_ok = false;
 };
-// `on`: the lanes whose cluster ends; sets their `panic` where the reference's slice index would
+// Wave-uniform call that overwrites the probe of EVERY lane (none is pending when it is made: an event resolves the lane's pending
+// cluster first).  `on`: the lanes whose cluster ends; sets their `panic` where the reference's slice index would.
 PLO_DEV void lane_probe_issue(LaneProbe &p, bool on, const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins,
-                              int bound, bool &panic) {
+                              int bound, const uint8_t *safe, bool &panic) {
     const int re = rs + del, qe = qs + ins;
     const int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
     int maxk = wv::imin(max_left, bound);
     const bool bad = (max_left > 0) & ((re - 1 >= ref_len) | (qe - 1 >= rd.len));  // slice-index panic (:38-39)
     panic = panic | (on & bad);
-    maxk = bad ? 0 : maxk;
-    bool ok = false;
-    if (on && maxk > 0) ok = xw16_issue(ref, ref_len, re - 16, rd, qe - 16, p.w);
-    p.re = on ? re : p.re;
-    p.qe = on ? qe : p.qe;
-    p.maxk = on ? maxk : p.maxk;
-    p.async_ok = on ? ok : p.async_ok;
+    maxk = (bad | !on) ? 0 : maxk;
+    p.async_ok = xw16_issue(on & (maxk > 0), ref, ref_len, re - 16, rd, qe - 16, safe, p.w);
+    p.re = re;
+    p.qe = qe;
+    p.maxk = maxk;
 }
 PLO_DEV int match_run_back_from(const uint8_t *ref, int ref_len, int re, ReadSeq &rd, int qe, int maxk, int k, int &probes) {
     while (k < maxk) {
@@ -289,7 +304,10 @@ PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, i
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords (+ one spare dword behind it).
+// One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords.
+// (Measured and dropped: the group's CIGAR span copied into LDS with coalesced loads and picked apart there, results gathered in
+// LDS and stored coalesced -- 37 % slower than every lane reading / writing its own 16 bytes: the extra LDS round trips cost more
+// than the scattered requests.)
 // -------------------------------------------------------------------------------------------------------------------
 template <bool SP>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
@@ -335,8 +353,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         const bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
         do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
     }
-    const int nblk = has ? wv::imax(0, wv::imin(W1 + 1, kv1) - W0) : 0;
-    const int gap = 2 * nblk;               // room in front of a stage's input: what the liftover may add to it
+    // Room in front of a stage's input = what the liftover may add to it: one more piece per key of the block map inside the
+    // item's span -- entries W0+1 .. W1-1, and W0 itself when no block holds the item's start -- and one jump deletion (:91-96)
+    // per block entered that way.
+    const int gap = has ? 2 * wv::imax(0, W1 - W0) : 0;
     const int W = n_in + gap + LANE_SLACK;  // the item's region, dwords
 
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
@@ -518,7 +538,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (wv::ballot(res) != 0ull) resolve(res);
                     if (pass == 1) break;
                     if (wv::ballot(endc) != 0ull) {
-                        lane_probe_issue(pr, endc, sref, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, panic);
+                        lane_probe_issue(pr, endc, sref, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, (const uint8_t *)plo_safe_words, panic);
                         p_match = endc ? match : p_match;
                         p_ins = endc ? ins : p_ins;
                         p_del = endc ? del : p_del;
@@ -834,17 +854,21 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // Group indices: class 0 first.  The item indices of the next group are fetched one group ahead.
 template <bool SP>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
-                                   uint32_t n0, uint32_t n1, uint32_t *lds, int capw, WaveCtx &ctx) {
+                                   uint32_t n0, uint32_t n1, uint32_t LANE_CHUNK_GROUPS, uint32_t *lds, int capw, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
     const uint32_t t0 = (n0 + 63u) >> 6, t1 = (n1 + 63u) >> 6;
+    // The order is sorted by weight inside chunks of LANE_CHUNK_GROUPS groups (k_chunk_sort; 1 = unsorted) and the number of waves is
+    // usually a multiple of that: without the per-chunk rotation a wave would take the same rank -- say, the heaviest group -- of
+    // every chunk.
     auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
-        if (t < t0) {
-            lo = t * 64u;
-            hi = lo + 64u < n0 ? lo + 64u : n0;
-        } else {
-            lo = n0 + (t - t0) * 64u;
-            hi = lo + 64u < n0 + n1 ? lo + 64u : n0 + n1;
-        }
+        const bool c1 = t >= t0;
+        const uint32_t base = c1 ? n0 : 0u, end = c1 ? n0 + n1 : n0, tc = c1 ? t - t0 : t, nt = c1 ? t1 : t0;
+        const uint32_t chunk = tc / LANE_CHUNK_GROUPS, r = tc % LANE_CHUNK_GROUPS;
+        const uint32_t ng = nt - chunk * LANE_CHUNK_GROUPS < LANE_CHUNK_GROUPS ? nt - chunk * LANE_CHUNK_GROUPS : LANE_CHUNK_GROUPS;
+        const uint32_t rot = ((chunk + (c1 ? 7u : 0u)) * 0x9E3779B1u) >> 16;
+        const uint32_t tt = chunk * LANE_CHUNK_GROUPS + (r + rot) % ng;
+        lo = base + tt * 64u;
+        hi = lo + 64u < end ? lo + 64u : end;
     };
     uint32_t t = first;
     uint32_t g_next = 0;

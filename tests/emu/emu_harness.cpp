@@ -168,8 +168,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         nin_p[j] = item_cls[i] >= 2 ? item_nin[i] : 0;  // only the large items are tiled
     }
     const uint32_t n_small = r0[n_items] + r1[n_items], n_large = n_items - n_small;
-    {   // k_chunk_sort: the lane part of the class order sorted by weight inside chunks of 2048 positions (per class)
-        const uint32_t CH = 2048, n0 = r0[n_items], n1 = r1[n_items];
+    {   // k_chunk_sort: the lane part of the class order sorted by weight inside chunks of 4 groups (per class)
+        const uint32_t CH = 64 * 4, n0 = r0[n_items], n1 = r1[n_items];
         auto sort_range = [&](uint32_t lo, uint32_t hi) {
             for (uint32_t a0 = lo; a0 < hi; a0 += CH)
                 std::stable_sort(perm.begin() + a0, perm.begin() + std::min(hi, a0 + CH),
@@ -209,8 +209,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
                 w.run([&]() {
                     WaveCtx ctx;
-                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
-                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
+                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], 4u, llds.data(), lane_capw, ctx);
+                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], 4u, llds.data(), lane_capw, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();
