@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from portello_amd import abi, api, devbatch, shard, synth  # noqa: E402
+from portello_amd import build as plo_build  # noqa: E402
 from portello_amd import gather as plo_gather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -105,7 +106,7 @@ def pipeline_cpus() -> int:
     return pipeline.effective_cpus()
 
 
-def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: int, io_threads: int, pcie_reads: int = 60000):
+def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: int, io_threads: int, pcie_reads: int = 60000, verify: bool = True):
     """BAM file in -> lifted BAM file out on a bounded sample of the workload (a block of consecutive reads from the middle of
     the coordinate-sorted read set, written as a real BGZF-compressed read->contig BAM first): BGZF inflate + record parsing +
     batch construction -> page-locked H2D -> lift kernels -> D2H -> BAM record assembly (tags, flags, reversed seq/qual) ->
@@ -140,6 +141,24 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                "sample": f"reads [{lo}, {lo + n}) of the workload as a BGZF level-1 read->contig BAM (synthetic qualities / aux tags, "
                          f"written in {t_write:.1f} s outside the timed run); output BGZF level 0",
                "note": "supplementary: one GPU, one node's host cores; `value` of the bench line stays the HBM-resident kernel rate"}
+        if verify:
+            # after the timed run: the written BAM re-read with the independent reader and compared, record for record, with the
+            # expectation (oracle alignments + the Python restatement of the record logic) for a strided sample of >= 5 000 reads
+            try:
+                from oracle import expect
+
+                every = max(1, (n // 500) // 12)
+                t0 = time.perf_counter()
+                v = expect.verify_lifted_bam(inp, outp, ixd, cn, rn, window=500, every=every, threads=min(16, io_threads),
+                                             unassembled_bam=os.path.join(d, "unassembled.bam"))
+                v["seconds"] = time.perf_counter() - t0
+                e2e["records_verified"] = v["records_verified"] if v["ok"] else 0
+                e2e["verification"] = v
+                if not v["ok"]:
+                    log("[bench] END-TO-END VERIFICATION FAILURE: the written BAM differs from the expected records")
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] end_to_end verification could not run: {e!r}")
+                e2e["records_verified"] = None
         # the host-buffer entry point alone: whole sample in one window, dense bases and sparse bases (margin 32)
         rd = bam.BamReader(inp, io_threads)
         eng = api.Engine(index)
@@ -382,12 +401,16 @@ def main():
         # attribute them to the dominant kernel in proportion to its share of the lift time
         share = dom_ms / max(1e-9, sum(kms.values()))
         achieved = (tm.algo_bytes * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic from the PMC counters (profiles/hbm_traffic.json, refreshed by tools/save_profiles.py): reported only when the
+        # entry was collected on this workload, this read count and these very kernel sources -- else null
         traffic = None
+        src_hash = plo_build.source_hash()
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
             try:
-                tr = json.load(open(prof))
-                traffic = tr.get(cfg.name, {}).get(dom_name, tr.get(cfg.name, {}).get(dominant))
+                ent = json.load(open(prof)).get(cfg.name, {})
+                if ent.get("_reads") == int(my_reads) and ent.get("_source_hash") == src_hash and ent.get("_n_gpus", 1) == world:
+                    traffic = ent.get(dom_name, ent.get(dominant))
             except Exception:
                 traffic = None
 
@@ -410,7 +433,7 @@ def main():
                        "retry_items_per_gpu": int(tm.n_retry_items), "lane_items_per_gpu": int(tm.n_lane_items), "seq_fmt": "bam4",
                        "tile_geometry": {"slice_elements": int(tm.tile_cap), "window": int(tm.tile_window)},
                        "parallelism": (f"one read set, 20 Mb windows dealt to {world} ranks by input ops" if strong else f"{world} independent read sets"),
-                       "host_workers_per_gpu": n_workers,
+                       "host_workers_per_gpu": n_workers, "kernel_source_hash": src_hash,
                        "gather": gather_desc},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
@@ -439,13 +462,29 @@ def main():
 
         pending_print = [fallback]  # what rank 0 prints if the next RCCL section does not come back
 
+        # A collective that hangs or fails must not look like a healthy N-GPU run: the line rank 0 prints then has
+        # "gather_failed": true at top level and "value": null (the complete no-gather measurement stays in `no_gather`), and
+        # every rank exits non-zero.
+        def failed_line(reason):
+            r = dict(pending_print[0])
+            r["no_gather"] = {"value": r["value"], "unit": "reads/s", "ms_per_step": r["ms_per_step"],
+                              "note": "same K steps without the record gather (each rank keeps / writes its own shard)"}
+            r["value"] = None
+            r["gather_failed"] = True
+            r["gather_failure"] = reason
+            return r
+
         def gather_bail():
-            log("[bench] an RCCL record gather did not finish in time: printing the last complete measurement")
+            log("[bench] an RCCL record gather did not finish in time")
             if rank == 0:
-                print(json.dumps(pending_print[0]), flush=True)
-            os._exit(0)
+                print(json.dumps(failed_line("timeout: a record gather did not come back within PLO_BENCH_GATHER_TIMEOUT")), flush=True)
+            os._exit(3)
+
+        gather_error = [None]
 
         def guarded(fn):
+            if gather_error[0] is not None:  # (after an RCCL error the next collective would only hang until the watchdog fires)
+                return None
             wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "150")), gather_bail)
             wd.daemon = True
             wd.start()
@@ -453,6 +492,7 @@ def main():
                 return fn()
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] RCCL record gather failed: {e!r}")
+                gather_error[0] = repr(e)
                 return None
             finally:
                 wd.cancel()
@@ -464,6 +504,10 @@ def main():
 
         dt_sync = guarded(sync_run)
         result = fallback
+        if dt_sync is None:
+            if rank == 0:
+                print(json.dumps(failed_line(gather_error[0] or "the synchronous record gather failed")), flush=True)
+            os._exit(3)
         if dt_sync is not None:
             result = make_result(dt_sync, "rccl send/recv to rank 0 after every step")
             pending_print[0] = result
@@ -547,9 +591,10 @@ def main():
         def bail():
             log("[bench] the supplementary distributed measurements did not finish in time: printing the headline result without them")
             result["supplementary_timed_out"] = True
+            result["degraded"] = True
             if rank == 0:
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(4)  # the headline (gathered) measurement is complete and printed; a collective of the supplementary part hung
 
         watchdog = threading.Timer(float(os.environ.get("PLO_BENCH_SUPP_TIMEOUT", "300")), bail)
         watchdog.daemon = True
@@ -592,7 +637,8 @@ def main():
     if rank == 0 and world == 1 and dist is None and args.e2e_reads > 0:
         try:
             ixd_host = w.index_data()
-            e2e, pcie = end_to_end(w, index, ixd_host, args.e2e_reads, args.e2e_window, args.e2e_workers, int(os.environ.get("PLO_BENCH_IO_THREADS", "0")) or max(2, min(64, pipeline_cpus())))
+            e2e, pcie = end_to_end(w, index, ixd_host, args.e2e_reads, args.e2e_window, args.e2e_workers, int(os.environ.get("PLO_BENCH_IO_THREADS", "0")) or max(2, min(64, pipeline_cpus())),
+                                   verify=not args.no_cpu_baseline)
             result["end_to_end"] = e2e
             if pcie is not None:
                 result["pcie_inclusive"] = pcie

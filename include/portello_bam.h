@@ -24,7 +24,7 @@
  *
  * Parity: the aux / set() / bam_write1 byte semantics restate third-party code that is absent from the reference
  * tree -- "parity unpinned by the reference's tests"; the SA / split-segment parsing is pinned by split_read.rs:198-232
- * and sa_tag_parser.rs:66-77 (tests/golden/reference_vectors.json, "split_segments").
+ * and sa_tag_parser.rs:66-77 (transcribed in tests/test_bam.py: test_sa_parser_reference_vector, test_split_segments_reference_vectors).
  *
  * Conventions as in portello_liftover.h: int status, no unwinding, plo_bam_last_error() for the message; objects are
  * single-threaded (internally they use `n_threads` worker threads for (de)compression and record assembly).
@@ -58,7 +58,8 @@ plo_status plo_bam_header(const plo_bam_reader *r, const char **text, uint32_t *
 
 /* Next window of the file: at most max_records primary records (fewer at the end of the file; 0 = end).
  * Records are classified as the reference does:
- *   unmapped flag set                     -> pass-through list (scan_unmapped_reads :551-555)
+ *   unmapped flag set, no reference id    -> pass-through list (scan_unmapped_reads :551-555)
+ *   unmapped flag set, reference id >= 0  -> PLO_ERR_DATA (the reference's window loop asserts !is_unmapped(), :396)
  *   supplementary flag set                -> skipped (:404)
  *   everything else                       -> a primary read of the batch
  * The window owns copies of the record bytes. */

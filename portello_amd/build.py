@@ -20,6 +20,18 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def source_hash() -> str:
+    """identifies the kernel sources a measurement was made with (profiles/hbm_traffic.json entries carry it: bench.py reports a
+    counter-derived traffic figure only for the very code, workload and read count it was collected on)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_timing() -> str:
     """instrumented variant (per-phase s_memtime accumulation) used by tools/tune.py only"""
     out = os.path.join(HERE, "libportello_liftover_timing.so")

@@ -154,6 +154,12 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
             break;
         }
         uint16_t flag = rec.flag();
+        if ((flag & 0x4) && rec.tid() >= 0) {
+            // an unmapped record placed on a contig (its mate's position): the reference's window loop asserts
+            // !record.is_unmapped() (src/read_alignment_scanner.rs:396) -- its unmapped fetch (:544) only sees tid = -1 records
+            st = fail(PLO_ERR_DATA, "unmapped record placed on a contig (flag 0x4 with a reference id): the reference aborts on it (read_alignment_scanner.rs:396)");
+            break;
+        }
         if (flag & 0x4) unm_at.push_back(at);                 // scan_unmapped_reads :551-555
         else if (!(flag & 0x800)) w->rec_at.push_back(at);    // :404 supplementary records are reached through the primary's SA tag
         at += 4 + (size_t)bs;

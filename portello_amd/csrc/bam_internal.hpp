@@ -611,23 +611,28 @@ bool parse_cigar_text(const char *s, const char *e, std::vector<uint32_t> &out) 
     return true;
 }
 
-// get_seq_order_read_split_segments (split_read.rs:56-155) of one primary record.  Long CIGARs stored in the CG tag
-// (more than 65535 ops) are what htslib hands to the reference after bam_read1: the real CIGAR.
-plo_status split_segments(const std::unordered_map<std::string, uint32_t> &label_to_index, const Rec &rec, std::vector<SaSeg> &out, std::vector<uint32_t> &primary_cigar,
-                          std::string &err) {
-    out.clear();
+// The CIGAR htslib hands to the reference for ANY record after bam_read1: a long one (more than 65535 ops) is stored in the
+// CG:B,I tag behind the placeholder <l_seq>S<ref_len>N and restored on read.
+inline void real_cigar(const Rec &rec, std::vector<uint32_t> &cigar) {
     const uint32_t nc = rec.n_cigar();
-    primary_cigar.resize(nc);
-    for (uint32_t i = 0; i < nc; ++i) primary_cigar[i] = rd32(rec.cigar() + 4 * (size_t)i);
-    if (nc == 2 && (primary_cigar[0] & 15u) == 4 && (primary_cigar[0] >> 4) == rec.l_seq() && (primary_cigar[1] & 15u) == 3) {
+    cigar.resize(nc);
+    for (uint32_t i = 0; i < nc; ++i) cigar[i] = rd32(rec.cigar() + 4 * (size_t)i);
+    if (nc == 2 && (cigar[0] & 15u) == 4 && (cigar[0] >> 4) == rec.l_seq() && (cigar[1] & 15u) == 3) {
         size_t fl = 0;
         const uint8_t *cg = aux_find(rec.aux(), rec.end(), "CG", &fl);
         if (cg && cg[2] == 'B' && cg[3] == 'I') {
             uint32_t n = rd32(cg + 4);
-            primary_cigar.resize(n);
-            for (uint32_t i = 0; i < n; ++i) primary_cigar[i] = rd32(cg + 8 + 4 * (size_t)i);
+            cigar.resize(n);
+            for (uint32_t i = 0; i < n; ++i) cigar[i] = rd32(cg + 8 + 4 * (size_t)i);
         }
     }
+}
+
+// get_seq_order_read_split_segments (split_read.rs:56-155) of one primary record.
+plo_status split_segments(const std::unordered_map<std::string, uint32_t> &label_to_index, const Rec &rec, std::vector<SaSeg> &out, std::vector<uint32_t> &primary_cigar,
+                          std::string &err) {
+    out.clear();
+    real_cigar(rec, primary_cigar);
     const bool fwd = !(rec.flag() & 0x10);
     uint64_t rs, re, rsize;
     read_clip_positions(primary_cigar.data(), primary_cigar.size(), rs, re, rsize);

@@ -297,8 +297,8 @@ plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const
             ct.qname = qname;
             ct.have_primary = true;
         } else {  // add_split_read_cigar_to_supp_cigar_set (:135-183)
-            Cigar cg(rec.n_cigar());
-            for (uint32_t i = 0; i < rec.n_cigar(); ++i) cg[i] = rd32(rec.cigar() + 4 * (size_t)i);
+            Cigar cg;
+            real_cigar(rec, cg);  // (a long CIGAR comes in the CG tag, as for the primary record)
             SplitReadKey k = key_of((uint32_t)rec.tid(), rec.pos(), !(flag & 0x10), cg);
             if (!ct.supp.emplace(k, std::move(cg)).second)
                 return bail(fail(PLO_ERR_DATA, "Can't uniquely identify split read alignment info in contig '" + qname + "'"));

@@ -12,40 +12,12 @@ import pytest
 import bamcheck
 from oracle import pyrecords as pr
 from portello_amd import abi, api, bam, bamsynth, synth
+from oracle.expect import expected_records  # (shared with bench.py's verification of its end-to-end sample)
 from portello_amd import cigar as cg
 
 
 def _label_to_index(names):
     return {n: i for i, n in enumerate(names)}
-
-
-def expected_records(rec_bytes, ix: abi.IndexData, contig_names, ref_names, res: abi.BatchResult, is_target_region=False):
-    """the reference's per-read loop (src/read_alignment_scanner.rs:393-488) in pure Python, lifted alignments taken from `res`;
-    also checks the item enumeration (a8) and need_flipped (a9) of `res` against the Python glue"""
-    l2i = _label_to_index(contig_names)
-    out, k, seg_global = [], 0, 0
-    for rb in rec_bytes:
-        rec = pr.record_from_bytes(rb)
-        segs = pr.get_seq_order_read_split_segments(l2i, rec)
-        remapped = []
-        for seg in segs:
-            c = seg.chrom_index
-            g0, g1 = int(ix.contig_seg_off[c]), int(ix.contig_seg_off[c + 1])
-            csegs = [(int(ix.seg_seq_order_start[g]), int(ix.seg_seq_order_end[g])) for g in range(g0, g1)]
-            for cseg in pr.get_contig_split_segments_from_read_mapping(seg, csegs):
-                g = g0 + cseg
-                assert int(res.item_seg[k]) == seg_global and int(res.item_cseg[k]) == cseg, (k, seg_global, cseg)
-                cfwd = bool(ix.seg_is_fwd_strand[g])
-                need_flipped, _, _ = pr.strand_glue(rec.is_reverse(), seg, cfwd, int(ix.contig_len[c]))
-                assert int(res.item_need_flipped[k]) == int(need_flipped)
-                if int(res.item_status[k]) == abi.ITEM_LIFTED:
-                    remapped.append(pr.lifted_record(rec, contig_names[c], cseg, cfwd, int(ix.seg_chrom_index[g]), int(ix.seg_mapq[g]),
-                                                     need_flipped, int(res.item_ref_pos[k]), [int(x) for x in res.item_cigar(k)]))
-                k += 1
-            seg_global += 1
-        out += pr.finish_remapped_alignment_set(ref_names, rec, remapped, is_target_region)
-    assert k == res.n_items
-    return [r.to_bytes() for r in out]
 
 
 def test_sa_parser_reference_vector():
@@ -385,3 +357,52 @@ def test_device_inflate_matches_host_inflate(tmp_path, monkeypatch):
             got[dev] = wins
             print(f"level {level} device {dev}: {time.perf_counter() - t0:.3f} s")
         assert got["0"] == got["1"] and sum(x[0] for x in got["1"]) == w.n_reads
+
+
+def test_unmapped_record_placed_on_a_contig_is_a_data_error(tmp_path):
+    """flag 0x4 with a reference id: the reference's window loop asserts !record.is_unmapped() (read_alignment_scanner.rs:396);
+    only tid = -1 records reach its pass-through copy (:544)"""
+    p = str(tmp_path / "placed.bam")
+    wr = bam.BamWriter(p, "@HD\tVN:1.6\n", ["ctg0"], [1000], level=0)
+    wr.write(_sam_record(0, 5, "10M", "ACGTACGTAC", "IIIIIIIIII"))
+    wr.write(bamsynth.encode_record(0, 17, 0, 0x4, b"placed_unmapped", np.zeros(0, np.uint32), bytes(5), 10, b"\x20" * 10, b""))
+    wr.close()
+    rd = bam.BamReader(p, 1)
+    with pytest.raises(api.PortelloError) as e:
+        rd.read_window(5)
+    assert e.value.status == bam.ERR_DATA
+    rd.close()
+    # the same record without a reference id is passed through
+    p2 = str(tmp_path / "unplaced.bam")
+    wr = bam.BamWriter(p2, "@HD\tVN:1.6\n", ["ctg0"], [1000], level=0)
+    wr.write(_sam_record(0, 5, "10M", "ACGTACGTAC", "IIIIIIIIII"))
+    wr.write(bamsynth.encode_record(-1, -1, 0, 0x4, b"unplaced", np.zeros(0, np.uint32), bytes(5), 10, b"\x20" * 10, b""))
+    wr.close()
+    rd = bam.BamReader(p2, 1)
+    win = rd.read_window(5)
+    assert win.n_records == 1 and win.unmapped_bytes()[1] == 1
+    win.close()
+    rd.close()
+
+
+@pytest.mark.gpu
+def test_bam_to_bam_chr20_size_every_record(tmp_path):
+    """BASELINE configs[1] size (50 k reads): BAM file in -> pipeline.run_bam_to_bam (reader / two lift workers / writer, the path
+    bench.py's end_to_end times) -> BAM file out; the written file, re-read with the independent reader, holds exactly the records
+    expected from the oracle's alignments and the Python restatement of the record logic (every window, every record)"""
+    from oracle import expect
+    from portello_amd import pipeline
+
+    w = synth.generate(synth.config("chr20", n_reads=50_000), device="cuda")
+    inp, outp, unp = str(tmp_path / "reads.bam"), str(tmp_path / "lifted.bam"), str(tmp_path / "unassembled.bam")
+    meta = bamsynth.write_read_bam(w, inp, level=1, n_threads=8)
+    ixd = w.index_data()
+    index = api.Index(w.index_data_device())
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, [int(s.numel()) for s in w.chrom_seq], window_reads=5000, n_workers=2,
+                                 io_threads=8, unassembled_path=unp)
+    assert st.reads == w.n_reads
+    v = expect.verify_lifted_bam(inp, outp, ixd, cn, rn, window=1000, every=1, threads=8, unassembled_bam=unp)
+    assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st.records_out == v["records_in_output"], v
+    assert v["unassembled_ok"]
+    index.close()

@@ -310,6 +310,45 @@ def test_geometry_sweep(oracle):
         index.close()
 
 
+def test_every_item_of_200k_reads(oracle):
+    """tests/soak.py's full-result comparison inside the suite: ALL items of a 200 k-read chr20 workload (207 k items: forward and
+    reverse contigs, split reads, every kernel of the default geometry) against the oracle"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("chr20", n_reads=200_000, seed=synth.config("chr20").seed + 17), device="cuda")
+    index = api.Index(w.index_data_device())
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    got = devbatch.run_and_download(eng, devbatch.DeviceBatch.from_workload(w))
+    t = eng.timing()
+    ref = oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, os.cpu_count() or 8)
+    assert got.n_items == ref.n_items and t.n_lane_items > 0.9 * got.n_items
+    assert got.canonical() == ref.canonical()
+    eng.close()
+    index.close()
+
+
+def test_rccl_gather_path_with_one_rank():
+    """bench.py's N > 1 path (window deal, per-rank batch from read ranges, RCCL size all-gather + send/recv of the result arrays,
+    verification against the single-GPU result) driven with world size 1 on this GPU -- what the pool's one-GPU boxes allow
+    (two ranks on one device are refused by RCCL, profiles/r02_rccl_2proc_1gpu_refused.txt)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLO_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PLO_BENCH_GATHER_TIMEOUT="120")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "chr20", "--reads", "30000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--e2e-reads", "0", "--overlap-workers", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["value"] and not line.get("gather_failed") and line["config"]["gather"].startswith("rccl")
+    assert line["verify"]["gathered_equals_single_gpu_result"] is True and line["verify"]["reads"] == 30000
+    assert set(line["gather_modes"]) >= {"after_every_step"}
+
+
 def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
     """bench.py's N > 1 path wraps the engine's device outputs as torch tensors (no copy) before the RCCL gather"""
     import torch

@@ -2,6 +2,8 @@
 vectors for the clipping / identity helpers and the repeated-match trimmer, then the C++ implementation against the
 pure-Python restatement (oracle/pyphase1.py) on synthetic aligner output, and the round trip workload -> taken-apart BAM ->
 phase 1 -> the workload's segments."""
+import struct
+
 import numpy as np
 import pytest
 
@@ -204,3 +206,29 @@ def test_bams_in_lifted_bam_out(oracle, tmp_path):
     ph.close()
     eng.close()
     index.close()
+
+
+def test_phase1_supplementary_record_with_long_cigar_in_cg_tag(tmp_path):
+    """a supplementary assembly->reference alignment of more than 65535 ops arrives as <l_seq>S<n>N + CG:B,I; htslib hands the
+    reference the real CIGAR for every record, so the record's key matches the SA-derived one and its CIGAR replaces the SA tag's
+    approximate one (contig_alignment_scanner/mod.rs:135-183, 371-416)"""
+    rn, cn = ["chr1"], ["ctg"]
+    n_pairs = 35000
+    real = np.array([(40 << 4) | 5] + [(1 << 4) | 7, (1 << 4) | 8] * n_pairs, np.uint32)  # 40H (1= 1X) x 35000: 70 001 ops
+    l_seq = 2 * n_pairs
+    placeholder = np.array([(l_seq << 4) | 4, (l_seq << 4) | 3], np.uint32)
+    cg_tag = b"CGBI" + struct.pack("<I", len(real)) + real.astype("<u4").tobytes()
+    recs = [bamsynth.encode_record(0, 1000, 60, 0, b"ctg", np.array(C("40=%dS" % l_seq), np.uint32), bytes((40 + l_seq + 1) // 2), 40 + l_seq,
+                                   b"\xff" * (40 + l_seq), b"SAZchr1,5001,+,40S%dM,60,0;\0" % l_seq),
+            bamsynth.encode_record(0, 5000, 60, 0x800, b"ctg", placeholder, bytes(l_seq // 2), l_seq, b"\xff" * l_seq, cg_tag)]
+    path = str(tmp_path / "long.bam")
+    wr = bam.BamWriter(path, "@HD\tVN:1.6\n", rn, [200000], level=1)
+    wr.write(b"".join(recs))
+    wr.close()
+    ph = bam.Phase1(path, cn, [40 + l_seq], n_threads=1)
+    got = _segments_of(ph.index_data([np.zeros(200000, np.uint8)]))[0]
+    exp = p1.scan_contig_bam(recs, rn, cn)
+    assert got == [(s.seq_order_read_start, s.seq_order_read_end, s.chrom_index, s.pos, s.is_fwd_strand, s.mapq, _norm_clip(s.cigar))
+                   for s in exp.contigs[0]]
+    assert len(got) == 2 and len(got[1][6]) > 65535  # the supplementary segment carries the record's own 70 001-op CIGAR
+    ph.close()

@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ver = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = f"gpurun_out/{ver}"
 pre = f"profiles/{rnd}_{ver}_wgs30x"
 rows = list(csv.reader(open(f"{src}/kernel_stats.csv")))
@@ -32,8 +32,8 @@ def rd(p):
 
 fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
 with open(f"{pre}_pmc_summary.csv", "w") as f:
-    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_tiles --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0\n")
-    f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of the tile kernel (k_lift_tiles_c256 for this workload); FETCH_SIZE / WRITE_SIZE in KiB\n")
+    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex <dominant kernel> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0\n")
+    f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of the dominant kernel (k_lift_lanes for this workload); FETCH_SIZE / WRITE_SIZE in KiB\n")
     f.write("counter,mean_per_launch,launches\n")
     for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
         for l in open(f"{src}/{p}.csv"):
@@ -42,7 +42,8 @@ with open(f"{pre}_pmc_summary.csv", "w") as f:
 h = json.load(open("profiles/hbm_traffic.json"))
 b = json.load(open(f"{src}/bench.json"))
 h["wgs30x"] = {b["roofline"]["kernel"]: int((2 * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr,
-               "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"]}
+               "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
+               "_reads": b["config"]["reads_this_rank"], "_source_hash": b["config"]["kernel_source_hash"], "_n_gpus": b["n_gpus"]}
 json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
 print(h["wgs30x"])
 print(json.dumps(b["roofline"]))
@@ -74,8 +75,9 @@ if os.path.exists(f"{src}/stress_kernel_stats.csv"):
                 if "," in l:
                     f.write(l)
     sb = json.load(open(f"{src}/stress_bench.json"))
-    h["stress"] = {"k_lift_mid": int((2 * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr,
-                   "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"]}
+    h["stress"] = {sb["roofline"]["kernel"]: int((2 * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr,
+                   "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"],
+                   "_reads": sb["config"]["reads_this_rank"], "_source_hash": sb["config"]["kernel_source_hash"], "_n_gpus": sb["n_gpus"]}
     json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
     print(h["stress"])
     print(json.dumps(sb["roofline"]))
