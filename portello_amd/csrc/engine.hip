@@ -1,19 +1,20 @@
 // engine.hip -- gfx950 kernels + the C ABI of include/portello_liftover.h.
 //
 // Kernel pipeline of one batch (all on the context's stream):
-//   k_seg_count          eight lanes per read split segment: reference span + how many contig segments it touches (a8)
-//   scan                 item offsets, n_items
-//   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3), item weights
-//   k_class_flags/scan/k_permute   class order (strand x size) so that tiles are strand-homogeneous
-//   scan + k_max_u32     weight prefix; maximum, sum and histogram of the weights -> per-batch tile geometry (one host sync)
-//   k_tile_bounds        first item of every tile (windows of the weight prefix)
-//   k_lift_tiles         DOMINANT KERNEL: persistent waves, one wave per tile of items, the whole
-//                        shift / liftover / length check / simplify pipeline on a flattened op stream in LDS
-//   k_lift_retry         items of tiles that overflowed their LDS slice: one item per wave, larger slice
+//   k_seg_count          four lanes per read split segment: batch validation, reference span, how many contig segments it touches (a8)
+//   scan                 item offsets, n_items (host sync: buffer sizes)
+//   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3), item class + weight
+//   k_cls_hist / k_cls_scan / k_permute2   class order (strand x light / heavy): groups and tiles are strand-homogeneous; the host reads
+//                        the class counts and the weight sum / maximum while k_permute2 runs
+//   k_lift_lanes         DOMINANT KERNEL on HiFi batches (lane_core.hpp): persistent waves, 64 light items per wave, one LANE per item,
+//                        the whole shift / liftover / length check / simplify pipeline in place in a ~180-byte LDS region per item
+//   (heavy items only)   scan of the weights, k_max_u32 (weight histogram -> tile geometry, host sync), k_tile_bounds,
+//   k_lift_tiles         persistent waves, one wave per tile of items, the pipeline as wave scans over a flattened op stream in LDS
+//   k_lift_retry         items whose LDS region / slice overflowed (lanes or tiles): one item per wave, larger slice
 //   k_lift_mid           items heavier than the routing threshold: one WORKGROUP per item (8 or 16 waves share the item's op
 //                        stream in LDS, scan carries cross the waves through LDS: Coop<NW>, lift_core.hpp)
 //   k_lift_big           items too heavy even for that: one wave per item, wave-private global scratch
-//   k_sum_stats          per-wave statistic slots -> batch counters (after every lift kernel)
+//   k_sum_stats          per-wave statistic slots -> batch counters (after the lift kernels)
 //   k_compact_cigar      dense re-packing of the slab-allocated output CIGARs (plo_compact_output_dev)
 //   k_finish_* / k_revcomp / k_sa_*   record finishing and SA text (plo_finish_batch_dev, plo_sa_segments_dev)
 //   k_map_build          block maps of the contig segments, once per index (plo_index_create)
@@ -180,26 +181,114 @@ __global__ void k_item_desc(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stage
     build_item_desc(ix, bt, wk, stages, i, seg, in_cseg[i], segment_ref_len(bt, seg));
 }
 
-// class order (lift_types.hpp DevWork): flags of classes 0,1,2 (scanned into ranks), then the permutation itself
-__global__ void k_class_flags(const uint32_t *item_cls, uint32_t n, uint32_t *f0, uint32_t *f1, uint32_t *f2) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = item_cls[i];
-    f0[i] = c == 0;
-    f1[i] = c == 1;
-    f2[i] = c == 2;
+// ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_tot /*[4]*/, unsigned &block_total) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = (unsigned)wv::scan_add((int)v);
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += wave_tot[k];
+    block_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return inc + base;
 }
-__global__ void k_permute(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *r0, const uint32_t *r1,
-                          const uint32_t *r2, uint32_t n, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = item_cls[i];
-    uint32_t j = class_order_pos(i, c, r0[i], r1[i], r2[i], r0[n], r1[n], r2[n]);
-    perm[j] = i;
-    // only the large items are tiled; items no geometry can hold (heavier than huge_w) take no room in the weight stream: they
-    // ride along in their neighbours' tiles, 64 per pass, and are handed to the large-item kernel there
-    uint32_t w = item_nin[i];
-    nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
+
+// Class order (lift_types.hpp DevWork) in three launches: per block of CLS_BLOCK items the counts of classes 0, 1, 2 (k_cls_hist,
+// which also reduces the weights the host sizes buffers by), an exclusive scan of the block counts (k_cls_scan, one workgroup),
+// and the permutation itself from block offset + rank inside the block (k_permute2).
+constexpr uint32_t CLS_THREADS = 256, CLS_PER = 8, CLS_BLOCK = CLS_THREADS * CLS_PER;
+// totals: [0..2] items of class 0 / 1 / 2, [3] heaviest item, [4..5] 64-bit sum of the weights; must be zeroed
+__global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial,
+                                                          uint32_t *totals) {
+    __shared__ uint32_t acc[4];
+    __shared__ unsigned long long accw;
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) accw = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0;
+    unsigned long long sw = 0;
+    for (uint32_t k = 0; k < CLS_PER; ++k) {
+        if (base + k < n) {
+            const uint32_t c = item_cls[base + k], w = item_w[base + k];
+            c0 += c == 0;
+            c1 += c == 1;
+            c2 += c == 2;
+            mw = w > mw ? w : mw;
+            sw += w;
+        }
+    }
+    // (counts of a wave fit 16 bits: 64 threads x 8 items)
+    const int p01 = wv::reduce_add((int)(c0 | (c1 << 16))), p2 = wv::reduce_add((int)c2), pm = wv::reduce_max((int)(mw & 0x7fffffffu));
+    const unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(sw & 0xffffffull)), hi = (unsigned)wv::reduce_add((int)(unsigned)(sw >> 24));
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&acc[0], (uint32_t)p01 & 0xffffu);
+        atomicAdd(&acc[1], (uint32_t)p01 >> 16);
+        atomicAdd(&acc[2], (uint32_t)p2);
+        atomicMax(&acc[3], (uint32_t)pm);
+        atomicAdd(&accw, (unsigned long long)lo + ((unsigned long long)hi << 24));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[threadIdx.x * nb + blockIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (acc[3]) atomicMax(&totals[3], acc[3]);
+        atomicAdd((unsigned long long *)(totals + 4), accw);
+    }
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, uint32_t nb, uint32_t *totals) {
+    __shared__ unsigned wt[4];
+    for (uint32_t c = 0; c < 3; ++c) {
+        uint32_t *p = partial + c * nb;
+        unsigned carry = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+            const uint32_t i = b0 + threadIdx.x;
+            const unsigned v = i < nb ? p[i] : 0;
+            unsigned tot;
+            const unsigned inc = block_scan_incl(v, wt, tot);
+            if (i < nb) p[i] = carry + inc - v;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) totals[c] = carry;
+    }
+}
+__global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *partial, const uint32_t *totals,
+                                                          uint32_t n, uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w) {
+    __shared__ unsigned wt[4];
+    const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
+    uint32_t cls[CLS_PER];
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    for (uint32_t k = 0; k < CLS_PER; ++k) {
+        cls[k] = base + k < n ? item_cls[base + k] : 3u;
+        c0 += cls[k] == 0;
+        c1 += cls[k] == 1;
+        c2 += cls[k] == 2;
+    }
+    unsigned tot;
+    const unsigned i01 = block_scan_incl(c0 | (c1 << 16), wt, tot);  // (a block holds 2 048 items: each count fits 16 bits)
+    const unsigned i2 = block_scan_incl(c2, wt, tot);
+    uint32_t r0 = partial[0 * nb + blockIdx.x] + (i01 & 0xffffu) - c0;
+    uint32_t r1 = partial[1 * nb + blockIdx.x] + (i01 >> 16) - c1;
+    uint32_t r2 = partial[2 * nb + blockIdx.x] + i2 - c2;
+    const uint32_t n0 = totals[0], n1 = totals[1], n2 = totals[2];
+    for (uint32_t k = 0; k < CLS_PER; ++k) {
+        const uint32_t i = base + k;
+        if (i >= n) break;
+        const uint32_t c = cls[k];
+        const uint32_t j = class_order_pos(i, c, r0, r1, r2, n0, n1, n2);
+        perm[j] = i;
+        // only the large items are tiled; items no geometry can hold (heavier than huge_w) take no room in the weight stream: they
+        // ride along in their neighbours' tiles, 64 per pass, and are handed to the large-item kernel there
+        const uint32_t w = item_nin[i];
+        nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
+        r0 += c == 0;
+        r1 += c == 1;
+        r2 += c == 2;
+    }
 }
 
 // The lane-per-item kernel runs a group of 64 items for as long as its heaviest item takes; in read order that is about twice
@@ -254,11 +343,9 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
 }
 
 // thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
-__global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, const uint32_t *r0,
-                              const uint32_t *r1, uint32_t *tile_lo) {
+__global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t n_small, uint32_t *tile_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    uint32_t n_small = r0[n_items] + r1[n_items];
     uint32_t lo = prefix_lower_bound(op_prefix, n_items, (unsigned long long)t * (unsigned)window);
     tile_lo[t] = lo > n_small ? lo : n_small;
 }
@@ -319,23 +406,6 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n,
         if (bmax) atomicMax(out, bmax);
         atomicAdd((unsigned long long *)(out + 2), bsum);
     }
-}
-
-// ---- device-wide exclusive scan of uint32 (three launches; out has n+1 entries, out[n] = total) -------------------
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_PER_THREAD = 8;
-constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
-
-__device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_tot /*[4]*/, unsigned &block_total) {
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned inc = (unsigned)wv::scan_add((int)v);
-    if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
-    unsigned base = 0;
-    for (int k = 0; k < w; ++k) base += wave_tot[k];
-    block_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-    return inc + base;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const uint32_t *in, uint32_t n, uint32_t *partial) {
@@ -826,7 +896,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, item_cls, cls0, cls1, cls2, rank0, rank1, rank2, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
+    DevBuf misc, whist, cls_partial, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
@@ -840,6 +910,7 @@ struct plo_ctx {
     // (most of the batch's bytes) runs under it; the first lift kernel waits for ev_seq
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_seq = nullptr;
+    hipEvent_t ev_cls = nullptr;  // class totals copied to the host (k_permute2 runs behind it)
     bool seq_pending = false;
     bool ev_big = false, ev_mid = false;
     uint64_t dense_total = 0;
@@ -1058,6 +1129,11 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
         }
         c->own_stream = true;
     }
+    if (hipEventCreateWithFlags(&c->ev_cls, hipEventDisableTiming) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return PLO_ERR_HIP;
+    }
     for (int i = 0; i < 7; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) {
             for (int k = 0; k < i; ++k) (void)hipEventDestroy(c->ev[k]);
@@ -1111,7 +1187,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->misc, &c->item_cls, &c->cls0, &c->cls1, &c->cls2, &c->rank0, &c->rank1, &c->rank2, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->misc, &c->whist, &c->cls_partial, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -1127,6 +1203,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     for (int i = 0; i < 5; ++i)
         if (c->fev[i]) (void)hipEventDestroy(c->fev[i]);
     if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
+    if (c->ev_cls) (void)hipEventDestroy(c->ev_cls);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1237,12 +1314,6 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->item_cseg.ensure(ni * 4));
     HIP_TRY(c, c->item_nin.ensure(ni * 4));
     HIP_TRY(c, c->item_cls.ensure(ni * 4));
-    HIP_TRY(c, c->cls0.ensure(ni * 4));
-    HIP_TRY(c, c->cls1.ensure(ni * 4));
-    HIP_TRY(c, c->cls2.ensure(ni * 4));
-    HIP_TRY(c, c->rank0.ensure((ni + 1) * 4));
-    HIP_TRY(c, c->rank1.ensure((ni + 1) * 4));
-    HIP_TRY(c, c->rank2.ensure((ni + 1) * 4));
     HIP_TRY(c, c->retry_list.ensure(ni * 4));
     HIP_TRY(c, c->perm.ensure(ni * 4));
     HIP_TRY(c, c->nin_p.ensure(ni * 4));
@@ -1345,66 +1416,60 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>());
         HIP_TRY(c, hipGetLastError());
     }
-    {
-        if (n_items) hipLaunchKernelGGL(k_class_flags, dim3((n_items + 255) / 256), dim3(256), 0, st,
-                                        (const uint32_t *)c->item_cls.as<uint32_t>(), n_items, c->cls0.as<uint32_t>(),
-                                        c->cls1.as<uint32_t>(), c->cls2.as<uint32_t>());
-        plo_status s = PLO_OK;
-        if (c->lane_max_w < 0) {
-            // lane kernel off: every item is "large" (classes 2 and 3 only), the ranks of classes 0 and 1 are all zero
-            HIP_TRY(c, hipMemsetAsync(c->rank0.p, 0, ((size_t)n_items + 1) * 4, st));
-            HIP_TRY(c, hipMemsetAsync(c->rank1.p, 0, ((size_t)n_items + 1) * 4, st));
-        } else {
-            s = scan_u32(c, c->cls0.as<uint32_t>(), n_items, c->rank0.as<uint32_t>());
-            if (s != PLO_OK) return s;
-            s = scan_u32(c, c->cls1.as<uint32_t>(), n_items, c->rank1.as<uint32_t>());
-            if (s != PLO_OK) return s;
-        }
-        s = scan_u32(c, c->cls2.as<uint32_t>(), n_items, c->rank2.as<uint32_t>());
-        if (s != PLO_OK) return s;
-        if (n_items) hipLaunchKernelGGL(k_permute, dim3((n_items + 255) / 256), dim3(256), 0, st,
-                                        (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
-                                        (const uint32_t *)c->rank0.as<uint32_t>(), (const uint32_t *)c->rank1.as<uint32_t>(),
-                                        (const uint32_t *)c->rank2.as<uint32_t>(), n_items, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
-                                        c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu);
-        s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
-        if (s != PLO_OK) return s;
-    }
+    // ---- class order: block counts -> scan -> permutation (three launches); the host learns the class counts and the weights'
+    // sum / maximum from one copy, made while k_permute2 runs
     uint32_t total_ops = 0, max_nin = 0, n_small = 0, h_cls[2] = {0, 0};
     unsigned long long all_ops = 0;
+    const uint32_t cls_nb = (n_items + CLS_BLOCK - 1) / CLS_BLOCK;
     {
         HIP_TRY(c, c->misc.ensure(256));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
-        if (n_items)
-            hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 256u)), dim3(256), 0, st,
-                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->misc.as<uint32_t>(),
-                               (const uint32_t *)c->op_prefix.as<uint32_t>() + n_items, (const uint32_t *)c->rank0.as<uint32_t>() + n_items,
-                               (const uint32_t *)c->rank1.as<uint32_t>() + n_items);
-        // one copy: [0] max weight, [2..3] weight sum, [4] tiled weight, [5..6] class-0/1 counts, [8..] weight histogram
+        HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 3 * 4));
         uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;  // clear of h[0..47] below
-        HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, (WHIST_AT + WHIST_BINS) * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(m_ + WHIST_AT + WHIST_BINS, c->verr.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (m_[WHIST_AT + WHIST_BINS]) return verr_status(m_[WHIST_AT + WHIST_BINS]);
-        uint32_t *h = c->h_counters.as<uint32_t>();
-        h[0] = n_items ? m_[4] : 0;
-        h[1] = m_[0];
-        h[2] = n_items ? m_[5] : 0;
-        h[3] = n_items ? m_[6] : 0;
-        h[4] = m_[2];
-        h[5] = m_[3];
-        for (int k = 0; k < WHIST_BINS; ++k) h[8 + k] = m_[WHIST_AT + k];
-        total_ops = h[0];  // weight of the tiled items
-        max_nin = h[1];
-        n_small = n_items ? h[2] + h[3] : 0;
-        h_cls[0] = n_items ? h[2] : 0;
-        h_cls[1] = n_items ? h[3] : 0;
-        all_ops = (unsigned long long)h[4] | ((unsigned long long)h[5] << 32);
+        memset(m_, 0, 8 * 4);
+        if (n_items) {
+            hipLaunchKernelGGL(k_cls_hist, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(),
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, cls_nb, c->cls_partial.as<uint32_t>(), c->misc.as<uint32_t>());
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_THREADS), 0, st, c->cls_partial.as<uint32_t>(), cls_nb, c->misc.as<uint32_t>());
+            HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, 6 * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(m_ + 6, c->verr.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipEventRecord(c->ev_cls, st));
+            hipLaunchKernelGGL(k_permute2, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(),
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), (const uint32_t *)c->cls_partial.as<uint32_t>(),
+                               (const uint32_t *)c->misc.as<uint32_t>(), n_items, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
+                               c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventSynchronize(c->ev_cls));  // (the copies are done; k_permute2 may still be running)
+        }
+        if (m_[6]) return verr_status(m_[6]);
+        h_cls[0] = m_[0];
+        h_cls[1] = m_[1];
+        n_small = m_[0] + m_[1];
+        max_nin = m_[3];
+        all_ops = (unsigned long long)m_[4] | ((unsigned long long)m_[5] << 32);
         if (all_ops > 0x7fffffffull) {  // op indices are int: the weights bound the ops of every stage, output included
             c->err = "batch too large: the item weights (CIGAR ops + 2 x block-map entries) sum to more than 2^31; split the batch";
             return PLO_ERR_RANGE;
         }
-        if (c->adaptive && n_items) {
+    }
+    // ---- items too heavy for the lane-per-item kernel: tiles of the wave-cooperative kernel (weight prefix, per-batch geometry) ----
+    if (n_items > n_small) {
+        plo_status s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
+        if (s != PLO_OK) return s;
+        HIP_TRY(c, c->whist.ensure(256));
+        HIP_TRY(c, hipMemsetAsync(c->whist.p, 0, 256, st));
+        hipLaunchKernelGGL(k_max_u32, dim3(std::min<uint32_t>((n_items + 255) / 256, 256u)), dim3(256), 0, st,
+                           (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, c->whist.as<uint32_t>(),
+                           (const uint32_t *)c->op_prefix.as<uint32_t>() + n_items, (const uint32_t *)c->misc.as<uint32_t>(),
+                           (const uint32_t *)c->misc.as<uint32_t>() + 1);
+        // one copy: [0] max weight, [2..3] weight sum, [4] tiled weight, [8..] weight histogram
+        uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;
+        HIP_TRY(c, hipMemcpyAsync(m_, c->whist.p, (WHIST_AT + WHIST_BINS) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        uint32_t *h = c->h_counters.as<uint32_t>();
+        for (int k = 0; k < WHIST_BINS; ++k) h[8 + k] = m_[WHIST_AT + k];
+        total_ops = m_[4];  // weight of the tiled items
+        if (c->adaptive) {
             // Tile geometry from the batch's weight distribution: the routing threshold covers all but 0.2 % of the items
             // (those take the large-item kernel), the LDS slice holds one window plus the overhang of its last item.  Dense
             // contig block maps (many blocks per read) thus get larger slices and fewer resident waves instead of a
@@ -1436,10 +1501,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         }
     }
     const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
-    HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
-    hipLaunchKernelGGL(k_tile_bounds, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->op_prefix.as<uint32_t>(),
-                       n_items, n_tiles, c->window, (const uint32_t *)c->rank0.as<uint32_t>(), (const uint32_t *)c->rank1.as<uint32_t>(),
-                       c->tile_lo.as<uint32_t>());
+    if (n_items > n_small) {
+        HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
+        hipLaunchKernelGGL(k_tile_bounds, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->op_prefix.as<uint32_t>(),
+                           n_items, n_tiles, c->window, n_small, c->tile_lo.as<uint32_t>());
+    }
     wk.tile_lo = c->tile_lo.as<uint32_t>();
     wk.n_small = n_small;
     HIP_TRY(c, hipEventRecord(c->ev[1], st));

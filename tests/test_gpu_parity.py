@@ -343,7 +343,9 @@ def test_rccl_gather_path_with_one_rank():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "chr20", "--reads", "30000", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--e2e-reads", "0", "--overlap-workers", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    line = json.loads(lines[0])
     assert line["value"] and not line.get("gather_failed") and line["config"]["gather"].startswith("rccl")
     assert line["verify"]["gathered_equals_single_gpu_result"] is True and line["verify"]["reads"] == 30000
     assert set(line["gather_modes"]) >= {"after_every_step"}
