@@ -231,6 +231,116 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
         shutil.rmtree(d, ignore_errors=True)
 
 
+def stream_main(args, cfg, dev, dev_index, chunk_reads):
+    """A read set larger than one batch (stress at 2 M reads, wgs30x at 6.2 M): chunks generated on one set of
+    contigs, all resident in HBM, lifted batch after batch.  One step = one pass over all batches.  The timed passes use one host
+    worker (clean HIP-event kernel times for the roofline object); `overlap` repeats them with two."""
+    from portello_amd import stream
+
+    chunks = stream.generate_chunks(synth, cfg.name, cfg.n_reads, chunk_reads, dev, log)
+    torch.cuda.synchronize()
+    index = api.Index(chunks[0].index_data_device(), device=dev_index)
+    dbs = [devbatch.DeviceBatch.from_workload(w) for w in chunks]
+    descs = [db.desc() for db in dbs]
+    total_reads = sum(w.n_reads for w in chunks)
+    times = {k_: [] for k_ in ("lift", "lanes", "enum", "big", "mid", "retry")}
+    agg = {"items": 0, "in_ops": 0, "out_ops": 0, "algo": 0, "mid_items": 0, "big_items": 0, "lane_items": 0, "retry_items": 0}
+
+    def record(tm):
+        times["lift"].append(tm.lift_ms)
+        times["lanes"].append(tm.lanes_ms)
+        times["enum"].append(tm.enumerate_ms)
+        times["big"].append(tm.big_ms)
+        times["mid"].append(tm.mid_ms)
+        times["retry"].append(tm.retry_ms)
+        agg["items"] += int(tm.n_items)
+        agg["in_ops"] += int(tm.n_in_ops)
+        agg["out_ops"] += int(tm.n_out_ops)
+        agg["algo"] += int(tm.algo_bytes)
+        agg["mid_items"] += int(tm.n_mid_items)
+        agg["big_items"] += int(tm.n_big_items)
+        agg["lane_items"] += int(tm.n_lane_items)
+        agg["retry_items"] += int(tm.n_retry_items)
+
+    one = stream.StreamRunner(index, dev, 1)
+    for _ in range(max(1, args.warmup)):
+        one.run(descs)
+    one.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one.run(descs, record=record)
+    one.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_calls = args.steps * len(descs)
+    kms = {"k_lift_lanes": float(np.sum(times["lanes"])) / n_calls, "k_lift_mid": float(np.sum(times["mid"])) / n_calls,
+           "k_lift_tiles": float(np.sum(times["lift"])) / n_calls, "k_lift_big": float(np.sum(times["big"])) / n_calls,
+           "k_lift_retry": float(np.sum(times["retry"])) / n_calls}
+    dominant = max(kms, key=kms.get)
+    dom_ms = kms[dominant]
+    share = dom_ms / max(1e-9, sum(kms.values()))
+    algo_per_call = agg["algo"] / n_calls
+    achieved = (algo_per_call * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    dom_name = {"k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
+    result = {
+        "metric": "lifted HiFi reads/sec (whole node)", "value": total_reads * args.steps / dt, "unit": "reads/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": cfg.name, "reads_total": int(total_reads), "reads_this_rank": int(total_reads), "read_len_mean": cfg.read_len_mean,
+                   "streamed": True, "batches": len(descs), "reads_per_batch": [w.n_reads for w in chunks],
+                   "items_per_gpu": agg["items"] // args.steps, "in_ops_per_gpu": agg["in_ops"] // args.steps, "out_ops_per_gpu": agg["out_ops"] // args.steps,
+                   "large_items_per_gpu": agg["big_items"] // args.steps, "mid_items_per_gpu": agg["mid_items"] // args.steps,
+                   "lane_items_per_gpu": agg["lane_items"] // args.steps, "retry_items_per_gpu": agg["retry_items"] // args.steps, "seq_fmt": "bam4",
+                   "parallelism": "one read set on one set of contigs, lifted as consecutive batches through one context (one step = one pass over all batches)",
+                   "host_workers_per_gpu": 1, "kernel_source_hash": plo_build.source_hash(), "gather": "none"},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(algo_per_call * share),
+                     "kernel_ms": dom_ms, "launches_per_step": len(descs), "enumerate_ms": float(np.sum(times["enum"])) / n_calls,
+                     "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"], "lift_big_ms": kms["k_lift_big"],
+                     "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"]},
+    }
+    one.close()
+    if args.overlap_workers > 1:
+        two = stream.StreamRunner(index, dev, args.overlap_workers)
+        two.run(descs)
+        two.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            two.run(descs)
+        two.sync()
+        torch.cuda.synchronize()
+        odt = time.perf_counter() - t1
+        result["overlap"] = {"host_workers_per_gpu": args.overlap_workers, "value": total_reads * args.steps / odt, "unit": "reads/s",
+                             "ms_per_step": odt / args.steps * 1e3,
+                             "note": "the same passes with the batches dealt to several host workers (one context + HIP stream each)"}
+        two.close()
+    if not args.no_cpu_baseline:
+        # parity on every batch's strided sample + the CPU baseline on the first batch
+        try:
+            chk = api.Engine(index)
+            ixd_host = chunks[0].index_data()
+            ok_all, n_checked, cb = True, 0, None
+            for k_, (w_, db_) in enumerate(zip(chunks, dbs)):
+                got = devbatch.run_and_download(chk, db_)
+                b_, ok, n_items = cpu_baseline(w_, got, budget_s=(15.0 if k_ == 0 else 1.0), ixd=ixd_host)
+                cb = cb or b_
+                ok_all = ok_all and ok
+                n_checked += n_items
+            chk.close()
+            result["cpu_baseline"] = cb
+            result["parity_sample_items"] = n_checked
+            result["parity_sample_ok"] = bool(ok_all)
+            if not ok_all:
+                log("[bench] PARITY FAILURE on the sampled reads")
+        except Exception as e:  # noqa: BLE001 -- the baseline must never hide the measurement
+            log(f"[bench] cpu_baseline failed: {e!r}")
+            result["cpu_baseline"] = None
+    print(json.dumps(result), flush=True)
+    index.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +352,9 @@ def main():
                     help="N > 1: strong = one read set sharded by windows over the ranks (BASELINE configs[3]); weak = every rank "
                          "its own read set of the full size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-reads", type=int, default=0,
+                    help="N = 1: read sets of more than this many reads are lifted as a stream of batches (portello_amd/stream.py); default "
+                         "250 k for the stress profile (0.5 G input ops per batch; a batch is bounded by 31-bit op indices), 8 M otherwise")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("PLO_BENCH_E2E_READS", "60000")),
                     help="N = 1: size of the BAM-to-BAM end-to-end sample (0 = skip the end_to_end / pcie_inclusive objects)")
     ap.add_argument("--e2e-window", type=int, default=7500,
@@ -289,6 +402,9 @@ def main():
     if args.reads:
         over["n_reads"] = args.reads
     cfg = synth.config(args.workload, **over)
+    chunk_reads = args.chunk_reads or (250_000 if cfg.name.startswith("stress") else 8_000_000)
+    if world == 1 and dist is None and cfg.n_reads > chunk_reads:
+        return stream_main(args, cfg, dev, dev_index, chunk_reads)
     t0 = time.perf_counter()
     w = synth.generate(cfg, device=dev)
     torch.cuda.synchronize()

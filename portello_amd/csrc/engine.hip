@@ -549,6 +549,25 @@ __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu
     lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw, chunk_groups);
 }
 
+// The same lane-per-item code for HEAVY items (too heavy for an LDS region: indel-dense or very long CIGARs), every lane's region in
+// wave-private global scratch; `per` items per wave.
+template <bool SP>
+PLO_DEV void lift_lanes_g_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t lo, uint32_t mid, uint32_t hi,
+                                 uint32_t per, uint32_t *scratch, int stride) {
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    WaveCtx ctx;
+    lane_heavy_persistent<SP>(ix, bt, wk, stages, wave, n_waves, lo, mid, hi, per, scratch + (size_t)wave * (size_t)per * (size_t)stride, stride, ctx);
+    wave_ctx_flush(wk, ctx, wave);
+}
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_g(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
+                                                                                                     uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
+    lift_lanes_g_kernel<false>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
+}
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_g_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
+                                                                                                        uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
+    lift_lanes_g_kernel<true>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
+}
+
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
 // items per wave with a larger LDS slice (retry_cap)
 constexpr uint32_t RETRY_PER = 1;
@@ -896,7 +915,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, whist, cls_partial, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
+    DevBuf misc, whist, cls_partial, lane_scratch, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
     DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
@@ -930,6 +949,11 @@ struct plo_ctx {
     // per item -- 36 KB of LDS per wave, synchronous probes -- was a net loss and had been removed; this is a different kernel.)
     int lane_max_w = 192;
     int lane_capw = 3072;
+    // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch) for batches with at least that many
+    // heavy items; < 0: never (default).  Measured on the stress workload, 100 k reads: 15.9 ms at 64 items per wave (21.5 at 16)
+    // against 13.1 ms of the workgroup-per-item kernel -- every region access is an L2 round trip and 1 600 groups leave the chip
+    // at 1.5 waves per SIMD to hide it; kept as an option (PLO_LANE_HEAVY_MIN) for batches of millions of heavy items.
+    int lane_heavy_min = -1;
     int lane_chunk_groups = 1;  // k_chunk_sort: groups of 64 per sorted chunk of the class order (1: no sorting)
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
@@ -1170,6 +1194,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
+    if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
     if (const char *e = getenv("PLO_LANE_CHUNK_GROUPS")) c->lane_chunk_groups = std::min(32, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
@@ -1187,7 +1212,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->misc, &c->whist, &c->cls_partial, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -1418,7 +1443,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     }
     // ---- class order: block counts -> scan -> permutation (three launches); the host learns the class counts and the weights'
     // sum / maximum from one copy, made while k_permute2 runs
-    uint32_t total_ops = 0, max_nin = 0, n_small = 0, h_cls[2] = {0, 0};
+    uint32_t total_ops = 0, max_nin = 0, n_small = 0, h_cls[3] = {0, 0, 0};
     unsigned long long all_ops = 0;
     const uint32_t cls_nb = (n_items + CLS_BLOCK - 1) / CLS_BLOCK;
     {
@@ -1444,6 +1469,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         if (m_[6]) return verr_status(m_[6]);
         h_cls[0] = m_[0];
         h_cls[1] = m_[1];
+        h_cls[2] = m_[2];
         n_small = m_[0] + m_[1];
         max_nin = m_[3];
         all_ops = (unsigned long long)m_[4] | ((unsigned long long)m_[5] << 32);
@@ -1452,8 +1478,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             return PLO_ERR_RANGE;
         }
     }
-    // ---- items too heavy for the lane-per-item kernel: tiles of the wave-cooperative kernel (weight prefix, per-batch geometry) ----
-    if (n_items > n_small) {
+    // ---- items too heavy for an LDS region.  Many of them: the lane-per-item code again, regions in global scratch (k_lift_lanes_g).
+    // A few: tiles of the wave-cooperative kernel (weight prefix, per-batch geometry).
+    const bool heavy_lanes = n_items > n_small && c->lane_max_w >= 0 && c->lane_heavy_min >= 0 && n_items - n_small >= (uint32_t)c->lane_heavy_min;
+    if (n_items > n_small && !heavy_lanes) {
         plo_status s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
         HIP_TRY(c, c->whist.ensure(256));
@@ -1501,7 +1529,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         }
     }
     const uint32_t n_tiles = total_ops / (uint32_t)c->window + 1;
-    if (n_items > n_small) {
+    if (n_items > n_small && !heavy_lanes) {
         HIP_TRY(c, c->tile_lo.ensure((size_t)(n_tiles + 1) * 4));
         hipLaunchKernelGGL(k_tile_bounds, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)c->op_prefix.as<uint32_t>(),
                            n_items, n_tiles, c->window, n_small, c->tile_lo.as<uint32_t>());
@@ -1551,7 +1579,36 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
-        if (n_items > n_small) {
+        if (heavy_lanes) {
+            // as many items per wave as it takes to give every resident wave a group (at least 8, at most 64 lanes at work)
+            int occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_g_sp : (const void *)k_lift_lanes_g, LANE_WAVES * 64, 0) != hipSuccess || occ < 1)
+                occ = 1;
+            const uint32_t n_heavy = n_items - n_small, n2 = h_cls[2], n3 = n_heavy - n2;
+            const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
+            uint32_t per = std::min(64u, std::max(8u, (n_heavy + slots - 1) / slots));
+            if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
+            const uint32_t groups = (n2 + per - 1) / per + (n3 + per - 1) / per;
+            const int stride = (int)((max_nin + LANE_SLACK + 31u) & ~31u);  // (regions start on 128-byte lines)
+            uint32_t nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
+            const unsigned long long per_wave = (unsigned long long)per * (unsigned long long)stride * 4ull;
+            nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_WAVES)));
+            HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_WAVES * nblk)));
+            if (getenv("PLO_DEBUG_GEOMETRY"))
+                fprintf(stderr, "[plo] heavy items through the lane-per-item code: %u items, %u per wave, %u workgroups, regions of %d dwords, %.1f MB scratch\n", n_heavy, per,
+                        nblk, stride, per_wave * LANE_WAVES * nblk / 1e6);
+            if (!n_small) {
+                wk.slab_pre = 1u;
+                wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
+            } else {
+                wk.slab_pre = 0u;  // (the light items' waves own the first slabs)
+            }
+            PLO_STAT_RANGE(nblk * LANE_WAVES);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+            else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->ev[2], st));
+        } else if (n_items > n_small) {
             uint32_t lds_per_wave = (uint32_t)((tile_mem_bytes(c->cap) + 15) & ~(size_t)15);
             if (const char *e = getenv("PLO_LDS_PAD")) lds_per_wave += (uint32_t)atoi(e) & ~15u;  // occupancy experiments
             const uint32_t tw = (uint32_t)c->tile_waves;

@@ -304,14 +304,16 @@ PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, i
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords.
+// One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords, shared out among the items by their
+// weights (fixed_stride == 0: LDS, light items) -- or, fixed_stride > 0, one region of that many dwords per lane in whatever memory
+// `lds` points to (heavy items: wave-private global scratch, k_lift_lanes_g).
 // (Measured and dropped: the group's CIGAR span copied into LDS with coalesced loads and picked apart there, results gathered in
 // LDS and stored coalesced -- 37 % slower than every lane reading / writing its own 16 bytes: the extra LDS round trips cost more
 // than the scattered requests.)
 // -------------------------------------------------------------------------------------------------------------------
 template <bool SP>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
-                       uint32_t *lds, int capw, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre) {
+                       uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre) {
     const int lane = wv::lane();
     const bool has = lane < nit;
     const uint32_t g = have_g ? g_pre : (has ? list[item_begin + (uint32_t)lane] : 0u);
@@ -362,7 +364,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
     {
-        const bool defer = has && W > capw;
+        const bool defer = has && W > (fixed_stride > 0 ? fixed_stride : capw);
         const unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int slot = 0;
@@ -379,10 +381,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // ---- rounds: the longest prefix of the pending items whose regions fit the slice (nearly always all of them) ----
     while (wv::ballot(pending) != 0ull) {
         const int wv_ = pending ? W : 0;
-        const int incl = wv::scan_add(wv_);
-        const bool act0 = pending && incl <= capw;
+        const int incl = fixed_stride > 0 ? (lane + 1) * fixed_stride : wv::scan_add(wv_);
+        const bool act0 = pending && (fixed_stride > 0 || incl <= capw);
         pending = pending && !act0;
-        uint32_t *const R = lds + (act0 ? incl - wv_ : 0);
+        uint32_t *const R = lds + (act0 ? incl - (fixed_stride > 0 ? fixed_stride : wv_) : 0);
         wv::sync();  // the previous round's regions are dead
 
         int status = PLO_ITEM_LIFTED;
@@ -886,7 +888,23 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
             group(t + stride, lo2, hi2);
             g_next = lo2 + lane < hi2 ? wk.perm[lo2 + lane] : 0u;
         }
-        lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, ctx, wk.perm, true, g);
+        lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g);
+        wv::sync();
+    }
+}
+
+// Persistent wave over the HEAVY items (classes 2 and 3: positions [lo, mid) and [mid, hi) of the class order), `per` items per
+// group (<= 64: few heavy items are spread over more waves, at fewer lanes each, so that they still fill the chip), every lane with
+// a region of `stride` dwords in the wave's global scratch.
+template <bool SP>
+PLO_DEV void lane_heavy_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t step,
+                                   uint32_t lo, uint32_t mid, uint32_t hi, uint32_t per, uint32_t *regions, int stride, WaveCtx &ctx) {
+    const uint32_t t0 = (mid - lo + per - 1) / per, t1 = (hi - mid + per - 1) / per;
+    for (uint32_t t = first; t < t0 + t1; t += step) {
+        const bool c1 = t >= t0;
+        const uint32_t b = c1 ? mid + (t - t0) * per : lo + t * per, e = c1 ? hi : mid;
+        const uint32_t n = e - b < per ? e - b : per;
+        lane_tile<SP>(ix, bt, wk, stages, b, (int)n, regions, 0x7fffffff, stride, ctx, wk.perm, false, 0u);
         wv::sync();
     }
 }

@@ -349,6 +349,7 @@ class Workload:
     seg_is_fwd_r: torch.Tensor
     seg_cigar_off_r: torch.Tensor
     cigar: torch.Tensor
+    contig_fwd: Optional[List[torch.Tensor]] = None  # the contigs' bases (generate(..., keep_contigs=True)): more reads on the same contigs
 
     @property
     def n_reads(self) -> int:
@@ -419,12 +420,20 @@ def _pack_bam4(ascii_seq: torch.Tensor, seq_off: torch.Tensor) -> Tuple[torch.Te
     return packed, byte_off
 
 
-def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workload:
+def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu", reuse: Optional["Workload"] = None, keep_contigs: bool = False) -> Workload:
+    """`reuse`: a workload generated with keep_contigs=True -- its reference, contigs and contig segments are taken over and only
+    the READS are generated (from cfg.seed, cfg.n_reads, the read profile of cfg): the chunks of a read set larger than one
+    batch (bench.py --stream, tests) share one index that way."""
     device = torch.device(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(cfg.seed)
     rng = np.random.default_rng(cfg.seed)
     torch.manual_seed(cfg.seed)  # torch.poisson draws from the global generator
+    if reuse is not None:
+        assert reuse.contig_fwd is not None, "generate(..., reuse=w): w must come from generate(..., keep_contigs=True)"
+        return _generate_reads(cfg, device, gen, rng, reuse.chrom_seq, reuse.contig_fwd, [int(x) for x in reuse.contig_len], list(reuse.contig_seg_off),
+                               list(reuse.seg_chrom_index), list(reuse.seg_pos), list(reuse.seg_is_fwd), list(reuse.seg_mapq), list(reuse.seg_start),
+                               list(reuse.seg_end), reuse.seg_cigar_off, reuse.seg_cigar, reuse.rev_contig_seq, keep_contigs)
 
     chrom_seq = [make_reference(L, cfg.tract_frac, gen, device) for L in cfg.chrom_lens]
 
@@ -523,7 +532,12 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
     seg_cigar_off = np.zeros(len(seg_cigs) + 1, dtype=np.uint32)
     seg_cigar_off[1:] = np.cumsum([len(c) for c in seg_cigs])
     seg_cigar = np.concatenate(seg_cigs) if seg_cigs else np.zeros(0, np.uint32)
+    return _generate_reads(cfg, device, gen, rng, chrom_seq, contig_fwd, contig_len, contig_seg_off, seg_chrom, seg_pos, seg_fwd, seg_mapq, seg_start,
+                           seg_end, seg_cigar_off, seg_cigar, rev_contig_seq, keep_contigs)
 
+
+def _generate_reads(cfg, device, gen, rng, chrom_seq, contig_fwd, contig_len, contig_seg_off, seg_chrom, seg_pos, seg_fwd, seg_mapq, seg_start,
+                    seg_end, seg_cigar_off, seg_cigar, rev_contig_seq, keep_contigs) -> "Workload":
     # ---- reads ----
     n_contigs = len(contig_len)
     clen = np.array(contig_len, dtype=np.int64)
@@ -680,4 +694,4 @@ def generate(cfg: WorkloadConfig, device: str | torch.device = "cpu") -> Workloa
         read_is_reverse=cat("is_rev", torch.uint8), read_seq_len=seq_len.to(torch.int32), read_seq_off=read_seq_off,
         seq=seq, seg_read=cat("seg_read", torch.long), seg_contig=cat("seg_contig", torch.long),
         seg_pos_r=cat("seg_pos", torch.long), seg_is_fwd_r=cat("seg_fwd", torch.uint8),
-        seg_cigar_off_r=seg_cigar_off_r, cigar=cat("ops", torch.long))
+        seg_cigar_off_r=seg_cigar_off_r, cigar=cat("ops", torch.long), contig_fwd=contig_fwd if keep_contigs else None)

@@ -26,7 +26,7 @@ struct Out {
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
                                   int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, int lane_max_w, int lane_capw,
-                                  plo_batch_out *out, unsigned long long *counters_out) {
+                                  int lane_heavy_per, plo_batch_out *out, unsigned long long *counters_out) {
     // lane_max_w >= 0: items up to that weight run through the lane-per-item code (lane_core.hpp) with an LDS slice of lane_capw
     // dwords per wave; what it cannot hold goes to the retry list like on the GPU
     // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
@@ -202,6 +202,25 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         wk.out_cap = out_cap;
         std::vector<unsigned char> lds(tile_mem_bytes(cap) + 64);
         const uint32_t n_waves = 3;  // persistent waves striding over the tiles, like k_lift_tiles
+        // lane_heavy_per > 0: the heavy classes through the lane-per-item code with fixed regions (k_lift_lanes_g) instead of the tiles
+        const bool heavy_lanes = lane_max_w >= 0 && lane_heavy_per > 0 && n_large > 0;
+        if (heavy_lanes) {
+            uint32_t max_w = 0;
+            for (uint32_t i = 0; i < n_items; ++i) max_w = std::max(max_w, item_nin[i]);
+            const int stride = (int)((max_w + LANE_SLACK + 31u) & ~31u);
+            std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu);
+            for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
+                w.run([&]() {
+                    WaveCtx ctx;
+                    if (sp) lane_heavy_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, regions.data(), stride, ctx);
+                    else lane_heavy_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, regions.data(), stride, ctx);
+                    wave_ctx_flush(wk, ctx, 0);
+                });
+                sum_stats();
+            }
+        }
         if (n_small) {  // k_lift_lanes: persistent waves over the groups of 64 of the two lane classes
             std::vector<uint32_t> llds((size_t)lane_capw + 16, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
@@ -216,7 +235,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 sum_stats();
             }
         }
-        for (uint32_t wv_id = 0; wv_id < n_waves && n_large; ++wv_id) {
+        for (uint32_t wv_id = 0; wv_id < n_waves && n_large && !heavy_lanes; ++wv_id) {
             wv::EmuWave w;
             w.order_seed = order_seed ? order_seed + wv_id : 0;
             TileMem m = carve_tile_mem(lds.data(), cap);

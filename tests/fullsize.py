@@ -84,3 +84,38 @@ def check_strided_parity(w, res, oracle, n_blocks=40, block=400, threads=8, ix=N
         n_flip += int(ref.item_need_flipped.sum())
         contigs.update(int(c) for c in b.seg_contig)
     return n_cmp, n_flip, len(contigs)
+
+
+def check_properties_device(w, out, dev, min_lifted=0.9):
+    """properties (1)-(3) of check_properties computed on the GPU over every op of a result that is still in the engine's device
+    buffers (a 250 k-read batch of the stress profile has 0.5 G output ops: too many to walk in numpy): read length of every
+    lifted CIGAR == seq_len, canonical form, status range.  Returns (#items, #lifted)."""
+    import torch
+
+    from portello_amd import gather
+
+    t = gather.tensors_from_out(out, dev)
+    n = int(out.n_items)
+    status = t["item_status"].long()
+    assert int((status > abi.ITEM_NO_LIFTOVER).sum().item()) == 0
+    lifted = status == abi.ITEM_LIFTED
+    assert float(lifted.float().mean().item()) > min_lifted
+    lens = t["item_cigar_len"].long()
+    off = t["item_cigar_off"].long()
+    total = int(lens.sum().item())
+    item = torch.repeat_interleave(torch.arange(n, device=dev), lens)
+    start = torch.cumsum(lens, 0) - lens
+    idx = off[item] + (torch.arange(total, device=dev) - start[item])
+    ops = t["cigar"].long()[idx]
+    del idx
+    ty, ln = ops & 15, ops >> 4
+    del ops
+    # (2) canonical form: no zero-length op, only M I D N S H, no equal neighbours inside a CIGAR
+    assert int((ln <= 0).sum().item()) == 0 and int((ty > 5).sum().item()) == 0
+    assert int(((item[1:] == item[:-1]) & (ty[1:] == ty[:-1])).sum().item()) == 0
+    # (1) read bases consumed == seq_len (src/read_alignment_scanner.rs:206-207)
+    readc = (ty == 0) | (ty == 1) | (ty == 4) | (ty == 5)
+    rl = torch.zeros(n, dtype=torch.long, device=dev).scatter_add_(0, item, ln * readc.long())
+    seq_len = w.read_seq_len.long()[w.seg_read.long()[t["item_seg"].long()]]
+    assert int(((rl != seq_len) & lifted).sum().item()) == 0
+    return n, int(lifted.sum().item())

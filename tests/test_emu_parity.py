@@ -184,3 +184,18 @@ def test_lane_path_indel_dense(oracle):
         rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=100000, lane_capw=60000)
         assert rc == 0
         _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
+
+
+@pytest.mark.parametrize("per", [64, 8, 3])
+def test_lane_path_heavy_items_in_fixed_regions(oracle, per):
+    """indel-dense items too heavy for an LDS region run through the same lane-per-item code with one fixed region per lane
+    (k_lift_lanes_g: wave-private global scratch), `per` items per wave; light ones through the LDS path in the same batch"""
+    cfg = synth.config("tiny", n_reads=40, seed=134, read_len_mean=2500, read_len_sd=900, split_read_frac=0.2,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    for stages in (abi.STAGES_ALL, abi.STAGE_LSHIFT, abi.STAGE_STRAND | abi.STAGE_LIFTOVER):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=150, lane_capw=3072, lane_heavy_per=per, order_seed=per)
+        assert rc == 0 and 0 < cnt[23] < res.n_items and cnt[2] == 0  # some light, some heavy, nothing through the tile kernels
+        _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)

@@ -290,6 +290,51 @@ def test_full_size_stress(oracle):
     _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
 
 
+def test_full_size_stress_2m_reads_streamed(oracle):
+    """BASELINE configs[4] at SURVEY.md 8(d)'s default size, 2 M reads (4 G input ops): more than one batch's 31-bit op indices hold,
+    so the read set is lifted as a stream of eight 250 k-read batches on one index, two contexts taking turns
+    (portello_amd/stream.py, the way the reference walks its windows, read_alignment_scanner.rs:495-535).  Every batch: properties
+    of ALL its records checked on the device, oracle parity on blocks of reads spread over the batch."""
+    import torch
+
+    import fullsize
+    from portello_amd import devbatch, stream
+
+    dev = torch.device("cuda", 0)
+    n_total, chunk = 2_000_000, 250_000
+    base = synth.config("stress")
+    first = synth.generate(synth.config("stress", n_reads=chunk), device=dev, keep_contigs=True)
+    index = api.Index(first.index_data_device())
+    ixd = first.index_data()
+    runner = stream.StreamRunner(index, dev, 2)
+    done = {"reads": 0, "items": 0, "lifted": 0, "cmp": 0, "mid": 0}
+    lock = __import__("threading").Lock()
+    for pair in range(n_total // chunk // 2):  # two chunks resident at a time, one per context
+        ws = [first if k == 0 else synth.generate(synth.config("stress", n_reads=chunk, seed=base.seed + 7919 * k), device=dev, reuse=first)
+              for k in (2 * pair, 2 * pair + 1)]
+        dbs = [devbatch.DeviceBatch.from_workload(w) for w in ws]
+        torch.cuda.synchronize()
+
+        def consume(k, eng, out):
+            eng.sync()
+            with lock:  # (the checks allocate tens of GB of temporaries on the device: one batch at a time)
+                n, nl = fullsize.check_properties_device(ws[k], out, dev)
+                res = devbatch.download(eng, out)
+                n_cmp, _, _ = fullsize.check_strided_parity(ws[k], res, oracle, 8, 25, ix=ixd)
+                done["items"] += n
+                done["lifted"] += nl
+                done["cmp"] += n_cmp
+                done["mid"] += int(eng.timing().n_mid_items)
+                done["reads"] += ws[k].n_reads
+
+        runner.run([d.desc() for d in dbs], consume=consume)
+        del dbs, ws
+    runner.close()
+    index.close()
+    _dump("full_size_stress_2m_streamed.json", done)
+    assert done["reads"] == n_total and done["items"] > n_total and done["cmp"] > 1000 and done["mid"] > 0.9 * n_total
+
+
 def test_geometry_sweep(oracle):
     """every item of five workloads with different contig block-map densities / strand mixes (hence different per-batch tile
     geometries, retry and large-item traffic) against the oracle (tests/soak.py at a size that finishes in a minute)"""
