@@ -57,7 +57,7 @@ constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 
 // spanning more than 2^30 bases (PLO_ERR_RANGE) -- what the reference's types rule out by construction.
 enum { VERR_INDEX = 1u, VERR_RANGE = 2u };
 __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen, uint32_t *seg_readlen,
-                                                   uint32_t *err) {
+                                                   uint32_t *seg_nm, uint32_t *err) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = t / SEG_LANES, sub = t % SEG_LANES;
     const bool live = s < bt.n_segs;
@@ -101,16 +101,37 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     }
     long long part = 0;
     unsigned long long rpart = 0;  // read bases the CIGAR consumes (M I S H = X): what the length check compares with seq_len
-    for (uint32_t i = c0 + sub; i < c1; i += SEG_LANES * SEG_UNROLL) {  // independent loads in flight
-        uint32_t c[SEG_UNROLL];
+    // Every lane of the group takes eight CONSECUTIVE ops per step (two 16-byte loads; the group's four lanes 128 contiguous bytes), so
+    // that "is the previous op an alignment match too" -- the merged op count the lane-per-item kernel sizes its LDS regions by --
+    // needs one shuffle per step: the last op of the lane below, or of the group's last lane in the previous step.
+    uint32_t pairs = 0, carry = 0;
+    constexpr uint32_t OPL = 8;
+    for (uint32_t base = c0; base < c1; base += SEG_LANES * OPL) {
+        const uint32_t my = base + OPL * sub;
+        uint32_t c[OPL];
+        if (my + OPL <= c1) {
+            const Ops4 a = *(const Ops4 *)(bt.cigar + my), b = *(const Ops4 *)(bt.cigar + my + 4);
+            c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+        } else {
 #pragma unroll
-        for (uint32_t u = 0; u < SEG_UNROLL; ++u) c[u] = (i + SEG_LANES * u < c1) ? bt.cigar[i + SEG_LANES * u] : 0u;  // 0 = M of length 0
-#pragma unroll
-        for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
-            if ((0x18D >> (c[u] & 15u)) & 1) part += (long long)(c[u] >> 4);
-            if ((0x1B3 >> (c[u] & 15u)) & 1) rpart += (unsigned long long)(c[u] >> 4);
-            if ((c[u] & 15u) > 8u) bad |= VERR_RANGE;
+            for (uint32_t u = 0; u < OPL; ++u) c[u] = (my + u < c1) ? bt.cigar[my + u] : 0xfu;  // (15: no op code, counted nowhere below)
         }
+        uint32_t mprev = 0, mfirst = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < OPL; ++u) {
+            const uint32_t t = c[u] & 15u;
+            const bool have = my + u < c1;
+            if ((0x18D >> t) & 1) part += (long long)(c[u] >> 4);
+            if ((0x1B3 >> t) & 1) rpart += (unsigned long long)(c[u] >> 4);
+            if (have && t > 8u) bad |= VERR_RANGE;
+            const uint32_t m = (have && ((0x181u >> t) & 1u)) ? 1u : 0u;
+            if (u == 0) mfirst = m;
+            else pairs += m & mprev;
+            mprev = m;
+        }
+        const uint32_t below = (uint32_t)__shfl_up((int)mprev, 1, 64);
+        pairs += mfirst & (sub ? below : carry);
+        carry = (uint32_t)__shfl((int)mprev, (int)((threadIdx.x & 63u) | (SEG_LANES - 1)), 64);
     }
     // the first interval of every lane is fetched before the reduction needs the ops
     const uint32_t gl = g0 + sub;
@@ -123,6 +144,7 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     for (uint32_t d = 1; d < SEG_LANES; d <<= 1) {
         part += __shfl_xor(part, (int)d, 64);
         rpart += (unsigned long long)__shfl_xor((long long)rpart, (int)d, 64);
+        pairs += (uint32_t)__shfl_xor((int)pairs, (int)d, 64);
     }
     if (part > 0x3fffffffLL) bad |= VERR_RANGE;
     if (bad) atomicOr(err, bad);
@@ -136,6 +158,7 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     if (!live || sub != 0) return;
     seg_reflen[s] = (int)part;
     seg_readlen[s] = rpart > 0xfffffffeull ? 0xffffffffu : (uint32_t)rpart;
+    seg_nm[s] = (c1 - c0) - pairs;
     seg_cnt[s] = n;
 }
 
@@ -288,57 +311,6 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
         r0 += c == 0;
         r1 += c == 1;
         r2 += c == 2;
-    }
-}
-
-// The lane-per-item kernel runs a group of 64 items for as long as its heaviest item takes; in read order that is about twice
-// the average (a group's longest CIGAR against its mean).  So the lane part of the class order is sorted by item weight -- but
-// only inside chunks of LANE_SORT_CHUNK consecutive positions: neighbours in the order are reads over the same stretch of a
-// contig, and the groups of a chunk run on one XCD at about the same time, which is what keeps the contig lines their homology
-// probes share in that XCD's L2 (a global sort would fetch them from HBM once per read instead of once).
-// One workgroup per chunk: counting sort in LDS (weights are bounded by the lane path's limit, <= 255 bins + clamp).
-constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_MAX_CHUNK / LANE_SORT_THREADS;
-__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wsum[4];
-    const uint32_t c0 = (n0 + chunk - 1) / chunk;
-    uint32_t lo, hi;
-    if (blockIdx.x < c0) {  // chunks do not straddle the two lane classes
-        lo = blockIdx.x * chunk;
-        hi = lo + chunk < n0 ? lo + chunk : n0;
-    } else {
-        lo = n0 + (blockIdx.x - c0) * chunk;
-        hi = lo + chunk < n0 + n1 ? lo + chunk : n0 + n1;
-    }
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t g[LANE_SORT_PER], k[LANE_SORT_PER];
-#pragma unroll
-    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
-        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
-        g[j] = p < hi ? perm[p] : 0u;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
-        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
-        uint32_t w = p < hi ? weight[g[j]] : 0u;
-        k[j] = w < 255u ? w : 255u;
-        if (p < hi) atomicAdd(&hist[k[j]], 1u);
-    }
-    __syncthreads();
-    // exclusive prefix of the 256 bins: thread t owns bin t
-    const uint32_t mine = hist[threadIdx.x];
-    const uint32_t inc = (uint32_t)wv::scan_add((int)mine);
-    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
-    hist[threadIdx.x] = before + inc - mine;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
-        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
-        if (p < hi) perm[lo + atomicAdd(&hist[k[j]], 1u)] = g[j];
     }
 }
 
@@ -524,7 +496,7 @@ constexpr int LANE_WAVES = 4;
 #define PLO_LANE_WPE_MIN PLO_LANE_WPE
 #endif
 template <bool SP>
-PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw, uint32_t chunk_groups) {
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
@@ -537,16 +509,16 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
         ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, chunk_groups, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
+    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t n1, int capw, uint32_t chunk_groups) {
-    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw, chunk_groups);
+                                                                                                   uint32_t n1, int capw) {
+    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                      uint32_t n1, int capw, uint32_t chunk_groups) {
-    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw, chunk_groups);
+                                                                                                      uint32_t n1, int capw) {
+    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw);
 }
 
 // The same lane-per-item code for HEAVY items (too heavy for an LDS region: indel-dense or very long CIGARs), every lane's region in
@@ -915,8 +887,8 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf misc, whist, cls_partial, lane_scratch, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
-    DevBuf d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
+    DevBuf misc, whist, cls_partial, lane_scratch, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_nm, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
+    DevBuf d_n_m, d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
     DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense, wave_stats;
@@ -954,7 +926,6 @@ struct plo_ctx {
     // against 13.1 ms of the workgroup-per-item kernel -- every region access is an L2 round trip and 1 600 groups leave the chip
     // at 1.5 waves per SIMD to hide it; kept as an option (PLO_LANE_HEAVY_MIN) for batches of millions of heavy items.
     int lane_heavy_min = -1;
-    int lane_chunk_groups = 1;  // k_chunk_sort: groups of 64 per sorted chunk of the class order (1: no sorting)
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1195,7 +1166,6 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
-    if (const char *e = getenv("PLO_LANE_CHUNK_GROUPS")) c->lane_chunk_groups = std::min(32, std::max(1, atoi(e)));
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1212,8 +1182,8 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
-                      &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_in_off, &c->d_n_in, &c->d_pos1,
+                      &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_nm, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_n_m, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
                       &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
@@ -1322,9 +1292,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->seg_off.ensure((size_t)(ns + 1) * 4));
         HIP_TRY(c, c->seg_reflen.ensure((size_t)std::max(1u, ns) * 4));
         HIP_TRY(c, c->seg_readlen.ensure((size_t)std::max(1u, ns) * 4));
+        HIP_TRY(c, c->seg_nm.ensure((size_t)std::max(1u, ns) * 4));
         if (ns)
             hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt,
-                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->verr.as<uint32_t>());
+                               c->seg_cnt.as<uint32_t>(), c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->seg_nm.as<uint32_t>(), c->verr.as<uint32_t>());
         plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
         if (s != PLO_OK) return s;
         uint32_t *h = c->h_counters.as<uint32_t>();
@@ -1345,6 +1316,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->op_prefix.ensure((size_t)(n_items + 1) * 4));
     HIP_TRY(c, c->d_in_off.ensure(ni * 4));
     HIP_TRY(c, c->d_n_in.ensure(ni * 4));
+    HIP_TRY(c, c->d_n_m.ensure(ni * 4));
     HIP_TRY(c, c->d_pos1.ensure(ni * 4));
     HIP_TRY(c, c->d_w0.ensure(ni * 4));
     HIP_TRY(c, c->d_w1.ensure(ni * 4));
@@ -1382,6 +1354,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.item_op_prefix = c->op_prefix.as<uint32_t>();
     wk.d.in_off = c->d_in_off.as<uint32_t>();
     wk.d.n_in = c->d_n_in.as<uint32_t>();
+    wk.d.n_m = c->d_n_m.as<uint32_t>();
     wk.d.pos1 = c->d_pos1.as<int>();
     wk.d.w0 = c->d_w0.as<uint32_t>();
     wk.d.w1 = c->d_w1.as<uint32_t>();
@@ -1397,6 +1370,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.d.chrom_ref_len = c->d_chrom_ref_len.as<int>();
     wk.d.read_len = c->d_read_len.as<uint32_t>();
     wk.seg_readlen = c->seg_readlen.as<uint32_t>();
+    wk.seg_nm = c->seg_nm.as<uint32_t>();
     wk.status = c->o_status.as<uint8_t>();
     wk.flip = c->o_flip.as<uint8_t>();
     wk.mapq = c->o_mapq.as<uint8_t>();
@@ -1558,12 +1532,6 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.slab_offset = 0;
         if (n_small) {
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
-            if (attempt == 0 && c->lane_chunk_groups > 1) {
-                const uint32_t ch = 64u * (uint32_t)c->lane_chunk_groups;
-                const uint32_t chunks = (n0 + ch - 1) / ch + (n1 + ch - 1) / ch;
-                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
-                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
-            }
             const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
             const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
             int occ = 1;
@@ -1574,8 +1542,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw, (uint32_t)c->lane_chunk_groups);
-            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw, (uint32_t)c->lane_chunk_groups);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
+            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));

@@ -30,6 +30,27 @@ PLO_DEV uint32_t segment_read_len_sat(const DevBatch &bt, uint32_t seg) {
     return r > 0xfffffffeull ? 0xffffffffu : (uint32_t)r;
 }
 
+// ops of the segment's CIGAR once neighbouring alignment-match ops (M = X) are merged into one
+PLO_DEV uint32_t segment_n_merged(const DevBatch &bt, uint32_t seg) {
+    uint32_t c0 = bt.seg_cigar_off[seg], c1 = bt.seg_cigar_off[seg + 1];
+    uint32_t n = 0;
+    bool prev = false;
+    for (uint32_t i = c0; i < c1; ++i) {
+        const bool m = ((0x181u >> (bt.cigar[i] & 15u)) & 1u) != 0u;
+        n += (m && prev) ? 0u : 1u;
+        prev = m;
+    }
+    return n;
+}
+
+// The LDS region of an item in the lane-per-item kernel (lane_core.hpp): its ops (`n`: merged count when a stage that merges
+// follows, the raw count otherwise), room for what the liftover may add -- one more piece per key of the block map inside the item's
+// span (entries w0+1 .. w1-1, and w0 itself when no block holds the item's start) and one jump deletion per block entered that
+// way -- and a little slack for the shift stage.
+constexpr int LANE_SLACK = 2;
+PLO_DEV int lane_region_gap(int w0, int w1) { return 2 * (w1 > w0 ? w1 - w0 : 0); }
+PLO_DEV int lane_region_dwords(int n, int w0, int w1) { return n + lane_region_gap(w0, w1) + LANE_SLACK; }
+
 // block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
 // Eight-way: seven independent probes per level, so that a map of a few thousand blocks costs four or five memory round trips
 // instead of a dozen dependent ones (the descriptor kernel is a chain of dependent loads per item, nothing else).
@@ -181,8 +202,12 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
     wk.item_nin[i] = (uint32_t)item_weight((int)n_in, w0, w1, kv1);  // tiling weight
-    wk.item_cls[i] = (((stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd)) ? 1u : 0u) |
-                     ((wk.lane_max_w < 0 || item_weight((int)n_in, w0, w1, kv1) > wk.lane_max_w) ? 2u : 0u);
+    const bool do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
+    const uint32_t n_m = wk.seg_nm ? wk.seg_nm[seg] : segment_n_merged(bt, seg);
+    const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);  // (the lane kernel's LOAD merges match runs for these stages)
+    wk.item_cls[i] = (do_shift ? 1u : 0u) |
+                     ((wk.lane_max_w < 0 || lane_region_dwords((int)(merges ? n_m : n_in), w0, w1) > wk.lane_max_w) ? 2u : 0u);
+    wk.d.n_m[i] = n_m;
     wk.d.in_off[i] = in_off;
     wk.d.n_in[i] = n_in;
     wk.d.pos1[i] = (int)pos1;

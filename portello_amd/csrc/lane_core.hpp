@@ -40,7 +40,6 @@ static const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static __device__ const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-constexpr int LANE_SLACK = 2;  // dwords on top of an item's weight (the shift stage may add an op per cluster in odd cases)
 
 // -------------------------------------------------------------------------------------------------------------------
 // Streaming clean_up_cigar_edge_indels + compress_cigar (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:265-291, 204-228).
@@ -332,12 +331,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 #endif
 
     // ---- descriptors (build_item_desc, enumerate.hpp) ----
-    int n_in = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0, shift_ref_len = 0;
+    int n_in = 0, n_m = 0, in_off = 0, pos1 = 0, kv0 = 0, kv1 = 0, W0 = 0, W1 = 0, seq_len = 0, shift_ref_len = 0;
     bool len_bad = false, rev = false, do_shift = false, flip = false;
     unsigned long long seq_off = 0, shift_ref = 0;
     if (has) {
         in_off = (int)wk.d.in_off[g];
         n_in = (int)wk.d.n_in[g];
+        n_m = (int)wk.d.n_m[g];
         W0 = (int)wk.d.w0[g];
         W1 = (int)wk.d.w1[g];
         kv0 = (int)wk.d.kv0[g];
@@ -355,11 +355,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         const bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
         do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
     }
-    // Room in front of a stage's input = what the liftover may add to it: one more piece per key of the block map inside the
-    // item's span -- entries W0+1 .. W1-1, and W0 itself when no block holds the item's start -- and one jump deletion (:91-96)
-    // per block entered that way.
-    const int gap = has ? 2 * wv::imax(0, W1 - W0) : 0;
-    const int W = n_in + gap + LANE_SLACK;  // the item's region, dwords
+    // The item's region (enumerate.hpp lane_region_dwords): its ops as LOAD stores them -- match runs merged when the next stage
+    // merges them anyway -- behind a gap for what the liftover may add.
+    const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);
+    const int n_ld = merges ? n_m : n_in;
+    const int gap = has ? lane_region_gap(W0, W1) : 0;
+    const int W = n_ld + gap + LANE_SLACK;  // dwords
 
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
@@ -411,8 +412,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // ops to walk -- and the ops of a shifted item then alternate match / cluster, which is what keeps its scans short.
         {
             const bool ld = act0;
-            const bool merge = ld & (shift_on | ((stages & PLO_STAGE_LIFTOVER) != 0));
-            const int inb = shift_on ? W - n_in : gap;
+            const bool merge = ld & merges;
+            const int inb = shift_on ? W - n_ld : gap;
             const int nmax = wv::reduce_max(ld ? n_in : 0);
             uint32_t run = 0;
             bool has_run = false;
@@ -854,23 +855,22 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // Persistent wave over the groups of the lane classes: class c (0: no shift stage, 1: shift stage) occupies positions
 // [c_begin, c_end) of the class order and is cut into groups of 64 from its start, so that groups are strand-homogeneous.
 // Group indices: class 0 first.  The item indices of the next group are fetched one group ahead.
+// (Measured and dropped: the class order sorted by item weight inside chunks of 4 .. 32 groups, so that a group does not wait for
+// its one longest CIGAR -- a quarter fewer loop trips per group, but 5-15 % slower overall: neighbours in the batch share
+// descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.)
 template <bool SP>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
-                                   uint32_t n0, uint32_t n1, uint32_t LANE_CHUNK_GROUPS, uint32_t *lds, int capw, WaveCtx &ctx) {
+                                   uint32_t n0, uint32_t n1, uint32_t *lds, int capw, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
     const uint32_t t0 = (n0 + 63u) >> 6, t1 = (n1 + 63u) >> 6;
-    // The order is sorted by weight inside chunks of LANE_CHUNK_GROUPS groups (k_chunk_sort; 1 = unsorted) and the number of waves is
-    // usually a multiple of that: without the per-chunk rotation a wave would take the same rank -- say, the heaviest group -- of
-    // every chunk.
     auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
-        const bool c1 = t >= t0;
-        const uint32_t base = c1 ? n0 : 0u, end = c1 ? n0 + n1 : n0, tc = c1 ? t - t0 : t, nt = c1 ? t1 : t0;
-        const uint32_t chunk = tc / LANE_CHUNK_GROUPS, r = tc % LANE_CHUNK_GROUPS;
-        const uint32_t ng = nt - chunk * LANE_CHUNK_GROUPS < LANE_CHUNK_GROUPS ? nt - chunk * LANE_CHUNK_GROUPS : LANE_CHUNK_GROUPS;
-        const uint32_t rot = ((chunk + (c1 ? 7u : 0u)) * 0x9E3779B1u) >> 16;
-        const uint32_t tt = chunk * LANE_CHUNK_GROUPS + (r + rot) % ng;
-        lo = base + tt * 64u;
-        hi = lo + 64u < end ? lo + 64u : end;
+        if (t < t0) {
+            lo = t * 64u;
+            hi = lo + 64u < n0 ? lo + 64u : n0;
+        } else {
+            lo = n0 + (t - t0) * 64u;
+            hi = lo + 64u < n0 + n1 ? lo + 64u : n0 + n1;
+        }
     };
     uint32_t t = first;
     uint32_t g_next = 0;

@@ -59,6 +59,7 @@ enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN
 struct ItemDesc {
     uint32_t *in_off;   // first input CIGAR op of the item's read segment
     uint32_t *n_in;     // number of input ops
+    uint32_t *n_m;      // ... after merging neighbouring alignment-match ops (= X M): what the lane-per-item kernel walks (lane_core.hpp LOAD)
     int *pos1;          // start on the map strand: seg_pos, or rev_pos for reverse-mapped contig segments (STRAND)
     uint32_t *w0, *w1;  // window [w0, w1) of the contig segment's block map that can intersect the item
     uint32_t *kv0, *kv1;  // the contig segment's whole block map
@@ -109,6 +110,7 @@ struct DevWork {
     unsigned long long *wave_stats;  // [waves of the launch][4]: algorithmic bytes, input ops, output ops of every wave (summed by k_sum_stats)
     uint32_t *big_list;            // items too heavy for a shared tile: workgroup-per-item kernel (k_lift_mid)
     const uint32_t *seg_readlen;   // [n_segs] read bases consumed by every read segment's CIGAR (k_seg_count); NULL: computed per item
+    const uint32_t *seg_nm;        // [n_segs] op count of every read segment's CIGAR with neighbouring match ops merged (k_seg_count); NULL: per item
     uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
     uint32_t stat_base;            // first statistic slot of the launch (every lift launch of a batch has its own range)
     uint32_t *miss_list;           // PLO_SEQ_BAM4_SPARSE: items whose probes needed absent bases (PLO_ITEM_NEED_BASES)

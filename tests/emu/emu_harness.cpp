@@ -97,7 +97,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     std::vector<int> d_pos1(a);
     std::vector<uint64_t> d_seq_off(a), d_shift_ref(a), d_chrom_ref(a);
     std::vector<int> d_shift_ref_len(a), d_chrom_ref_len(a);
-    std::vector<uint32_t> d_read_len(a);
+    std::vector<uint32_t> d_read_len(a), d_n_m(a);
     unsigned long long counters[CNT_N];
     memset(counters, 0, sizeof(counters));
 
@@ -125,6 +125,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.d.chrom_ref = d_chrom_ref.data();
     wk.d.chrom_ref_len = d_chrom_ref_len.data();
     wk.d.read_len = d_read_len.data();
+    wk.d.n_m = d_n_m.data();
     wk.status = o->status.data();
     wk.flip = o->flip.data();
     wk.mapq = o->mapq.data();
@@ -168,16 +169,6 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         nin_p[j] = item_cls[i] >= 2 ? item_nin[i] : 0;  // only the large items are tiled
     }
     const uint32_t n_small = r0[n_items] + r1[n_items], n_large = n_items - n_small;
-    {   // k_chunk_sort: the lane part of the class order sorted by weight inside chunks of 4 groups (per class)
-        const uint32_t CH = 64 * 4, n0 = r0[n_items], n1 = r1[n_items];
-        auto sort_range = [&](uint32_t lo, uint32_t hi) {
-            for (uint32_t a0 = lo; a0 < hi; a0 += CH)
-                std::stable_sort(perm.begin() + a0, perm.begin() + std::min(hi, a0 + CH),
-                                 [&](uint32_t x, uint32_t y) { return std::min(item_nin[x], 255u) < std::min(item_nin[y], 255u); });
-        };
-        sort_range(0, n0);
-        sort_range(n0, n0 + n1);
-    }
     wk.perm = perm.data();
     wk.n_small = n_small;
     wk.retry_list = retry_list.data();
@@ -228,8 +219,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
                 w.run([&]() {
                     WaveCtx ctx;
-                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], 4u, llds.data(), lane_capw, ctx);
-                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], 4u, llds.data(), lane_capw, ctx);
+                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
+                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();
