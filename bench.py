@@ -700,6 +700,33 @@ def main():
         for e in o_engs:
             e.close()
 
+    # a reference-sized window (the reference lifts ~50 k reads per 20 Mb window task, src/read_alignment_scanner.rs:508-534,575): the
+    # per-call fixed cost -- launches, host round trips -- against a batch forty times smaller than the headline's
+    window_50k = None
+    if dist is None and n_workers == 1 and w.n_reads >= 100_000:
+        try:
+            lo = w.n_reads // 2
+            wdb = devbatch.DeviceBatch.from_workload(w, lo, lo + 50_000)
+            wdesc = wdb.desc()
+            torch.cuda.synchronize()
+            for _ in range(5):
+                eng.liftover_batch_dev(wdesc)
+            eng.sync()
+            n_calls = 200
+            t1 = time.perf_counter()
+            for _ in range(n_calls):
+                eng.liftover_batch_dev(wdesc)
+            eng.sync()
+            wdt = time.perf_counter() - t1
+            tmw = eng.timing()
+            window_50k = {"value": 50_000 * n_calls / wdt, "unit": "reads/s", "reads_per_call": 50_000, "calls": n_calls, "ms_per_call": wdt / n_calls * 1e3,
+                          "device_ms_per_call": float(tmw.total_ms), "host_workers_per_gpu": 1,
+                          "note": "plo_liftover_batch_dev on a device-resident 50 k-read window, one context, back to back"}
+            last_out[0] = eng.liftover_batch_dev(desc)  # (the headline batch's result back in the context: the parity sample below reads it)
+            eng.sync()
+        except Exception as e:  # noqa: BLE001 -- supplementary
+            log(f"[bench] window_50k failed: {e!r}")
+
     # Everything from here on is supplementary.  At N > 1 it runs more collectives (gather variants, verification): if any of that
     # does not finish, every rank gives up after a while and rank 0 still prints the headline measurement made above.
     watchdog = None
@@ -745,7 +772,7 @@ def main():
         log(f"[bench] supplementary distributed measurements failed: {e!r}")
     if watchdog is not None:
         watchdog.cancel()
-    for name, obj in (("shard", shard_info), ("overlap", overlap), ("no_gather", no_gather), ("gather_modes", gather_modes),
+    for name, obj in (("shard", shard_info), ("overlap", overlap), ("window_50k", window_50k), ("no_gather", no_gather), ("gather_modes", gather_modes),
                       ("verify", verify)):
         if obj is not None:
             result[name] = obj

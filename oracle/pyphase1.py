@@ -140,6 +140,7 @@ class Seg:  # SeqOrderSplitReadSegment (split_read.rs:15-32)
     cigar: List[int]
     mapq: int
     from_primary_bam_record: bool
+    no_map: bool = False  # target-region runs: SA segment without its supplementary record -> empty contig_to_ref_map (mod.rs:396-414)
 
 
 def _reverse_range(r: Tuple[int, int], size: int) -> Tuple[int, int]:  # int_range.rs:89-94
@@ -198,6 +199,8 @@ def clip_repeated_contig_matches(contigs: List[List[Seg]]) -> int:  # :214-303
                 ci = i1 if clip_seg1 else i2
                 if clip_seg_isec_range(segs[ci], isec):
                     eliminated[ci] = True
+                else:
+                    segs[ci].no_map = False  # clip_seg_info_isec_range rebuilds the map (trimmer.rs:130-134)
                 clipped += 1
         segs[:] = [s for s, e in zip(segs, eliminated) if not e]
     return clipped
@@ -269,6 +272,7 @@ def join_segments(s1: Seg, s2: Seg):  # :59-122
         s1.cigar, s2.cigar = s2.cigar, s1.cigar
         s1.pos = s2.pos
     s1.seq_order_read_end = s2.seq_order_read_end
+    s1.no_map = False  # the joined segment's map is rebuilt from the joined CIGAR (joiner.rs:62-121)
 
 
 def join_colinear_contig_segments(contigs: List[List[Seg]]) -> int:  # :124-186
@@ -341,6 +345,7 @@ def scan_contig_bam(records: Sequence[bytes], ref_names: Sequence[str], contig_n
                 s.cigar = list(supp[cid][k])
             else:
                 assert target_region is not None, "Can't find supplementary alignment record corresponding to segment reported in SA tag"
+                s.no_map = True
     if target_region is not None:  # filter_non_targeted_segments
         tc, ts, te = target_region
         for cid in range(n):

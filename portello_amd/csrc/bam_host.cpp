@@ -130,7 +130,11 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     // walk the records of the inflated stream (no copies), then take the whole stretch with one parallel copy
     size_t at = 0;  // offset from r->in.bpos
     std::vector<uint64_t> unm_at;
+    // A window also ends after 4 x max_records unmapped records or 1 GB of records: the tail of unmapped reads of a sorted
+    // read->contig BAM (often gigabytes) then comes in windows of bounded size instead of one
+    const size_t unm_cap = 4 * (size_t)max_records + 1024, byte_cap = (size_t)1 << 30;
     while (w->rec_at.size() < max_records) {
+        if (unm_at.size() >= unm_cap || (at >= byte_cap && w->rec_at.size() + unm_at.size() > 0)) break;
         if (r->in.avail() < at + 4 && (st = timed_fill(at + 4)) != PLO_OK) break;
         if (r->in.avail() == at) break;  // end of file
         if (r->in.avail() < at + 4) {

@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     // needs one shuffle per step: the last op of the lane below, or of the group's last lane in the previous step.
     uint32_t pairs = 0, carry = 0;
     constexpr uint32_t OPL = 8;
+    const uint32_t n_ops_all = bt.n_segs ? bt.seg_cigar_off[bt.n_segs] : 0u;
     for (uint32_t base = c0; base < c1; base += SEG_LANES * OPL) {
         const uint32_t my = base + OPL * sub;
         uint32_t c[OPL];
-        if (my + OPL <= c1) {
+        if (my < c1 && my + OPL <= n_ops_all) {  // (ops behind the segment's end belong to the next segment: masked by `have` below)
             const Ops4 a = *(const Ops4 *)(bt.cigar + my), b = *(const Ops4 *)(bt.cigar + my + 4);
             c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
         } else {
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
         for (uint32_t u = 0; u < OPL; ++u) {
             const uint32_t t = c[u] & 15u;
             const bool have = my + u < c1;
-            if ((0x18D >> t) & 1) part += (long long)(c[u] >> 4);
-            if ((0x1B3 >> t) & 1) rpart += (unsigned long long)(c[u] >> 4);
+            if (have && ((0x18D >> t) & 1)) part += (long long)(c[u] >> 4);
+            if (have && ((0x1B3 >> t) & 1)) rpart += (unsigned long long)(c[u] >> 4);
             if (have && t > 8u) bad |= VERR_RANGE;
             const uint32_t m = (have && ((0x181u >> t) & 1u)) ? 1u : 0u;
             if (u == 0) mfirst = m;
@@ -225,17 +226,14 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_t
 // which also reduces the weights the host sizes buffers by), an exclusive scan of the block counts (k_cls_scan, one workgroup),
 // and the permutation itself from block offset + rank inside the block (k_permute2).
 constexpr uint32_t CLS_THREADS = 256, CLS_PER = 8, CLS_BLOCK = CLS_THREADS * CLS_PER;
-// totals: [0..2] items of class 0 / 1 / 2, [3] heaviest item, [4..5] 64-bit sum of the weights; must be zeroed
-__global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial,
-                                                          uint32_t *totals) {
-    __shared__ uint32_t acc[4];
-    __shared__ unsigned long long accw;
-    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
-    if (threadIdx.x == 0) accw = 0;
+// partial: [5][nb] per block: items of class 0 / 1 / 2, heaviest item, sum of the weights (a block's 2 048 weights of < 2^21 fit 32 bits);
+// totals (k_cls_scan): [0..2] class counts, [3] heaviest item, [4..5] 64-bit sum of the weights
+__global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial) {
+    __shared__ uint32_t acc[5];
+    if (threadIdx.x < 5) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
-    uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0;
-    unsigned long long sw = 0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0, sw = 0;
     for (uint32_t k = 0; k < CLS_PER; ++k) {
         if (base + k < n) {
             const uint32_t c = item_cls[base + k], w = item_w[base + k];
@@ -243,25 +241,21 @@ __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_c
             c1 += c == 1;
             c2 += c == 2;
             mw = w > mw ? w : mw;
-            sw += w;
+            sw += w < 0x1fffffu ? w : 0x1fffffu;  // (heavier items are beyond every kernel's reach anyway; the sum only sizes buffers)
         }
     }
     // (counts of a wave fit 16 bits: 64 threads x 8 items)
     const int p01 = wv::reduce_add((int)(c0 | (c1 << 16))), p2 = wv::reduce_add((int)c2), pm = wv::reduce_max((int)(mw & 0x7fffffffu));
-    const unsigned lo = (unsigned)wv::reduce_add((int)(unsigned)(sw & 0xffffffull)), hi = (unsigned)wv::reduce_add((int)(unsigned)(sw >> 24));
+    const int ps = wv::reduce_add((int)sw);
     if ((threadIdx.x & 63u) == 0) {
         atomicAdd(&acc[0], (uint32_t)p01 & 0xffffu);
         atomicAdd(&acc[1], (uint32_t)p01 >> 16);
         atomicAdd(&acc[2], (uint32_t)p2);
         atomicMax(&acc[3], (uint32_t)pm);
-        atomicAdd(&accw, (unsigned long long)lo + ((unsigned long long)hi << 24));
+        atomicAdd(&acc[4], (uint32_t)ps);
     }
     __syncthreads();
-    if (threadIdx.x < 3) partial[threadIdx.x * nb + blockIdx.x] = acc[threadIdx.x];
-    if (threadIdx.x == 0) {
-        if (acc[3]) atomicMax(&totals[3], acc[3]);
-        atomicAdd((unsigned long long *)(totals + 4), accw);
-    }
+    if (threadIdx.x < 5) partial[threadIdx.x * nb + blockIdx.x] = acc[threadIdx.x];
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, uint32_t nb, uint32_t *totals) {
     __shared__ unsigned wt[4];
@@ -277,6 +271,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, ui
             carry += tot;
         }
         if (threadIdx.x == 0) totals[c] = carry;
+    }
+    // heaviest item and the sum of the weights
+    unsigned mx = 0;
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS) {
+        mx = partial[3 * nb + i] > mx ? partial[3 * nb + i] : mx;
+        sum += partial[4 * nb + i];
+    }
+    __shared__ unsigned long long ssum;
+    __shared__ unsigned smax;
+    if (threadIdx.x == 0) {
+        ssum = 0;
+        smax = 0;
+    }
+    __syncthreads();
+    atomicMax(&smax, mx);
+    atomicAdd(&ssum, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[3] = smax;
+        totals[4] = (uint32_t)(ssum & 0xffffffffull);
+        totals[5] = (uint32_t)(ssum >> 32);
     }
 }
 __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *partial, const uint32_t *totals,
@@ -1423,12 +1439,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     {
         HIP_TRY(c, c->misc.ensure(256));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
-        HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 3 * 4));
+        HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 5 * 4));
         uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;  // clear of h[0..47] below
         memset(m_, 0, 8 * 4);
         if (n_items) {
             hipLaunchKernelGGL(k_cls_hist, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(),
-                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, cls_nb, c->cls_partial.as<uint32_t>(), c->misc.as<uint32_t>());
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, cls_nb, c->cls_partial.as<uint32_t>());
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_THREADS), 0, st, c->cls_partial.as<uint32_t>(), cls_nb, c->misc.as<uint32_t>());
             HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, 6 * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipMemcpyAsync(m_ + 6, c->verr.p, 4, hipMemcpyDeviceToHost, st));

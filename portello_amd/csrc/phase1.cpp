@@ -109,6 +109,10 @@ struct Seg {  // ContigMappingSegmentInfo's seq_order_segment (the block map is 
     bool fwd = true;
     uint8_t mapq = 0;
     bool primary = false;
+    // target-region runs: an SA-tag segment whose supplementary record was never seen keeps the tag's approximate CIGAR but gets NO
+    // block map (contig_to_ref_map stays empty, mod.rs:396-414) -- until the trimmer or the joiner rebuild the map from the CIGAR
+    // (contig_repeated_match_trimmer.rs:130-134, contig_colinear_segment_joiner.rs:62-121)
+    bool no_map = false;
     Cigar cigar;
 };
 struct Range {
@@ -314,7 +318,9 @@ plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const
             auto it = ct.supp.find(key_of(s.chrom, s.pos, s.fwd, s.cigar));
             if (it != ct.supp.end()) {
                 s.cigar = it->second;
-            } else if (!target_region) {
+            } else if (target_region) {
+                s.no_map = true;
+            } else {
                 delete ph;
                 return fail(PLO_ERR_DATA, std::string("Can't find supplementary alignment record corresponding to segment reported in SA tag for contig '") +
                                               contig_names[c] + "'");
@@ -354,6 +360,7 @@ plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const
                 const bool clip_seg1 = g2 > g1 || (g2 == g1 && s2.mapq > s1.mapq);
                 const size_t ci = clip_seg1 ? i1 : i2;
                 if (clip_seg_isec_range(ct.segs[ci], isec)) eliminated[ci] = 1;
+                else ct.segs[ci].no_map = false;  // clip_seg_info_isec_range rebuilds the map of a segment it has clipped (:130-134)
                 ++ph->segments_clipped;
             }
         }
@@ -425,6 +432,7 @@ plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const
                 last.pos = seg.pos;
             }
             last.so_end = seg.so_end;
+            last.no_map = false;  // join_segments rebuilds the map from the joined CIGAR (:62-121)
             ++ph->segments_joined;
         }
     }
@@ -441,7 +449,7 @@ plo_status plo_phase1_scan(const char *asm_to_ref_bam, uint32_t n_contigs, const
             ph->seg_mapq.push_back(s.mapq);
             ph->seg_so_start.push_back((int64_t)s.so_start);
             ph->seg_so_end.push_back((int64_t)s.so_end);
-            ph->seg_cigar.insert(ph->seg_cigar.end(), s.cigar.begin(), s.cigar.end());
+            if (!s.no_map) ph->seg_cigar.insert(ph->seg_cigar.end(), s.cigar.begin(), s.cigar.end());  // (no CIGAR: an empty block map)
             ph->seg_cigar_off.push_back((uint32_t)ph->seg_cigar.size());
         }
         ph->contig_seg_off.push_back((uint32_t)ph->seg_chrom.size());

@@ -406,3 +406,28 @@ def test_bam_to_bam_chr20_size_every_record(tmp_path):
     assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st.records_out == v["records_in_output"], v
     assert v["unassembled_ok"]
     index.close()
+
+
+def test_long_tail_of_unmapped_reads_comes_in_bounded_windows(tmp_path):
+    """a window ends on the count of primary records -- and on 4 x that many (+ 1024) unmapped ones: the unmapped tail of a sorted BAM does
+    not end up in one window, and every pass-through record still arrives exactly once, in order"""
+    p = str(tmp_path / "tail.bam")
+    wr = bam.BamWriter(p, "@HD\tVN:1.6\n", ["ctg0"], [1000], level=1)
+    recs = [_sam_record(0, 5, "10M", "ACGTACGTAC", "IIIIIIIIII")]
+    tail = [bamsynth.encode_record(-1, -1, 0, 0x4, b"u%06d" % i, np.zeros(0, np.uint32), bytes(5), 10, b"\x20" * 10, b"") for i in range(3000)]
+    wr.write(b"".join(recs + tail))
+    wr.close()
+    rd = bam.BamReader(p, 2)
+    got, n_windows, n_prim = b"", 0, 0
+    while True:
+        win = rd.read_window(100)  # unmapped cap = 4 * 100 + 1024
+        if win is None:
+            break
+        u, k = win.unmapped_bytes()
+        assert k <= 4 * 100 + 1024
+        got += u
+        n_prim += win.n_records
+        n_windows += 1
+        win.close()
+    rd.close()
+    assert n_prim == 1 and n_windows == 3 and got == b"".join(tail)

@@ -232,3 +232,37 @@ def test_phase1_supplementary_record_with_long_cigar_in_cg_tag(tmp_path):
                    for s in exp.contigs[0]]
     assert len(got) == 2 and len(got[1][6]) > 65535  # the supplementary segment carries the record's own 70 001-op CIGAR
     ph.close()
+
+
+def test_phase1_target_region_unmatched_sa_segment_has_no_map(tmp_path):
+    """targeted run, SA segment inside the region whose supplementary record is missing: the reference keeps the segment (it still
+    takes part in the read -> contig segment selection) but leaves its contig_to_ref_map empty (mod.rs:396-414), so nothing lifts
+    through the SA tag's approximate CIGAR; a segment the trimmer clips gets its map rebuilt from that CIGAR (trimmer.rs:130-134)"""
+    rn, cn = ["chr1"], ["ctg"]
+
+    def scan(prim_cigar, sa):
+        prim = bamsynth.encode_record(0, 1000, 60, 0, b"ctg", np.array(C(prim_cigar), np.uint32), bytes(50), 100, b"\xff" * 100, sa)
+        path = str(tmp_path / "t2.bam")
+        wr = bam.BamWriter(path, "@HD\tVN:1.6\n", rn, [100000], level=0)
+        wr.write(prim)
+        wr.close()
+        ph = bam.Phase1(path, cn, [100], target_region=(0, 900, 1100), n_threads=1)
+        ixd = ph.index_data([np.zeros(100000, np.uint8)])
+        got = _segments_of(ixd)[0]
+        exp = p1.scan_contig_bam([prim], rn, cn, target_region=(0, 900, 1100))
+        ph.close()
+        return got, exp.contigs[0]
+
+    # no overlap between the two segments: the SA segment stays as it is, without a map (empty CIGAR in the index description)
+    got, exp = scan("60=40S", b"SAZchr1,1051,+,60S40M,60,0;\0")
+    assert [(g[0], g[1], g[3], len(g[6])) for g in got] == [(0, 60, 1000, 2), (60, 100, 1050, 0)]
+    assert [s.no_map for s in exp] == [False, True]
+    # overlapping on [50, 60), equal identity / MAPQ: the later (SA) segment is clipped -> its map is rebuilt from the clipped CIGAR
+    # (trimmer.rs:130-134); here the clipped segment then continues the first one exactly and the joiner merges the two
+    got, exp = scan("60=40S", b"SAZchr1,1051,+,50S50=,60,0;\0")
+    assert [(g[0], g[1], g[3]) for g in got] == [(0, 100, 1000)] and cg.decode(np.array(got[0][6], np.uint32)) == "60=40="
+    assert [(s.seq_order_read_start, s.seq_order_read_end, s.pos, s.no_map) for s in exp] == [(0, 100, 1000, False)]
+    # the same overlap but on the other strand (no join): the clipped SA segment stays a segment of its own, WITH a map
+    got, exp = scan("60=40S", b"SAZchr1,1051,-,50=50S,60,0;\0")
+    assert [(g[0], g[1]) for g in got] == [(0, 60), (60, 100)] and len(got[1][6]) > 0
+    assert [s.no_map for s in exp] == [False, False]
