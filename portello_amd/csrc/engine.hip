@@ -330,6 +330,56 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
     }
 }
 
+// The lane-per-item kernel runs a group of 64 items for as long as its longest item takes -- in batch order about twice the average.
+// Inside windows of LANE_SORT_WINDOW consecutive positions of the class order (two groups: the reads of a window still share their
+// descriptor / CIGAR / block-map cache lines) the items are therefore sorted by weight: a group of the longer and a group of the
+// shorter ones.  One workgroup per window, counting sort in LDS.
+constexpr uint32_t LANE_SORT_WINDOW = 128;
+constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_MAX_CHUNK / LANE_SORT_THREADS;
+__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t c0 = (n0 + chunk - 1) / chunk;
+    uint32_t lo, hi;
+    if (blockIdx.x < c0) {  // chunks do not straddle the two lane classes
+        lo = blockIdx.x * chunk;
+        hi = lo + chunk < n0 ? lo + chunk : n0;
+    } else {
+        lo = n0 + (blockIdx.x - c0) * chunk;
+        hi = lo + chunk < n0 + n1 ? lo + chunk : n0 + n1;
+    }
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t g[LANE_SORT_PER], k[LANE_SORT_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        g[j] = p < hi ? perm[p] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        uint32_t w = p < hi ? weight[g[j]] : 0u;
+        k[j] = w < 255u ? w : 255u;
+        if (p < hi) atomicAdd(&hist[k[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix of the 256 bins: thread t owns bin t
+    const uint32_t mine = hist[threadIdx.x];
+    const uint32_t inc = (uint32_t)wv::scan_add((int)mine);
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    hist[threadIdx.x] = before + inc - mine;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+        const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
+        if (p < hi) perm[lo + atomicAdd(&hist[k[j]], 1u)] = g[j];
+    }
+}
+
 // thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
 __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t n_small, uint32_t *tile_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -937,6 +987,8 @@ struct plo_ctx {
     // per item -- 36 KB of LDS per wave, synchronous probes -- was a net loss and had been removed; this is a different kernel.)
     int lane_max_w = 192;
     int lane_capw = 3072;
+    bool lane_sort = true;  // k_chunk_sort before the lane kernel
+    int lane_sort_window = LANE_SORT_WINDOW;
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch) for batches with at least that many
     // heavy items; < 0: never (default).  Measured on the stress workload, 100 k reads: 15.9 ms at 64 items per wave (21.5 at 16)
     // against 13.1 ms of the workgroup-per-item kernel -- every region access is an L2 round trip and 1 600 groups leave the chip
@@ -1181,6 +1233,8 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
+    if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
+    if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = std::min(2048, std::max(64, atoi(e) & ~63));
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
@@ -1548,6 +1602,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.slab_offset = 0;
         if (n_small) {
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
+            if (attempt == 0 && c->lane_sort) {
+                const uint32_t ch = (uint32_t)c->lane_sort_window;
+                const uint32_t chunks = (n0 + ch - 1) / ch + (n1 + ch - 1) / ch;
+                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
+                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
+            }
             const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
             const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
             int occ = 1;

@@ -872,24 +872,32 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
             hi = lo + 64u < n0 + n1 ? lo + 64u : n0 + n1;
         }
     };
-    uint32_t t = first;
+    // round j: wave w takes group j * stride + (w + j) % stride -- the waves rotate through the slots from round to round, so that
+    // a wave does not keep drawing the longer (or the shorter) half of every sorted window (k_chunk_sort) when the number of waves
+    // is even
+    auto slot = [&](uint32_t j) { return j * stride + (first + j) % stride; };
+    uint32_t j = 0, t = slot(0);
     uint32_t g_next = 0;
     if (t < t0 + t1) {
         uint32_t lo, hi;
         group(t, lo, hi);
         g_next = lo + lane < hi ? wk.perm[lo + lane] : 0u;
     }
-    for (; t < t0 + t1; t += stride) {
-        uint32_t lo, hi;
-        group(t, lo, hi);
+    for (; j * stride < t0 + t1; ++j) {
+        t = slot(j);
+        const uint32_t tn = slot(j + 1);
         const uint32_t g = g_next;
-        if (t + stride < t0 + t1) {
+        if (tn < t0 + t1) {
             uint32_t lo2, hi2;
-            group(t + stride, lo2, hi2);
+            group(tn, lo2, hi2);
             g_next = lo2 + lane < hi2 ? wk.perm[lo2 + lane] : 0u;
         }
-        lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g);
-        wv::sync();
+        if (t < t0 + t1) {
+            uint32_t lo, hi;
+            group(t, lo, hi);
+            lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g);
+            wv::sync();
+        }
     }
 }
 
