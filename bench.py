@@ -352,6 +352,9 @@ def main():
                     help="N > 1: strong = one read set sharded by windows over the ranks (BASELINE configs[3]); weak = every rank "
                          "its own read set of the full size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-calls", type=int, default=200,
+                    help="N = 1: calls of the supplementary `window_50k` measurement (0 = skip: traced / counter runs skip it, its launches "
+                         "would enter the per-kernel averages)")
     ap.add_argument("--chunk-reads", type=int, default=0,
                     help="N = 1: read sets of more than this many reads are lifted as a stream of batches (portello_amd/stream.py); default "
                          "250 k for the stress profile (0.5 G input ops per batch; a batch is bounded by 31-bit op indices), 8 M otherwise")
@@ -703,7 +706,7 @@ def main():
     # a reference-sized window (the reference lifts ~50 k reads per 20 Mb window task, src/read_alignment_scanner.rs:508-534,575): the
     # per-call fixed cost -- launches, host round trips -- against a batch forty times smaller than the headline's
     window_50k = None
-    if dist is None and n_workers == 1 and w.n_reads >= 100_000:
+    if dist is None and n_workers == 1 and w.n_reads >= 100_000 and args.window_calls > 0:
         try:
             lo = w.n_reads // 2
             wdb = devbatch.DeviceBatch.from_workload(w, lo, lo + 50_000)
@@ -712,7 +715,7 @@ def main():
             for _ in range(5):
                 eng.liftover_batch_dev(wdesc)
             eng.sync()
-            n_calls = 200
+            n_calls = args.window_calls
             t1 = time.perf_counter()
             for _ in range(n_calls):
                 eng.liftover_batch_dev(wdesc)

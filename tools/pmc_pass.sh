@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 ctrs="$1"; rx="${2:-k_lift_tiles}"; shift; shift || true
 d=$(mktemp -d /tmp/pmc.XXXXXX)
-timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc $ctrs --kernel-include-regex "$rx" --output-format csv -d "$d" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-workers 0 "$@" > /dev/null 2>&1
+timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc $ctrs --kernel-include-regex "$rx" --output-format csv -d "$d" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-workers 0 --window-calls 0 "$@" > /dev/null 2>&1
 python3 - "$d" <<'PY'
 import csv, glob, collections, sys
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):

@@ -7,7 +7,7 @@ v=${1:-v1}
 o=gpurun_out/$v
 mkdir -p $o
 python bench.py > $o/bench.json 2>/dev/null
-rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0 > $o/bench_under_rocprof.json 2>/dev/null
+rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0 --window-calls 0 > $o/bench_under_rocprof.json 2>/dev/null
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/kernel_stats.csv
 PMC_EXTRA="--e2e-reads 0"
 tools/pmc_pass.sh "FETCH_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
@@ -18,7 +18,7 @@ tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_C
 S="--workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0"
 SK=${PLO_PROFILE_STRESS_KERNEL:-k_lift_mid}
 python bench.py $S > $o/stress_bench.json 2>/dev/null
-rm -rf /tmp/kt2; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 bench.py $S --no-cpu-baseline --overlap-workers 0 > $o/stress_bench_under_rocprof.json 2>/dev/null
+rm -rf /tmp/kt2; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 bench.py $S --no-cpu-baseline --overlap-workers 0 --window-calls 0 > $o/stress_bench_under_rocprof.json 2>/dev/null
 f=$(find /tmp/kt2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/stress_kernel_stats.csv
 tools/pmc_pass.sh "FETCH_SIZE" "$SK" $S > $o/stress_pmc_fetch.csv 2>&1
 tools/pmc_pass.sh "WRITE_SIZE" "$SK" $S > $o/stress_pmc_write.csv 2>&1

@@ -16,7 +16,7 @@ hdr, body = rows[0], rows[1:]
 tot = sum(int(r[2]) for r in body)
 eng = [r for r in body if r[0].startswith("k_")]
 with open(f"{pre}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0   (default workload wgs30x, 10 steps + 2 warm-up)\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0 --window-calls 0   (default workload wgs30x, 10 steps + 2 warm-up)\n")
     f.write(f"# rows of the engine kernels only (the other {len(body) - len(eng)} rows are torch kernels of the synthetic generator); total traced kernel time {tot} ns\n")
     w = csv.writer(f)
     w.writerow(hdr)
@@ -32,7 +32,7 @@ def rd(p):
 
 fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
 with open(f"{pre}_pmc_summary.csv", "w") as f:
-    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex <dominant kernel> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-reads 0\n")
+    f.write("# rocprofv3 --pmc <counters> --kernel-include-regex <dominant kernel> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-workers 0 --window-calls 0 --e2e-reads 0\n")
     f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of the dominant kernel (k_lift_lanes for this workload); FETCH_SIZE / WRITE_SIZE in KiB\n")
     f.write("counter,mean_per_launch,launches\n")
     for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
