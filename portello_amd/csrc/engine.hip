@@ -48,8 +48,9 @@ using namespace plo;
 // xor-shuffle reduction, so that one load instruction covers SEG_LANES * 4 contiguous bytes of every segment's CIGAR;
 // lane 0 of the group then does the overlap test against the contig's segments.
 #ifndef PLO_SEG_LANES
-#define PLO_SEG_LANES 4  // measured on MI355X (wgs30x enumerate pass, round 1): 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms;
-                         // round 2: 8 lanes 0.539 ms, 4 lanes (8 loads in flight per lane) 0.485 ms, 2 lanes 0.486 ms
+#define PLO_SEG_LANES 2  // measured on MI355X (wgs30x enumerate pass): round 1, strided dword loads: 8 lanes 0.64 ms, 16 lanes 1.52 ms, 32 lanes 0.99 ms;
+                         // round 2: 8 lanes 0.539 ms, 4 lanes 0.485 ms, 2 lanes 0.486 ms; round 3, every lane 32 / SEG_LANES consecutive ops per step
+                         // with 16-byte loads: 8 lanes 0.497 ms, 4 lanes 0.432 ms, 2 lanes 0.402 ms, 1 lane 0.411 ms
 #endif
 constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 2 : 32 / SEG_LANES;
 // It is also the boundary check of the device path (the kernels index with what the batch says): bit 0 of *err = an index
@@ -105,14 +106,17 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     // that "is the previous op an alignment match too" -- the merged op count the lane-per-item kernel sizes its LDS regions by --
     // needs one shuffle per step: the last op of the lane below, or of the group's last lane in the previous step.
     uint32_t pairs = 0, carry = 0;
-    constexpr uint32_t OPL = 8;
+    constexpr uint32_t OPL = 32 / SEG_LANES;  // (a multiple of 4: 16-byte loads)
     const uint32_t n_ops_all = bt.n_segs ? bt.seg_cigar_off[bt.n_segs] : 0u;
     for (uint32_t base = c0; base < c1; base += SEG_LANES * OPL) {
         const uint32_t my = base + OPL * sub;
         uint32_t c[OPL];
         if (my < c1 && my + OPL <= n_ops_all) {  // (ops behind the segment's end belong to the next segment: masked by `have` below)
-            const Ops4 a = *(const Ops4 *)(bt.cigar + my), b = *(const Ops4 *)(bt.cigar + my + 4);
-            c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+#pragma unroll
+            for (uint32_t q = 0; q < OPL / 4; ++q) {
+                const Ops4 a = *(const Ops4 *)(bt.cigar + my + 4 * q);
+                c[4 * q] = a.x, c[4 * q + 1] = a.y, c[4 * q + 2] = a.z, c[4 * q + 3] = a.w;
+            }
         } else {
 #pragma unroll
             for (uint32_t u = 0; u < OPL; ++u) c[u] = (my + u < c1) ? bt.cigar[my + u] : 0xfu;  // (15: no op code, counted nowhere below)
