@@ -211,7 +211,7 @@ typedef struct plo_timing {
     uint64_t n_in_ops;   /* input CIGAR ops over all items                                          */
     uint64_t n_out_ops;  /* output CIGAR ops                                                        */
     uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device */
-    float lanes_ms;      /* always 0 (the lane-per-item kernel of API version 1 was removed)         */
+    float lanes_ms;      /* the lane-per-item kernel (k_lift_lanes: items whose working region fits an LDS share)  */
     float retry_ms;      /* items of tiles that overflowed their LDS slice, re-run one per wave       */
     uint32_t n_lane_items;
     uint32_t n_retry_items;
@@ -222,6 +222,9 @@ typedef struct plo_timing {
     uint32_t tile_cap;     /* geometry of the tile kernel for this batch: elements per LDS slice (256: the variant with the
                               capacity compiled in, k_lift_tiles_c256) and window of item weights per tile        */
     uint32_t tile_window;
+    float heavy_lanes_ms;        /* the lane-per-item kernel over heavy items (k_lift_lanes_g: regions in global scratch
+                                    behind LDS windows); lift_ms / mid_ms are 0 then                                   */
+    uint32_t n_heavy_lane_items;
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

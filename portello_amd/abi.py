@@ -133,6 +133,8 @@ class PloTiming(C.Structure):
         ("miss_ms", C.c_float),
         ("tile_cap", C.c_uint32),
         ("tile_window", C.c_uint32),
+        ("heavy_lanes_ms", C.c_float),
+        ("n_heavy_lane_items", C.c_uint32),
     ]
 
 

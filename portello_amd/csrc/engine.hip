@@ -565,8 +565,12 @@ constexpr int LANE_WAVES = 4;
 #ifndef PLO_LANE_WPE_MIN
 #define PLO_LANE_WPE_MIN PLO_LANE_WPE
 #endif
+#ifndef PLO_LANE_G_WPE
+#define PLO_LANE_G_WPE 2  // k_lift_lanes_g: the windows' bookkeeping on top of 168 registers would spill; 12 KB of LDS per wave anyway
+#endif
+constexpr int LANE_G_WAVES = 4;
 template <bool SP>
-PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, int capw) {
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
@@ -579,33 +583,41 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
         ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
+    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t n1, int capw) {
-    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, capw);
+                                                                                                   uint32_t n1, uint32_t gs, int capw) {
+    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                      uint32_t n1, int capw) {
-    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, capw);
+                                                                                                      uint32_t n1, uint32_t gs, int capw) {
+    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 
 // The same lane-per-item code for HEAVY items (too heavy for an LDS region: indel-dense or very long CIGARs), every lane's region in
-// wave-private global scratch; `per` items per wave.
+// wave-private global scratch and reached through per-lane LDS windows (lane_core.hpp, LaneWin); `per` items per wave.
+// A wave runs as long as its longest item, at the pace of a lone dependent instruction chain (about 3.5 us per op of the item on
+// the stress workload, 2.8 us with a SIMD to itself): the kernel's time hardly depends on the number of items until every
+// resident wave has its 64, and the workgroup-per-item kernel is the faster one for fewer than some 70 k heavy items
+// (lane_heavy_min).  Measured and dropped: the heavy classes sorted by weight (k_chunk_sort's idea without its windows), long
+// groups paired with short ones on a SIMD -- 7 % slower at 100 k reads, 11 % at 250 k: neighbours in the batch share reference and
+// block-map lines, and a group of items from all over the genome gives that up.
 template <bool SP>
 PLO_DEV void lift_lanes_g_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t lo, uint32_t mid, uint32_t hi,
                                  uint32_t per, uint32_t *scratch, int stride) {
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t k = threadIdx.x >> 6, n_waves = gridDim.x * LANE_G_WAVES;
+    const uint32_t wave = blockIdx.x * LANE_G_WAVES + k;
+    __shared__ uint32_t windows[LANE_G_WAVES][64 * LANE_WIN_DWORDS];
     WaveCtx ctx;
-    lane_heavy_persistent<SP>(ix, bt, wk, stages, wave, n_waves, lo, mid, hi, per, scratch + (size_t)wave * (size_t)per * (size_t)stride, stride, ctx);
+    lane_heavy_persistent<SP>(ix, bt, wk, stages, wave, n_waves, lo, mid, hi, per, windows[k], scratch + (size_t)wave * (size_t)per * (size_t)stride, stride, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_g(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_G_WPE, PLO_LANE_G_WPE))) void k_lift_lanes_g(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
                                                                                                      uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
     lift_lanes_g_kernel<false>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
 }
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_g_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_G_WPE, PLO_LANE_G_WPE))) void k_lift_lanes_g_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
                                                                                                         uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
     lift_lanes_g_kernel<true>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
 }
@@ -993,11 +1005,10 @@ struct plo_ctx {
     int lane_capw = 3072;
     bool lane_sort = true;  // k_chunk_sort before the lane kernel
     int lane_sort_window = LANE_SORT_WINDOW;
-    // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch) for batches with at least that many
-    // heavy items; < 0: never (default).  Measured on the stress workload, 100 k reads: 15.9 ms at 64 items per wave (21.5 at 16)
-    // against 13.1 ms of the workgroup-per-item kernel -- every region access is an L2 round trip and 1 600 groups leave the chip
-    // at 1.5 waves per SIMD to hide it; kept as an option (PLO_LANE_HEAVY_MIN) for batches of millions of heavy items.
-    int lane_heavy_min = -1;
+    // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows) for batches with at
+    // least that many heavy items; < 0: never.  Stress workload, heavy items -> k_lift_mid / k_lift_lanes_g: 20 k 2.8 / 7.9 ms,
+    // 60 k 8.0 / 9.6 ms, 80 k 10.5 / 9.6 ms, 100 k 13.1 / 9.9 ms, 250 k 32.5 / 19.7 ms.
+    int lane_heavy_min = 70000;
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1612,48 +1623,51 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
                                    (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
             }
-            const uint32_t groups = ((n0 + 63u) >> 6) + ((n1 + 63u) >> 6);
             const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
             int occ = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lds) != hipSuccess || occ < 1)
                 occ = 1;
+            // items per group: 64, fewer when that leaves resident waves without a group (small batches; the few light items of an
+            // indel-dense batch, whose regions would also take a wave's LDS slice several rounds at 64 a group)
+            uint32_t gs = 64;
+            {
+                const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
+                while (gs > 8u && (n0 + gs / 2 - 1) / (gs / 2) + (n1 + gs / 2 - 1) / (gs / 2) <= slots) gs >>= 1;
+                if (const char *e = getenv("PLO_LANE_GROUP")) gs = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
+            }
+            const uint32_t groups = (n0 + gs - 1) / gs + (n1 + gs - 1) / gs;
             uint32_t nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
             nblk = (nblk + 7u) & ~7u;
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
-            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, c->lane_capw);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
+            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
         if (heavy_lanes) {
             // as many items per wave as it takes to give every resident wave a group (at least 8, at most 64 lanes at work)
-            int occ = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_g_sp : (const void *)k_lift_lanes_g, LANE_WAVES * 64, 0) != hipSuccess || occ < 1)
-                occ = 1;
+            const int occ = PLO_LANE_G_WPE;  // (4 waves a workgroup, one per SIMD)
             const uint32_t n_heavy = n_items - n_small, n2 = h_cls[2], n3 = n_heavy - n2;
-            const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
+            const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_G_WAVES;
             uint32_t per = std::min(64u, std::max(8u, (n_heavy + slots - 1) / slots));
             if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
             const uint32_t groups = (n2 + per - 1) / per + (n3 + per - 1) / per;
-            const int stride = (int)((max_nin + LANE_SLACK + 31u) & ~31u);  // (regions start on 128-byte lines)
-            uint32_t nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
+            // (regions start on 128-byte lines; 64: room for the liftover's gap, lane_region_gap -- an item that needs more is retried)
+            const int stride = (int)((max_nin + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+            uint32_t nblk = std::min<uint32_t>((groups + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ));
             const unsigned long long per_wave = (unsigned long long)per * (unsigned long long)stride * 4ull;
-            nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_WAVES)));
-            HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_WAVES * nblk)));
+            nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_G_WAVES)));
+            HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_G_WAVES * nblk)));
             if (getenv("PLO_DEBUG_GEOMETRY"))
                 fprintf(stderr, "[plo] heavy items through the lane-per-item code: %u items, %u per wave, %u workgroups, regions of %d dwords, %.1f MB scratch\n", n_heavy, per,
-                        nblk, stride, per_wave * LANE_WAVES * nblk / 1e6);
-            if (!n_small) {
-                wk.slab_pre = 1u;
-                wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
-            } else {
-                wk.slab_pre = 0u;  // (the light items' waves own the first slabs)
-            }
-            PLO_STAT_RANGE(nblk * LANE_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
-            else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+                        nblk, stride, per_wave * LANE_G_WAVES * nblk / 1e6);
+            wk.slab_pre = 0u;  // (a group's output is a slab of its own; the light items' waves own the first slabs, if any)
+            if (!n_small) wk.slab_offset = 0ull;
+            PLO_STAT_RANGE(nblk * LANE_G_WAVES);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+            else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
         } else if (n_items > n_small) {
@@ -1846,6 +1860,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.tile_window = (uint32_t)c->window;
     c->timing.miss_ms = miss_ms;
     c->timing.n_lane_items = n_small;
+    c->timing.n_heavy_lane_items = heavy_lanes ? n_items - n_small : 0u;
     c->timing.n_retry_items = n_retry;
     if (c->adaptive && c->cap == TILE_CAP_SMALL && n_retry > n_items / 200) c->small_window_tight = true;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
@@ -2207,7 +2222,8 @@ plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev_mid ? c->ev[6] : c->ev[5], c->ev[3]);
     c->timing.enumerate_ms = a;
     c->timing.lanes_ms = l;
-    c->timing.lift_ms = b;
+    c->timing.lift_ms = c->timing.n_heavy_lane_items ? 0.0f : b;
+    c->timing.heavy_lanes_ms = c->timing.n_heavy_lane_items ? b : 0.0f;
     c->timing.retry_ms = r;
     c->timing.mid_ms = md;
     c->timing.big_ms = g;

@@ -81,8 +81,11 @@ PLO_DEV bool b_read_cons(int t) { return ((0x1B3u >> t) & 1u) != 0u; }  // M I S
 // Flags are `bool`s combined with & | ^ (no short-circuit: the code must stay one basic block).
 // `wlim`: first index that must not be written (the reader's position when the region is used in place).  PAD: the stream may
 // hold Pad ops (absent from compress_cigar's summing pattern, :210-212: a Pad following a Pad adds nothing).
-template <bool PAD = true>
+// ST: distance of neighbouring ops in o.R (1; 64: the write window of a heavy item, whose writer stops for good at the first op
+// that does not fit -- its window indices mean nothing from there).
+template <bool PAD = true, int ST = 1>
 PLO_DEV void lane_push(LaneOut &o, bool on, int t, int L, int wlim) {
+    if constexpr (ST != 1) on = on & !o.ovf;
     const bool lead = on & !o.seen_m;
     const bool drop_d = lead & (t == OP_D);
     o.lead_shift += drop_d ? L : 0;
@@ -93,7 +96,7 @@ PLO_DEV void lane_push(LaneOut &o, bool on, int t, int L, int wlim) {
     const bool same = live & (t == at);
     const bool flush = live & !same & (o.acc >= 16u);
     const bool ok = o.no < wlim;
-    if (flush & ok) o.R[o.no] = o.acc;
+    if (flush & ok) o.R[o.no * ST] = o.acc;
     o.ovf = o.ovf | (flush & !ok);
     o.pairs = o.pairs | (flush & b_is_indel(at) & b_is_indel(t));
     o.no += flush ? 1 : 0;
@@ -303,16 +306,99 @@ PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, i
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// Heavy items (k_lift_lanes_g): the lane's region lies in wave-private GLOBAL memory, and the stages reach it through two small
+// LDS windows per lane -- every stage reads its input front to back and writes its output front to back, so a read window
+// [rbase, rbase + LANE_RW) and a write window [wbase, wbase + LANE_WW) of region indices are all it needs.  The windows of all
+// lanes are refilled / flushed together (16 bytes per global access and lane) whenever some lane runs out: every LANE_RW
+// iterations at most.  (Reaching into the global region op by op instead -- the first version of that kernel -- makes every access
+// an L2 round trip on the loop's dependence chain: 15.9 ms against 13.1 ms of the workgroup-per-item kernel on the stress workload.)
+// Window element j of lane l is word j * 64 + l of the wave's LDS: whatever positions the lanes are at, lane l uses bank l.  The
+// windows are lane-private: no barrier between a lane's writes and its reads.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int LANE_RW = 20, LANE_WW = 28;  // dwords per lane; LANE_RW a multiple of 4
+constexpr int LANE_WIN_DWORDS = LANE_RW + LANE_WW;
+constexpr int LANE_WIN_MARGIN = 8;            // most ops a lane writes between two looks at the write window's fill
+constexpr int LANE_REGION_PAD = LANE_RW + 4;  // behind a region: a refill at its last op reads LANE_RW dwords
+struct LaneWin {
+    uint32_t *G = nullptr;                  // index 0 of the lane's region (global memory)
+    uint32_t *rw = nullptr, *ww = nullptr;  // element 0 of the lane's windows (LDS; element j at [j * 64])
+    int rbase = 0, wbase = 0;               // region index of element 0
+};
+PLO_DEV void win_fill(LaneWin &w, bool on, int idx) {
+    if (on) {
+        w.rbase = idx;
+        Ops4 v[LANE_RW / 4];
+#pragma unroll
+        for (int q = 0; q < LANE_RW / 4; ++q) v[q] = *(const PLO_GLOBAL Ops4 *)(w.G + idx + 4 * q);
+#pragma unroll
+        for (int q = 0; q < LANE_RW / 4; ++q) {
+            w.rw[(4 * q) * 64] = v[q].x;
+            w.rw[(4 * q + 1) * 64] = v[q].y;
+            w.rw[(4 * q + 2) * 64] = v[q].z;
+            w.rw[(4 * q + 3) * 64] = v[q].w;
+        }
+    }
+}
+// the same from the batch's input CIGAR `src` (n_in ops), walked backwards for reverse-mapped contig segments: window element j =
+// op idx + j in walking order.  Heavy items whose first stage can read the input as it is skip the LOAD pass.
+PLO_DEV void win_fill_input(LaneWin &w, bool on, int idx, const uint32_t *src, int n_in, bool rev) {
+    if (on) {
+        w.rbase = idx;
+        uint32_t a[LANE_RW];
+#pragma unroll
+        for (int q = 0; q < LANE_RW / 4; ++q) {
+            const int kq = idx + 4 * q;
+            if (kq + 3 < n_in) {  // four neighbours in memory
+                const Ops4 v = *(const PLO_GLOBAL Ops4 *)(src + (rev ? n_in - 4 - kq : kq));
+                a[4 * q] = rev ? v.w : v.x;
+                a[4 * q + 1] = rev ? v.z : v.y;
+                a[4 * q + 2] = rev ? v.y : v.z;
+                a[4 * q + 3] = rev ? v.x : v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[4 * q + j] = kq + j < n_in ? src[rev ? n_in - 1 - kq - j : kq + j] : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LANE_RW; ++j) w.rw[j * 64] = a[j];
+    }
+}
+// region indices [wbase, end) are in the window: out with them
+PLO_DEV void win_flush(LaneWin &w, bool on, int end) {
+    if (on) {
+        const int cnt = end - w.wbase;
+        uint32_t *const dst = w.G + w.wbase;
+#pragma unroll
+        for (int q = 0; q < LANE_WW / 4; ++q) {
+            Ops4 v;
+            v.x = w.ww[(4 * q) * 64];
+            v.y = w.ww[(4 * q + 1) * 64];
+            v.z = w.ww[(4 * q + 2) * 64];
+            v.w = w.ww[(4 * q + 3) * 64];
+            if (4 * q + 3 < cnt) *(PLO_GLOBAL Ops4 *)(dst + 4 * q) = v;
+        }
+        const int n4 = cnt & ~3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (n4 + j < cnt) dst[n4 + j] = w.ww[(n4 + j) * 64];
+        w.wbase = end;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // One group of up to 64 items, lane t <-> item t.  `lds`: the wave's slice of capw dwords, shared out among the items by their
-// weights (fixed_stride == 0: LDS, light items) -- or, fixed_stride > 0, one region of that many dwords per lane in whatever memory
-// `lds` points to (heavy items: wave-private global scratch, k_lift_lanes_g).
+// weights (light items) -- or, WIN, one region of fixed_stride dwords per lane in wave-private global scratch, reached through LDS
+// windows (heavy items, k_lift_lanes_g).
 // (Measured and dropped: the group's CIGAR span copied into LDS with coalesced loads and picked apart there, results gathered in
 // LDS and stored coalesced -- 37 % slower than every lane reading / writing its own 16 bytes: the extra LDS round trips cost more
 // than the scattered requests.)
 // -------------------------------------------------------------------------------------------------------------------
-template <bool SP>
+template <bool SP, bool WIN = false>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
-                       uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre) {
+                       uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre,
+                       uint32_t *greg = nullptr) {
+    // WIN (heavy items): `lds` = 64 x LANE_WIN_DWORDS dwords of LDS for the lanes' windows, `greg` = 64 regions of fixed_stride dwords
+    // in global memory; else: `lds` = the wave's slice of capw dwords, the regions themselves.
     const int lane = wv::lane();
     const bool has = lane < nit;
     const uint32_t g = have_g ? g_pre : (has ? list[item_begin + (uint32_t)lane] : 0u);
@@ -365,7 +451,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
     {
-        const bool defer = has && W > (fixed_stride > 0 ? fixed_stride : capw);
+        const bool defer = has && W > (WIN ? fixed_stride - LANE_REGION_PAD : capw);
         const unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int slot = 0;
@@ -382,10 +468,17 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // ---- rounds: the longest prefix of the pending items whose regions fit the slice (nearly always all of them) ----
     while (wv::ballot(pending) != 0ull) {
         const int wv_ = pending ? W : 0;
-        const int incl = fixed_stride > 0 ? (lane + 1) * fixed_stride : wv::scan_add(wv_);
-        const bool act0 = pending && (fixed_stride > 0 || incl <= capw);
+        const int incl = WIN ? 0 : wv::scan_add(wv_);
+        const bool act0 = pending && (WIN || incl <= capw);
         pending = pending && !act0;
-        uint32_t *const R = lds + (act0 ? incl - (fixed_stride > 0 ? fixed_stride : wv_) : 0);
+        // R: where the stages read / write their ops by region index -- the region itself, or (WIN) re-pointed at a window
+        uint32_t *R = WIN ? nullptr : lds + (act0 ? incl - wv_ : 0);
+        LaneWin win;
+        if constexpr (WIN) {
+            win.G = greg + (size_t)lane * (size_t)fixed_stride;
+            win.rw = lds + lane;
+            win.ww = lds + LANE_RW * 64 + lane;
+        }
         wv::sync();  // the previous round's regions are dead
 
         int status = PLO_ITEM_LIFTED;
@@ -399,6 +492,58 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         bool ovf = false, panic = false;
         unsigned algo = 0;
         int cur_off = 0, n = 0;  // the item's current CIGAR: R[cur_off .. cur_off + n)
+        constexpr int ST = WIN ? 64 : 1;
+        // the op at R[cur_off + k] (lanes without one: some readable word)
+        auto rd_at = [&](int k, bool ok) -> uint32_t {
+            if constexpr (WIN) return win.rw[ok ? (cur_off + k - win.rbase) * 64 : 0];
+            else return R[cur_off + (ok ? k : 0)];
+        };
+        // WIN, stages with the liftover: the first stage of an item -- the shift or the liftover, which take =, X and M ops alike --
+        // reads the batch's input through the window; `ext`: the lane's current CIGAR is still that input (cur_off = 0)
+        const bool direct = WIN && (stages & PLO_STAGE_LIFTOVER) != 0u;
+        bool ext = false;
+        auto rd_fill = [&](bool on, int idx) {
+            if constexpr (WIN) {
+                if (direct) {
+                    if (wv::ballot(on & ext) != 0ull) win_fill_input(win, on & ext, idx, bt.cigar + in_off, n_in, rev);
+                    if (wv::ballot(on & !ext) != 0ull) win_fill(win, on & !ext, idx);
+                } else {
+                    win_fill(win, on, idx);
+                }
+            }
+        };
+        // WIN: before rd_at -- the read windows of the stage's lanes move up to their positions when one of them has left its window
+        auto rd_need = [&](int k, bool ok, bool stage_on) {
+            if constexpr (WIN) {
+                if (wv::ballot(ok & (cur_off + k - win.rbase >= LANE_RW)) != 0ull) rd_fill(stage_on, cur_off + k);
+            }
+        };
+        // a stage's writer, from region index `base`
+        auto wr_open = [&](LaneOut &o, int base) {
+            if constexpr (WIN) {
+                win.wbase = base;
+                o.R = win.ww;
+            } else {
+                o.R = R + base;
+            }
+        };
+        // WIN: before a round of at most LANE_WIN_MARGIN pushes
+        auto wr_room = [&](LaneOut &o, bool on, int base) {
+            if constexpr (WIN) {
+                if (wv::ballot(on & !o.ovf & (base + o.no - win.wbase > LANE_WW - LANE_WIN_MARGIN)) != 0ull) {
+                    win_flush(win, on & !o.ovf, base + o.no);
+                    o.R = win.ww - o.no * 64;
+                }
+            }
+        };
+        // clean_up_cigar_edge_indels' trailing edge + compress: WIN, on the region itself (walks back)
+        auto wr_finish = [&](LaneOut &o, bool on, int base, int wlim) {
+            if constexpr (WIN) {
+                win_flush(win, on & !o.ovf, base + o.no);
+                o.R = win.G + base;
+            }
+            lane_out_finish(o, on, wlim);
+        };
         int pos = pos1;
         ReadSeq rd = item_read_seq<SP>(bt, seq_off, seq_len, flip ? 1 : 0);
         PLO_LT(0)
@@ -410,7 +555,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // shift builder (add_match: match_run += len, emitted as M, cigar_indel_shifter.rs:150-153,136) and the liftover (:102-109
         // turn every match piece into M, compress_cigar :220 merges the pieces of neighbouring ops).  Same result, a third fewer
         // ops to walk -- and the ops of a shifted item then alternate match / cluster, which is what keeps its scans short.
-        {
+        if (direct) {
+            n = act0 ? n_in : 0;
+            ext = act0;
+        } else {
             const bool ld = act0;
             const bool merge = ld & merges;
             const int inb = shift_on ? W - n_ld : gap;
@@ -419,8 +567,19 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             bool has_run = false;
             int w = 0;
             // 16 bytes per load and lane (every lane reads its own CIGAR: four ops per request instead of one), two in flight
+            if constexpr (WIN) win.wbase = inb;
+            auto put = [&](bool on, uint32_t v) {
+                if constexpr (WIN) {
+                    if (on) win.ww[(inb + w - win.wbase) * 64] = v;
+                } else {
+                    if (on) R[inb + w] = v;
+                }
+            };
             for (int k0 = 0; k0 < nmax; k0 += 8) {
                 PLO_LC(10, 1)
+                if constexpr (WIN) {
+                    if (wv::ballot(ld & (inb + w - win.wbase > LANE_WW - 9)) != 0ull) win_flush(win, ld, inb + w);
+                }
                 uint32_t r[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -446,14 +605,15 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     const uint32_t c = r[j];
                     const bool join = merge & have & has_run & b_is_match(op_type(c)) & b_is_match(op_type(run));
                     const bool flush = have & has_run & !join;
-                    if (flush) R[inb + w] = run;
+                    put(flush, run);
                     w += flush ? 1 : 0;
                     run = join ? ((run & ~15u) + (c & ~15u)) | (uint32_t)OP_M : (have ? c : run);
                     has_run = has_run | have;
                 }
             }
-            if (ld & has_run) R[inb + w] = run;
+            put(ld & has_run, run);
             w += (ld & has_run) ? 1 : 0;
+            if constexpr (WIN) win_flush(win, ld, inb + w);
             n = ld ? w : 0;
             cur_off = ld ? inb : 0;
         }
@@ -471,8 +631,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         if (wv::ballot(shift_on) != 0ull) {
             const uint8_t *const sref = (const uint8_t *)(uintptr_t)shift_ref;
             LaneOut o;
-            o.R = R + gap;
+            wr_open(o, gap);
+            rd_fill(shift_on, cur_off);
             const int wl0 = cur_off - gap;  // the writer may use what lies below the reader: index < wl0 + ops consumed
+            const int wl_ext = W - gap;     // ... or, reading the batch's input, all of the region
             int k = 0;
             bool fin = !shift_on;
             int ref_head = pos1, read_head = 0, match = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0;
@@ -482,6 +644,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             PLO_MARK("SHIFT LOOP BEGIN");
             while (wv::ballot(!fin) != 0ull) {
                 PLO_LC(8, 1)
+                wr_room(o, shift_on, gap);
                 // scan to the next event (not consumed)
                 bool stop = fin, ev_other = false, ev_end = false;
                 int ev_t = 0, ev_L = 0;
@@ -489,7 +652,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     PLO_LC(9, 1)
                     const bool act = !stop;
                     const bool have = k < n;
-                    const uint32_t c = R[cur_off + (have ? k : 0)];
+                    rd_need(k, have & shift_on, shift_on);
+                    const uint32_t c = rd_at(k, have & (!WIN | shift_on));
                     const int t = op_type(c), L = op_len(c);
                     const bool indel = have & b_is_indel(t);
                     const bool ism = have & b_is_match(t);
@@ -520,14 +684,14 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 const bool evl = !fin;             // lanes with an event
                 const bool endc = evl & in_blk;    // end_indel (:101-148)
                 const bool flushing = evl & (ev_other | ev_end);
-                const int wl = wl0 + k;
+                const int wl = ext ? wl_ext : wl0 + k;
                 auto resolve = [&](bool on) {  // end_indel's emission for the pending cluster (:132-147)
                     int h = lane_probe_finish(pr, on, sref, shift_ref_len, rd, probes);
                     h = rd.miss ? 0 : h;
                     const int sh = wv::imin(p_match, h);  // actual_shift_len (:132)
-                    lane_push<false>(o, on & (p_match - sh > 0), OP_M, p_match - sh, wl);
-                    lane_push<false>(o, on & (p_ins > 0), OP_I, p_ins, wl);
-                    lane_push<false>(o, on & (p_del > 0), OP_D, p_del, wl);
+                    lane_push<false, ST>(o, on & (p_match - sh > 0), OP_M, p_match - sh, wl);
+                    lane_push<false, ST>(o, on & (p_ins > 0), OP_I, p_ins, wl);
+                    lane_push<false, ST>(o, on & (p_del > 0), OP_D, p_del, wl);
                     match = on ? sh + msince : match;
                     msince = on ? 0 : msince;
                     pend = pend & !on;
@@ -553,10 +717,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (wv::ballot(flushing & pend) == 0ull) break;
                 }
                 if (wv::ballot(flushing) != 0ull) {  // add_other (:155-165); at the end: get_cigar()'s add_other(None) (:54-60)
-                    lane_push<false>(o, flushing & (match > 0), OP_M, match, wl);
+                    lane_push<false, ST>(o, flushing & (match > 0), OP_M, match, wl);
                     match = flushing ? 0 : match;
                     const bool oth = flushing & ev_other;
-                    lane_push<true>(o, oth, ev_t, ev_L, wl + 1);
+                    lane_push<true, ST>(o, oth, ev_t, ev_L, wl + 1);
                     read_head += (oth & b_read_cons(ev_t)) ? ev_L : 0;
                     ref_head += (oth & b_ref_cons(ev_t)) ? ev_L : 0;
                     k += oth ? 1 : 0;
@@ -564,11 +728,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
             }
             PLO_MARK("SHIFT LOOP END");
-            lane_out_finish(o, shift_on, wl0 + n);  // :35-38 clean_up_cigar_edge_indels + compress
+            wr_finish(o, shift_on, gap, ext ? wl_ext : wl0 + n);  // :35-38 clean_up_cigar_edge_indels + compress
             if (shift_on) {
                 algo += 2u * (unsigned)probes;
                 n = o.no;
                 cur_off = gap;
+                ext = false;
                 pos += o.lead_shift;
                 ovf = ovf | o.ovf;
             }
@@ -593,7 +758,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 algo += 16u * (unsigned)(W1 - W0) + 8u * (unsigned)lg;
             }
             LaneOut o;
-            o.R = R;
+            wr_open(o, 0);
+            rd_fill(lo_on, cur_off);
             int k = 0;
             bool in_op = false, ism = false, bvalid = false, has_start = false, has_end = false;
             int t = 0, seg_start = pos, seg_end = 0, block_pos = 0, r2s = 0, r2e = 0;
@@ -616,7 +782,9 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 PLO_LC(7, 1)
                 // the next op, unless one is being cut into pieces
                 const bool fetch = lo_on & !in_op & (k < n);
-                const uint32_t c = R[cur_off + (fetch ? k : 0)];
+                wr_room(o, lo_on, 0);
+                rd_need(k, fetch, lo_on);
+                const uint32_t c = rd_at(k, fetch);
                 k += fetch ? 1 : 0;
                 const int tf = op_type(c), Lf = op_len(c);
                 const bool copy = fetch & (((0x32u >> tf) & 1u) != 0u);  // I S H: :157-160 copied through; Pad (:213) emits nothing
@@ -662,13 +830,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 const bool done = piece & (pend >= seg_end);
                 in_op = in_op & !done;
                 seg_start = done ? seg_end : seg_start;
-                const int wl = cur_off + k;  // ops below R[cur_off + k] have been read
-                lane_push<false>(o, e0, OP_D, d, wl);
-                lane_push<false>(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
+                const int wl = ext ? W : cur_off + k;  // ops below R[cur_off + k] have been read
+                lane_push<false, ST>(o, e0, OP_D, d, wl);
+                lane_push<false, ST>(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
             }
             PLO_MARK("LIFTOVER LOOP END");
             PLO_LT(3)
-            lane_out_finish(o, lo_on, cur_off + n);  // :219-220
+            wr_finish(o, lo_on, 0, ext ? W : cur_off + n);  // :219-220
             if (lo_on) {
                 ovf = ovf | o.ovf;
                 if (!has_start) {  // :218 ref2_start_pos.map(...) on None
@@ -677,6 +845,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 } else {
                     n = o.no;
                     cur_off = 0;
+                    ext = false;
                     pos = r2s + o.lead_shift;  // :221
                 }
                 pairs = o.pairs;
@@ -706,14 +875,20 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
                 const uint8_t *const cref = (const uint8_t *)(uintptr_t)chrom_ref;
                 LaneOut o;
-                o.R = R;
+                wr_open(o, 0);
+                rd_fill(s_on, cur_off);
                 int ref_head = pos, read_head = 0, del = 0, ins = 0, blk_ref = 0, blk_read = 0, cmp = 0;
                 bool in_blk = false, spanic = false, zero_m = false;
+                // (Measured and dropped: the event-aligned walk of the shift stage here -- every lane scanning to the end of its next
+                // cluster, end_indel for all of them together.  5 % slower on the indel-dense stress workload, 2.6 % on wgs30x: the
+                // clusters that need base comparisons are few, and the rest of end_indel is cheaper than the second loop level.)
                 const int nmax = wv::reduce_max(s_on ? n : 0);
                 for (int k = 0; k <= nmax; ++k) {
                     const bool valid = s_on & (k < n);
                     const bool atend = s_on & (k == n);
-                    const uint32_t c = R[cur_off + (valid ? k : 0)];
+                    wr_room(o, s_on, 0);
+                    rd_need(k, valid, s_on);
+                    const uint32_t c = rd_at(k, valid);
                     const int t = op_type(c), L = op_len(c);
                     const bool indel = valid & b_is_indel(t);
                     const int wl = cur_off + wv::imin(k + 1, n);
@@ -746,11 +921,19 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                                 }
                             }
                         }
+                        // :101-104 M(pre) I D M(post).  A cluster of one kind (most) emits that one op: the M ops and the second
+                        // kind only where some lane has them
                         const bool emit_id = endc & !one_one;
-                        lane_push<false>(o, endc & (pre > 0), OP_M, pre, wl);  // :101-104
-                        lane_push<false>(o, emit_id & (ins > 0), OP_I, ins, wl);
-                        lane_push<false>(o, emit_id & (del > 0), OP_D, del, wl);
-                        lane_push<false>(o, endc & (post > 0), OP_M, post, wl);
+                        const bool both = wv::ballot(endc & !single) != 0ull;
+                        if (both) lane_push<false, ST>(o, endc & (pre > 0), OP_M, pre, wl);
+                        {
+                            const bool first_d = emit_id & (ins == 0);  // (then the one op is the D, if anything)
+                            lane_push<false, ST>(o, emit_id & ((first_d ? del : ins) > 0), first_d ? (int)OP_D : (int)OP_I, first_d ? del : ins, wl);
+                            if (both) {
+                                lane_push<false, ST>(o, emit_id & !first_d & (del > 0), OP_D, del, wl);
+                                lane_push<false, ST>(o, endc & (post > 0), OP_M, post, wl);
+                            }
+                        }
                         del = endc ? 0 : del;
                         ins = endc ? 0 : ins;
                         in_blk = in_blk & !endc;
@@ -763,11 +946,11 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     ins += (indel & (t == OP_I)) ? L : 0;
                     const bool cp = valid & !indel;
                     zero_m = zero_m | (cp & b_is_match(t) & (L == 0));  // an edge mark the writer would not see (LaneOut)
-                    lane_push<true>(o, cp, t, L, wl);  // :144-147
+                    lane_push<true, ST>(o, cp, t, L, wl);  // :144-147
                     read_head += (valid & b_read_cons(t)) ? L : 0;
                     ref_head += (valid & b_ref_cons(t)) ? L : 0;
                 }
-                lane_out_finish(o, s_on, cur_off + n);  // :153-154
+                wr_finish(o, s_on, 0, cur_off + n);  // :153-154
                 if (s_on) {
                     algo += 2u * (unsigned)cmp;
                     ovf = ovf | o.ovf | zero_m;
@@ -819,7 +1002,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         {
             const int ocmax = wv::reduce_max(fits ? oc : 0);
             uint32_t *const dst = wk.out_cigar + gbase + (unsigned long long)oS;
-            const uint32_t *const srcp = R + cur_off;
+            const uint32_t *const srcp = (WIN ? win.G : R) + cur_off;
             for (int k = 0; k < ocmax; k += 4) {  // 16 bytes per store and lane
                 if (fits && k + 3 < oc) {
                     Ops4 v;
@@ -853,23 +1036,25 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 }
 
 // Persistent wave over the groups of the lane classes: class c (0: no shift stage, 1: shift stage) occupies positions
-// [c_begin, c_end) of the class order and is cut into groups of 64 from its start, so that groups are strand-homogeneous.
+// [c_begin, c_end) of the class order and is cut into groups of `gs` (64; 32, 16 or 8 when the batch has too few items to give
+// every resident wave a group of 64: a group runs as long as its longest item whatever its size, so few items are better
+// spread over many waves) from its start, so that groups are strand-homogeneous.
 // Group indices: class 0 first.  The item indices of the next group are fetched one group ahead.
 // (Measured and dropped: the class order sorted by item weight inside chunks of 4 .. 32 groups, so that a group does not wait for
 // its one longest CIGAR -- a quarter fewer loop trips per group, but 5-15 % slower overall: neighbours in the batch share
 // descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.)
 template <bool SP>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
-                                   uint32_t n0, uint32_t n1, uint32_t *lds, int capw, WaveCtx &ctx) {
+                                   uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
-    const uint32_t t0 = (n0 + 63u) >> 6, t1 = (n1 + 63u) >> 6;
+    const uint32_t t0 = (n0 + gs - 1u) / gs, t1 = (n1 + gs - 1u) / gs;
     auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
         if (t < t0) {
-            lo = t * 64u;
-            hi = lo + 64u < n0 ? lo + 64u : n0;
+            lo = t * gs;
+            hi = lo + gs < n0 ? lo + gs : n0;
         } else {
-            lo = n0 + (t - t0) * 64u;
-            hi = lo + 64u < n0 + n1 ? lo + 64u : n0 + n1;
+            lo = n0 + (t - t0) * gs;
+            hi = lo + gs < n0 + n1 ? lo + gs : n0 + n1;
         }
     };
     // round j: wave w takes group j * stride + (w + j) % stride -- the waves rotate through the slots from round to round, so that
@@ -903,16 +1088,16 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
 
 // Persistent wave over the HEAVY items (classes 2 and 3: positions [lo, mid) and [mid, hi) of the class order), `per` items per
 // group (<= 64: few heavy items are spread over more waves, at fewer lanes each, so that they still fill the chip), every lane with
-// a region of `stride` dwords in the wave's global scratch.
+// a region of `stride` dwords in the wave's global scratch `regions` and its windows in `windows` (64 x LANE_WIN_DWORDS dwords of LDS).
 template <bool SP>
 PLO_DEV void lane_heavy_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t step,
-                                   uint32_t lo, uint32_t mid, uint32_t hi, uint32_t per, uint32_t *regions, int stride, WaveCtx &ctx) {
+                                   uint32_t lo, uint32_t mid, uint32_t hi, uint32_t per, uint32_t *windows, uint32_t *regions, int stride, WaveCtx &ctx) {
     const uint32_t t0 = (mid - lo + per - 1) / per, t1 = (hi - mid + per - 1) / per;
     for (uint32_t t = first; t < t0 + t1; t += step) {
         const bool c1 = t >= t0;
         const uint32_t b = c1 ? mid + (t - t0) * per : lo + t * per, e = c1 ? hi : mid;
         const uint32_t n = e - b < per ? e - b : per;
-        lane_tile<SP>(ix, bt, wk, stages, b, (int)n, regions, 0x7fffffff, stride, ctx, wk.perm, false, 0u);
+        lane_tile<SP, true>(ix, bt, wk, stages, b, (int)n, windows, 0x7fffffff, stride, ctx, wk.perm, false, 0u, regions);
         wv::sync();
     }
 }

@@ -198,29 +198,31 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         if (heavy_lanes) {
             uint32_t max_w = 0;
             for (uint32_t i = 0; i < n_items; ++i) max_w = std::max(max_w, item_nin[i]);
-            const int stride = (int)((max_w + LANE_SLACK + 31u) & ~31u);
-            std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu);
+            const int stride = (int)((max_w + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+            std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
                 w.run([&]() {
                     WaveCtx ctx;
-                    if (sp) lane_heavy_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, regions.data(), stride, ctx);
-                    else lane_heavy_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, regions.data(), stride, ctx);
+                    if (sp) lane_heavy_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, windows.data(), regions.data(), stride, ctx);
+                    else lane_heavy_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, n_small, n_small + r2[n_items], n_items, (uint32_t)lane_heavy_per, windows.data(), regions.data(), stride, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();
             }
         }
-        if (n_small) {  // k_lift_lanes: persistent waves over the groups of 64 of the two lane classes
+        // (items per group as the host picks them for small batches: 64 without an order seed, else 64 / 32 / 16 / 8 by the seed)
+        const uint32_t lane_group = order_seed ? 64u >> (order_seed % 4u) : 64u;
+        if (n_small) {  // k_lift_lanes: persistent waves over the groups of the two lane classes
             std::vector<uint32_t> llds((size_t)lane_capw + 16, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
                 w.run([&]() {
                     WaveCtx ctx;
-                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
-                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], llds.data(), lane_capw, ctx);
+                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
+                    else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });
                 sum_stats();

@@ -43,7 +43,7 @@ def test_version_string(lib_path):
 def test_ctypes_struct_layout_matches_header():
     # sizes implied by the header on LP64
     assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8
-    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8 + 4 * 4 + 2 * 4 + 2 * 4 + 2 * 4
+    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8 + 4 * 4 + 2 * 4 + 2 * 4 + 2 * 4 + 2 * 4
     assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8 + 2 * 8
     assert C.sizeof(abi.PloIndexDesc) == 8 + 2 * 8 + 8 + 8 * 8 + 8 + 3 * 8 + 8
 

@@ -168,7 +168,7 @@ def test_lane_path_small_slices_rounds_and_overflow(oracle):
     w = synth.generate(synth.config("tiny", n_reads=120, seed=132, split_read_frac=0.2, read_len_mean=2500, read_len_sd=900))
     ix, b = w.index_data(), w.batch_data()
     ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1)
-    for max_w, capw, seed in ((4096, 600, 0), (4096, 96, 77), (40, 3072, 0), (4096, 3072, 4711)):
+    for max_w, capw, seed in ((4096, 600, 0), (4096, 96, 77), (40, 3072, 0), (4096, 3072, 4711), (4096, 3072, 6)):
         rc, res, cnt = emu_lib.liftover_batch(ix, b, lane_max_w=max_w, lane_capw=capw, order_seed=seed)
         assert rc == 0
         _assert_same(ref, res)

@@ -36,6 +36,11 @@ def test_fuzz_emulated_device_algorithm(oracle, seed):
                                                   lane_capw=1024 if seed % 2 else 160)
             assert rc == 0 and cnt[23] > 0
             _diff(ref, got, b, f"lane path: seed {seed} alpha {alpha} stages {stages}")
+            # ... and with nearly every item in the heavy classes: regions in global scratch behind LDS windows (k_lift_lanes_g)
+            rc, got, cnt = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096, lane_max_w=12,
+                                                  lane_capw=1024, lane_heavy_per=(64, 5)[seed % 2])
+            assert rc == 0 and cnt[23] < got.n_items
+            _diff(ref, got, b, f"heavy lane path: seed {seed} alpha {alpha} stages {stages}")
 
 
 @pytest.mark.gpu

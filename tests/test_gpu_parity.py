@@ -137,6 +137,26 @@ def test_synthetic_indel_dense_large_item_kernels(oracle, monkeypatch, mid):
     eng_ix.close()
 
 
+@pytest.mark.parametrize("per", ["64", "7"])
+def test_synthetic_indel_dense_heavy_items_lane_per_item(oracle, monkeypatch, per):
+    """heavy items through the lane-per-item code (k_lift_lanes_g): regions in wave-private global scratch behind per-lane LDS
+    windows; every stage subset that changes what the windows carry"""
+    monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
+    monkeypatch.setenv("PLO_LANE_HEAVY_PER", per)
+    monkeypatch.setenv("PLO_LANE_MAX_W", "150")
+    w = _indel_dense_workload()
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    for stages in (abi.STAGES_ALL, abi.STAGE_LSHIFT, abi.STAGE_STRAND | abi.STAGE_LIFTOVER, abi.STAGE_STRAND):
+        got = eng.liftover_batch(b, stages)
+        t = eng.timing()
+        assert t.n_mid_items == 0 and t.n_big_items <= 2
+        _assert_same(oracle.liftover_batch(ix, b, stages, 4), got, f"heavy lanes, stages {stages}")
+    eng.close()
+    eng_ix.close()
+
+
 def test_synthetic_indel_dense_adaptive_geometry(oracle):
     """default: the routing threshold / LDS slice follow the batch's weight distribution, the same items stay in tiles"""
     w = _indel_dense_workload()
@@ -286,7 +306,8 @@ def test_full_size_wgs30x(oracle):
 
 def test_full_size_stress(oracle):
     """BASELINE configs[4] read profile (20 kb, 5 % indel-dense, ~2 000 ops per read) on the wgs30x contigs: every item is
-    far heavier than a shared tile holds, so this is the test of the workgroup-per-item kernel"""
+    far heavier than a shared tile holds, so this is the test of the workgroup-per-item kernel (60 k heavy items: fewer than
+    the lane-per-item kernel for heavy items asks for)"""
     _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
 
 
@@ -307,7 +328,7 @@ def test_full_size_stress_2m_reads_streamed(oracle):
     index = api.Index(first.index_data_device())
     ixd = first.index_data()
     runner = stream.StreamRunner(index, dev, 2)
-    done = {"reads": 0, "items": 0, "lifted": 0, "cmp": 0, "mid": 0}
+    done = {"reads": 0, "items": 0, "lifted": 0, "cmp": 0, "mid": 0, "heavy_lanes": 0}
     lock = __import__("threading").Lock()
     for pair in range(n_total // chunk // 2):  # two chunks resident at a time, one per context
         ws = [first if k == 0 else synth.generate(synth.config("stress", n_reads=chunk, seed=base.seed + 7919 * k), device=dev, reuse=first)
@@ -325,6 +346,7 @@ def test_full_size_stress_2m_reads_streamed(oracle):
                 done["lifted"] += nl
                 done["cmp"] += n_cmp
                 done["mid"] += int(eng.timing().n_mid_items)
+                done["heavy_lanes"] += int(eng.timing().n_heavy_lane_items)
                 done["reads"] += ws[k].n_reads
 
         runner.run([d.desc() for d in dbs], consume=consume)
@@ -332,7 +354,10 @@ def test_full_size_stress_2m_reads_streamed(oracle):
     runner.close()
     index.close()
     _dump("full_size_stress_2m_streamed.json", done)
-    assert done["reads"] == n_total and done["items"] > n_total and done["cmp"] > 1000 and done["mid"] > 0.9 * n_total
+    assert done["reads"] == n_total and done["items"] > n_total and done["cmp"] > 1000
+    # (250 k heavy items a batch: the lane-per-item kernel over global regions, k_lift_lanes_g, takes them -- test_full_size_stress,
+    # 60 k reads, is below its threshold and runs the workgroup-per-item kernel)
+    assert done["mid"] == 0 and done["heavy_lanes"] > 0.9 * n_total
 
 
 def test_geometry_sweep(oracle):
