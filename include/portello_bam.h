@@ -119,6 +119,15 @@ typedef struct plo_record_buf {
 plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *lift, const plo_records_params *params,
                              plo_record_buf *out);
 
+/* The same records from a batch that was finished on the device: `fin` and `sa` are HOST copies of what
+ * plo_finish_batch_dev and plo_sa_segments_dev returned for this window's batch (every array; `sa` may be NULL, the SA
+ * text is then written here).  Flags, bin, the primary record, reverse_alignment_seq_and_qual's bases and qualities
+ * (src/read_alignment_scanner.rs:125-133) and get_sa_tag_segment's text (:292-301) are taken from there and copied into
+ * place; this call lays out the records, cuts the aux fields and writes PS / ZM.  Byte-identical to plo_records_build.
+ * The window's batch must have been the dense one (plo_bam_window_batch): the device needs every base to reverse them. */
+plo_status plo_records_build_finished(plo_bam_window *w, const plo_batch_out *lift, const plo_finish_out *fin,
+                                      const plo_sa_out *sa, const plo_records_params *params, plo_record_buf *out);
+
 /* Header of the output files (get_alignment_file_header :35-59): @HD VN:1.6 SO:unsorted, one @SQ per chromosome,
    @PG PN/ID/VN/CL.  Returns a malloc'ed NUL-terminated text (free with plo_bam_free_text). */
 char *plo_bam_output_header(uint32_t n_ref, const char *const *ref_names, const uint32_t *ref_lens, const char *program_name,

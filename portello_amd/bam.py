@@ -60,6 +60,9 @@ def lib():
         L.plo_sparse_seq_pack.argtypes = [C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, vp, C.c_uint64, vp, C.POINTER(abi.PloBatchIn)]
         L.plo_records_build.restype = C.c_int
         L.plo_records_build.argtypes = [vp, C.POINTER(abi.PloBatchOut), C.POINTER(PloRecordsParams), C.POINTER(PloRecordBuf)]
+        L.plo_records_build_finished.restype = C.c_int
+        L.plo_records_build_finished.argtypes = [vp, C.POINTER(abi.PloBatchOut), C.POINTER(abi.PloFinishOut), C.POINTER(abi.PloSaOut),
+                                                 C.POINTER(PloRecordsParams), C.POINTER(PloRecordBuf)]
         L.plo_bam_output_header.restype = vp
         L.plo_bam_output_header.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_char_p, C.c_char_p, C.c_char_p]
         L.plo_bam_free_text.restype = None
@@ -165,6 +168,17 @@ class Window:
         pr = PloRecordsParams(C.pointer(index_desc), cn, rn, 1 if is_target_region else 0, n_threads)
         rb = PloRecordBuf()
         _check(lib().plo_records_build(self.handle, C.byref(lift_out), C.byref(pr), C.byref(rb)), "plo_records_build")
+        return rb
+
+    def build_records_finished_raw(self, lift_out, fin_out, sa_out, index_desc, contig_names, ref_names, is_target_region=False,
+                                   n_threads=0) -> PloRecordBuf:
+        """the records from a batch finished on the device (plo_records_build_finished): `lift_out`, `fin_out`, `sa_out` are HOST
+        copies of plo_liftover_batch_dev's, plo_finish_batch_dev's and plo_sa_segments_dev's results (devbatch.HostResults)"""
+        cn, rn = _names(contig_names), _names(ref_names)
+        pr = PloRecordsParams(C.pointer(index_desc), cn, rn, 1 if is_target_region else 0, n_threads)
+        rb = PloRecordBuf()
+        _check(lib().plo_records_build_finished(self.handle, C.byref(lift_out), C.byref(fin_out), C.byref(sa_out) if sa_out is not None else None,
+                                                C.byref(pr), C.byref(rb)), "plo_records_build_finished")
         return rb
 
     def close(self):

@@ -635,7 +635,10 @@ uint8_t *put_cigar_text(uint8_t *p, const uint32_t *c, uint32_t n) {
 
 }  // namespace
 
-extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *lift, const plo_records_params *pr, plo_record_buf *out) {
+// `fin` / `sa` (host copies of plo_finish_batch_dev's / plo_sa_segments_dev's results, or null): flags, bin, primary record,
+// reversed bases and qualities and the SA segments come from there and are only copied into place; else they are made here.
+static plo_status records_build(plo_bam_window *w, const plo_batch_out *lift, const plo_finish_out *fin, const plo_sa_out *sa, const plo_records_params *pr,
+                                plo_record_buf *out) {
     if (!w || !lift || !pr || !out || !pr->index || !pr->contig_names || !pr->ref_names) return PLO_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
     const uint32_t n = w->n_records();
@@ -687,10 +690,14 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
         Rec rec = w->record((uint32_t)r);
         const uint32_t lo = seg_item_lo[w->read_seg_off[r]], hi = seg_item_lo[w->read_seg_off[r + 1]];
         uint32_t n_lift = 0, prim = UINT32_MAX;
-        for (uint32_t i = lo; i < hi; ++i) {
-            if (!item_lifted(i)) continue;
-            ++n_lift;
-            if (prim == UINT32_MAX || lift->item_mapq[prim] < lift->item_mapq[i]) prim = i;  // :338-345 first maximum wins
+        if (fin) {
+            n_lift = fin->read_n_lifted[r];
+        } else {
+            for (uint32_t i = lo; i < hi; ++i) {
+                if (!item_lifted(i)) continue;
+                ++n_lift;
+                if (prim == UINT32_MAX || lift->item_mapq[prim] < lift->item_mapq[i]) prim = i;  // :338-345 first maximum wins
+            }
         }
         AuxPlan ap = plan_aux(rec);
         uint64_t bytes = 0;
@@ -707,14 +714,19 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
                 if (lift->item_need_flipped[i]) fl ^= 0x10;  // :126
                 fl |= 0x800;                                 // :282
                 if (i == prim) fl &= ~0x800u;                // :346
-                info[i].flag = fl;
+                info[i].flag = fin ? fin->item_flag[i] : fl;
                 const uint32_t seg = lift->item_seg[i];
                 const uint32_t contig = seg_contig[seg];
                 info[i].ps_len = (uint32_t)(strlen(pr->contig_names[contig]) + 6 + decimal_len(lift->item_cseg[i]) + 1);  // "{}_split{}{+|-}"
                 // "{chrom},{pos+1},{strand},{cigar},{mapq},0;" (:292-301)
                 const uint32_t *cg = lift->cigar + lift->item_cigar_off[i];
-                info[i].sa_len = (uint32_t)(strlen(pr->ref_names[lift->item_chrom_index[i]]) + 1 + decimal_len((uint64_t)(lift->item_ref_pos[i] + 1)) +
-                                            1 + 1 + 1 + cigar_text_len(cg, lift->item_cigar_len[i]) + 1 + decimal_len(lift->item_mapq[i]) + 3);
+                if (sa)
+                    info[i].sa_len = sa->item_sa_off[i + 1] - sa->item_sa_off[i];
+                else if (n_lift > 1)
+                    info[i].sa_len = (uint32_t)(strlen(pr->ref_names[lift->item_chrom_index[i]]) + 1 + decimal_len((uint64_t)(lift->item_ref_pos[i] + 1)) +
+                                                1 + 1 + 1 + cigar_text_len(cg, lift->item_cigar_len[i]) + 1 + decimal_len(lift->item_mapq[i]) + 3);
+                else
+                    info[i].sa_len = 0;
                 sa_total += info[i].sa_len;
             }
             for (uint32_t i = lo; i < hi; ++i) {
@@ -741,6 +753,12 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
         uint32_t k = read_nrec[r];
         AuxPlan ap = plan_aux(rec);
         const uint32_t l_seq = rec.l_seq(), seqb = (l_seq + 1) / 2;
+        // (fin: the flipped bases and qualities were made on the device, k_revcomp)
+        auto put_flipped = [&](uint8_t *q, uint64_t seq_off, uint64_t qual_off) -> uint8_t * {
+            memcpy(q, fin->rev_seq + seq_off, seqb);
+            memcpy(q + seqb, fin->rev_qual + qual_off, l_seq);
+            return q + seqb + l_seq;
+        };
         auto put_seq_qual = [&](uint8_t *q, bool flip) -> uint8_t * {
             if (flip) {
                 revcomp_packed(rec.seq(), l_seq, q);
@@ -762,6 +780,7 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
             fl &= ~0x800u;
             const bool flip = (fl & 0x10) != 0;
             if (flip) fl ^= 0x10;
+            if (fin) fl = fin->read_unmapped_flag[r];
             wr32(b, (uint32_t)-1);
             wr32(b + 4, (uint32_t)-1);
             b[8] = (uint8_t)rec.l_qname();
@@ -774,7 +793,7 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
             uint8_t *q = b + 32;
             memcpy(q, rec.qname(), rec.l_qname());
             q += rec.l_qname();
-            q = put_seq_qual(q, flip);
+            q = fin && fin->read_seq_off[r] != PLO_NO_FLIP ? put_flipped(q, fin->read_seq_off[r], fin->read_qual_off[r]) : put_seq_qual(q, fin ? false : flip);
             q = copy_aux(rec, ap, q);
             wr32(p, (uint32_t)(q - b));
             n_unm.fetch_add(1);
@@ -789,12 +808,15 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
             const uint32_t *cg = lift->cigar + lift->item_cigar_off[i];
             const int64_t pos = lift->item_ref_pos[i];
             int64_t ref_len = 0;
-            for (uint32_t c = 0; c < nc; ++c) ref_len += op_ref_len(cg[c]);
+            if (fin)
+                ref_len = fin->item_ref_end[i] - pos;
+            else
+                for (uint32_t c = 0; c < nc; ++c) ref_len += op_ref_len(cg[c]);
             wr32(b, lift->item_chrom_index[i]);
             wr32(b + 4, (uint32_t)(int32_t)pos);
             b[8] = (uint8_t)rec.l_qname();
             b[9] = lift->item_mapq[i];
-            wr16(b + 10, reg2bin((uint64_t)pos, (uint64_t)(pos + ref_len)));  // :278-279
+            wr16(b + 10, fin ? fin->item_bin[i] : reg2bin((uint64_t)pos, (uint64_t)(pos + ref_len)));  // :278-279
             wr16(b + 12, (uint16_t)(nc <= 0xffff ? nc : 2));
             wr16(b + 14, (uint16_t)info[i].flag);
             wr32(b + 16, l_seq);
@@ -810,7 +832,8 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
                 wr32(q + 4, ((uint32_t)ref_len << 4) | 3u);
                 q += 8;
             }
-            q = put_seq_qual(q, lift->item_need_flipped[i] != 0);
+            q = fin && fin->item_seq_off[i] != PLO_NO_FLIP ? put_flipped(q, fin->item_seq_off[i], fin->item_qual_off[i])
+                                                           : put_seq_qual(q, fin ? false : lift->item_need_flipped[i] != 0);
             q = copy_aux(rec, ap, q);
             // PS:Z "{contig}_split{cseg}{+|-}" (:254-265)
             const uint32_t seg = lift->item_seg[i];
@@ -838,6 +861,11 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
                 *q++ = 'Z';
                 for (uint32_t j = lo; j < hi; ++j) {
                     if (j == i || !item_lifted(j)) continue;
+                    if (sa) {  // (k_sa_text's segment of record j)
+                        memcpy(q, sa->sa_text + sa->item_sa_off[j], info[j].sa_len);
+                        q += info[j].sa_len;
+                        continue;
+                    }
                     const char *cn = pr->ref_names[lift->item_chrom_index[j]];
                     size_t l = strlen(cn);
                     memcpy(q, cn, l);
@@ -875,6 +903,20 @@ extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *
     out->n_lifted = n_lifted.load();
     out->n_unmapped_copies = n_unm.load();
     return PLO_OK;
+}
+
+extern "C" plo_status plo_records_build(plo_bam_window *w, const plo_batch_out *lift, const plo_records_params *pr, plo_record_buf *out) {
+    return records_build(w, lift, nullptr, nullptr, pr, out);
+}
+
+extern "C" plo_status plo_records_build_finished(plo_bam_window *w, const plo_batch_out *lift, const plo_finish_out *fin, const plo_sa_out *sa,
+                                                 const plo_records_params *pr, plo_record_buf *out) {
+    if (!fin || !fin->item_flag || !fin->item_bin || !fin->item_ref_end || !fin->item_seq_off || !fin->item_qual_off || !fin->read_n_lifted ||
+        !fin->read_unmapped_flag || !fin->read_seq_off || !fin->read_qual_off || ((fin->rev_seq_bytes || fin->rev_qual_bytes) && (!fin->rev_seq || !fin->rev_qual)))
+        return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: incomplete plo_finish_out (host copies of every array are needed)");
+    if (sa && (sa->n_items != lift->n_items || !sa->item_sa_off || (sa->sa_bytes && !sa->sa_text)))
+        return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: plo_sa_out does not belong to this result");
+    return records_build(w, lift, fin, sa, pr, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1042,7 +1042,9 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // Group indices: class 0 first.  The item indices of the next group are fetched one group ahead.
 // (Measured and dropped: the class order sorted by item weight inside chunks of 4 .. 32 groups, so that a group does not wait for
 // its one longest CIGAR -- a quarter fewer loop trips per group, but 5-15 % slower overall: neighbours in the batch share
-// descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.)
+// descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.  k_chunk_sort's windows of 128 items
+// are what survived of it.  Also measured and dropped: the groups dealt out by atomic queues, one per XCD, instead of the fixed
+// slots below -- 1.30 ms either way on wgs30x, the waves' loads are even enough, and a small batch pays for the atomics.)
 template <bool SP>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
                                    uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx) {

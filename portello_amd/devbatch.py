@@ -177,3 +177,88 @@ def download_sa(eng, so: abi.PloSaOut):
     off = eng.download(so.item_sa_off, np.uint32, int(so.n_items) + 1)
     text = eng.download(so.sa_text, np.uint8, int(so.sa_bytes))
     return off, text
+
+
+# ---- a BAM window's batch on the device, finished there, results back on the host (pipeline.run_bam_to_bam, device_finish) --------
+
+def _host_view(ptr, dtype, count: int) -> np.ndarray:
+    if not count:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).view(dtype)
+
+
+@dataclass
+class UploadedWindow:
+    """device copies of a window's plo_batch_in (dense bases) and plo_finish_in; keeps the tensors alive"""
+    batch: DeviceBatch
+    flags: torch.Tensor
+    qual: torch.Tensor
+    qual_off: torch.Tensor
+    qual_bytes: int
+
+    def finish_in(self) -> abi.PloFinishIn:
+        return abi.PloFinishIn(_p(self.flags, C.c_uint16), _p(self.qual, C.c_uint8), _p(self.qual_off, C.c_uint64), self.qual_bytes)
+
+
+def upload_window(desc: abi.PloBatchIn, fin: abi.PloFinishIn, dev) -> UploadedWindow:
+    """copies the host arrays of a window's batch descriptor (bam.Window.batch_desc(with_finish=True)) to the device, on torch's
+    current stream"""
+    n, ns = int(desc.n_reads), int(desc.n_segs)
+
+    def up(ptr, dtype, count, as_dtype=None):
+        a = _host_view(ptr, dtype, count)
+        if as_dtype is not None:
+            a = a.view(as_dtype)
+        t = torch.from_numpy(a) if count else torch.zeros(0, dtype=torch.from_numpy(np.zeros(1, as_dtype or dtype)).dtype)
+        return t.to(dev, non_blocking=True) if count else torch.zeros(1, dtype=t.dtype, device=dev)[:0]
+
+    coff = _host_view(desc.seg_cigar_off, np.uint32, ns + 1)
+    n_ops = int(coff[-1]) if ns else 0
+    b = DeviceBatch(read_is_reverse=up(desc.read_is_reverse, np.uint8, n), read_seq_len=up(desc.read_seq_len, np.uint32, n, np.int32),
+                    read_seq_off=up(desc.read_seq_off, np.uint64, n, np.int64), seq=up(desc.seq, np.uint8, int(desc.seq_bytes)),
+                    seq_fmt=int(desc.seq_fmt), seg_read=up(desc.seg_read, np.uint32, ns, np.int32), seg_contig=up(desc.seg_contig, np.uint32, ns, np.int32),
+                    seg_pos=up(desc.seg_pos, np.int64, ns), seg_is_fwd_strand=up(desc.seg_is_fwd_strand, np.uint8, ns),
+                    seg_cigar_off=up(desc.seg_cigar_off, np.uint32, ns + 1, np.int32), cigar=up(desc.cigar, np.uint32, n_ops, np.int32))
+    return UploadedWindow(b, up(fin.read_flags, np.uint16, n, np.int16), up(fin.qual, np.uint8, int(fin.qual_bytes)),
+                          up(fin.read_qual_off, np.uint64, n, np.int64), int(fin.qual_bytes))
+
+
+class HostResults:
+    """host copies of a context's device results for one batch -- plo_batch_out (compacted), plo_finish_out, plo_sa_out -- as the
+    structs plo_records_build_finished takes (the numpy arrays behind the pointers live as long as this object)"""
+
+    def __init__(self, eng, out: abi.PloBatchOut, fo: abi.PloFinishOut, so: Optional[abi.PloSaOut], n_reads: int):
+        self._keep = []
+
+        def dl(ptr, dtype, count, ctype):
+            a = eng.download(ptr, dtype, count)
+            self._keep.append(a)
+            return abi._ptr(a, ctype)
+
+        n, nc = int(out.n_items), int(out.n_cigar)
+        self.lift = abi.PloBatchOut()
+        self.lift.n_items = n
+        self.lift.n_cigar = nc
+        for name, dt, ct, cnt in (("item_seg", np.uint32, C.c_uint32, n), ("item_cseg", np.uint32, C.c_uint32, n), ("item_status", np.uint8, C.c_uint8, n),
+                                  ("item_need_flipped", np.uint8, C.c_uint8, n), ("item_mapq", np.uint8, C.c_uint8, n),
+                                  ("item_chrom_index", np.uint32, C.c_uint32, n), ("item_ref_pos", np.int64, C.c_int64, n),
+                                  ("item_cigar_off", np.uint64, C.c_uint64, n), ("item_cigar_len", np.uint32, C.c_uint32, n), ("cigar", np.uint32, C.c_uint32, nc)):
+            setattr(self.lift, name, dl(getattr(out, name), dt, cnt, ct))
+        ctypes_of = {np.uint16: C.c_uint16, np.int64: C.c_int64, np.uint8: C.c_uint8, np.uint64: C.c_uint64, np.uint32: C.c_uint32}
+        self.fin = abi.PloFinishOut()
+        for name, dt in abi.FINISH_ITEM_FIELDS:
+            setattr(self.fin, name, dl(getattr(fo, name), dt, n, ctypes_of[dt]))
+        for name, dt in abi.FINISH_READ_FIELDS:
+            setattr(self.fin, name, dl(getattr(fo, name), dt, n_reads, ctypes_of[dt]))
+        self.fin.rev_seq_bytes, self.fin.rev_qual_bytes = int(fo.rev_seq_bytes), int(fo.rev_qual_bytes)
+        self.fin.rev_seq = dl(fo.rev_seq, np.uint8, int(fo.rev_seq_bytes), C.c_uint8)
+        self.fin.rev_qual = dl(fo.rev_qual, np.uint8, int(fo.rev_qual_bytes), C.c_uint8)
+        self.fin.finish_ms, self.fin.revcomp_ms = fo.finish_ms, fo.revcomp_ms
+        self.sa = None
+        if so is not None:
+            self.sa = abi.PloSaOut()
+            self.sa.n_items = int(so.n_items)
+            self.sa.item_sa_off = dl(so.item_sa_off, np.uint32, int(so.n_items) + 1, C.c_uint32)
+            self.sa.sa_text = dl(so.sa_text, np.uint8, int(so.sa_bytes), C.c_uint8)
+            self.sa.sa_bytes = int(so.sa_bytes)
+            self.sa.sa_ms = so.sa_ms

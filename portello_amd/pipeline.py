@@ -56,19 +56,26 @@ class PipelineStats:
     unmapped_passed_through: int = 0
     bytes_out: int = 0
     seconds: float = 0.0
-    read_s: float = 0.0      # decode + batch construction (reader thread busy time)
+    read_s: float = 0.0      # BGZF inflate + record walk (reader thread busy time)
+    batch_s: float = 0.0     # batch construction (batcher thread busy time)
     lift_s: float = 0.0      # plo_liftover_batch, summed over workers
     build_s: float = 0.0     # plo_records_build, summed over workers
     write_s: float = 0.0     # BGZF output (writer thread busy time)
     device_ms: float = 0.0   # HIP-event time of the lift calls
+    finish_device_ms: float = 0.0  # device_finish: HIP-event time of the finishing, reverse-complement and SA-text kernels
     errors: List[str] = field(default_factory=list)
 
 
 def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: abi.IndexData, contig_names: Sequence[str],
                    ref_names: Sequence[str], ref_lens: Sequence[int], window_reads: int = 50_000, n_workers: int = 2,
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
-                   cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True) -> PipelineStats:  # noqa: E501
-    """sparse_margin: the windows' read bases go to the device as PLO_SEQ_BAM4_SPARSE (granules within that many bases of an indel;
+                   cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
+                   device_finish: bool = False) -> PipelineStats:  # noqa: E501
+    """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
+    (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
+    plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
+    them into place.  Same bytes as the host finishing (tests/test_bam.py).
+    sparse_margin: the windows' read bases go to the device as PLO_SEQ_BAM4_SPARSE (granules within that many bases of an indel;
     the complete bases stay in the window's records for the engine's second look); None = dense bases.  device_inflate: the BGZF
     blocks of the input are inflated on the GPU (leaves the host cores to record assembly and output; falls back to the host without
     a device), None = as the environment says"""
@@ -104,6 +111,10 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 pass
         return None
 
+    # the input side is two stages: BGZF inflate + record walk (read_window), then the window's batch arrays (batch_desc: CIGARs,
+    # bases, qualities gathered into the plo_batch_in layout) -- about half of the reader's time each
+    q_win: "queue.Queue" = queue.Queue(maxsize=2)
+
     def reader():
         try:
             while True:
@@ -111,18 +122,47 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 win = rd.read_window(window_reads)
                 if win is None:
                     break
-                desc = win.batch_desc(sparse_margin=sparse_margin) if win.n_records else None
                 st.read_s += time.perf_counter() - t
-                put(q_in, (win, desc))
+                put(q_win, win)
         except BaseException as e:  # noqa: BLE001
             st.errors.append(f"reader: {e!r}")
+            abort.set()
+        finally:
+            put(q_win, None)
+
+    def batcher():
+        try:
+            while True:
+                win = get(q_win)
+                if win is None:
+                    break
+                t = time.perf_counter()
+                if not win.n_records:
+                    desc = None
+                elif device_finish:
+                    desc = win.batch_desc(with_finish=True)  # (plo_batch_in, plo_finish_in), dense bases
+                else:
+                    desc = win.batch_desc(sparse_margin=sparse_margin)
+                st.batch_s += time.perf_counter() - t
+                put(q_in, (win, desc))
+        except BaseException as e:  # noqa: BLE001
+            st.errors.append(f"batcher: {e!r}")
             abort.set()
         finally:
             for _ in range(n_workers):
                 put(q_in, None)
 
     def lifter(k):
-        eng = api.Engine(index)
+        if device_finish:
+            import torch
+
+            from . import devbatch
+            dev = torch.device("cuda", index.device)
+            tstream = torch.cuda.Stream(device=dev)  # uploads, kernels and downloads of this worker, in order
+            eng = api.Engine(index, stream=tstream.cuda_stream)
+            sa_in, _sa_keep = devbatch.sa_inputs(ref_names, dev)
+        else:
+            eng = api.Engine(index)
         try:
             while True:
                 item = get(q_in)
@@ -132,9 +172,24 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 rb = None
                 if desc is not None:
                     t = time.perf_counter()
-                    lift = eng.liftover_batch_host(desc)
-                    t1 = time.perf_counter()
-                    rb = win.build_records_raw(lift, ixd, contig_names, ref_names, is_target_region, io_threads)
+                    if device_finish:
+                        with torch.cuda.stream(tstream):
+                            up = devbatch.upload_window(desc[0], desc[1], dev)
+                            ddesc = up.batch.desc()
+                            out = eng.liftover_batch_dev(ddesc)
+                            eng.compact_output_dev(out)
+                            fo = eng.finish_batch_dev(ddesc, up.finish_in())
+                            so = eng.sa_segments_dev(sa_in)
+                            host = devbatch.HostResults(eng, out, fo, so, win.n_records)
+                        t1 = time.perf_counter()
+                        rb = win.build_records_finished_raw(host.lift, host.fin, host.sa, ixd, contig_names, ref_names, is_target_region, io_threads)
+                        with lock:
+                            st.finish_device_ms += float(fo.finish_ms) + float(fo.revcomp_ms) + float(so.sa_ms)
+                        del up
+                    else:
+                        lift = eng.liftover_batch_host(desc)
+                        t1 = time.perf_counter()
+                        rb = win.build_records_raw(lift, ixd, contig_names, ref_names, is_target_region, io_threads)
                     t2 = time.perf_counter()
                     tm = eng.timing()
                     with lock:
@@ -178,7 +233,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.errors.append(f"writer: {e!r}")
             abort.set()
 
-    threads = [threading.Thread(target=reader), threading.Thread(target=writer)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
+    threads = [threading.Thread(target=reader), threading.Thread(target=batcher), threading.Thread(target=writer)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
     for t in threads:
         t.start()
     for t in threads:

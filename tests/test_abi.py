@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     L = C.CDLL(lib_path)
     syms = declared_symbols()
     assert {"plo_index_create", "plo_ctx_create", "plo_liftover_batch", "plo_liftover_batch_dev", "plo_selftest", "plo_bam_open",
-            "plo_bam_read_window", "plo_bam_window_batch", "plo_records_build", "plo_bam_writer_open", "plo_bam_output_header",
+            "plo_bam_read_window", "plo_bam_window_batch", "plo_records_build", "plo_records_build_finished", "plo_bam_writer_open", "plo_bam_output_header",
             "plo_bam_window_n_records", "plo_bam_window_batch_sparse", "plo_sparse_seq_pack", "plo_sparse_seq_bound"} <= set(syms)
     for s in syms:
         assert hasattr(L, s), f"{s} declared in the header but not exported"

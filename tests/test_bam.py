@@ -171,6 +171,63 @@ def test_record_bytes_match_python_restatement(small_bam, oracle, is_target_regi
     rd.close()
 
 
+@pytest.mark.parametrize("is_target_region", [False, True])
+def test_records_from_device_finished_batch_are_the_same_bytes(small_bam, oracle, is_target_region):
+    """plo_records_build_finished (flags, bin, reversed bases / qualities and SA text handed in from the device-side finishing
+    -- here: finish_core.hpp run on the host by the emulator library) against plo_records_build and the Python restatement"""
+    import ctypes as C
+
+    import emu_lib
+    w, path, meta = small_bam
+    ix = w.index_data()
+    _, _, recs = bamcheck.read_bam(path)
+    prim = [r for r in recs if not (struct.unpack_from("<H", r, 18)[0] & 0x804)]
+    rd = bam.BamReader(path, 2)
+    win = rd.read_window(100_000)
+    b = win.batch_data()
+    desc, fin_in = win.batch_desc(with_finish=True)
+    n = win.n_records
+    read_flags = np.ctypeslib.as_array(fin_in.read_flags, shape=(n,)).copy()
+    qual = np.ctypeslib.as_array(fin_in.qual, shape=(int(fin_in.qual_bytes),)).copy()
+    qoff = np.ctypeslib.as_array(fin_in.read_qual_off, shape=(n,)).copy()
+    res = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 2)
+    o, keep = abi.out_from_result(res)
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    data, off, n_lift, n_unm = win.build_records(o, ix.to_desc(), cn, rn, is_target_region=is_target_region, n_threads=3)
+    want = [data[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    assert want == expected_records(prim, ix, cn, rn, res, is_target_region)
+    f = emu_lib.finish_batch(b, read_flags, qual, qoff, res)
+    sa_off, sa_text, _ = emu_lib.sa_segments(b, res, f["item_flag"], f["read_n_lifted"], rn)
+    assert (f["item_seq_off"] != abi.NO_FLIP).any() and int(sa_off[-1]) > 0  # flipped records and split reads are in the sample
+    ptr = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(t))
+    arrs = {k: np.ascontiguousarray(v) for k, v in f.items()}
+    fo = abi.PloFinishOut()
+    ct = {np.dtype(np.uint16): C.c_uint16, np.dtype(np.int64): C.c_int64, np.dtype(np.uint8): C.c_uint8, np.dtype(np.uint64): C.c_uint64,
+          np.dtype(np.uint32): C.c_uint32}
+    for name, dt in abi.FINISH_ITEM_FIELDS + abi.FINISH_READ_FIELDS:
+        setattr(fo, name, arrs[name].ctypes.data_as(C.POINTER(ct[np.dtype(dt)])))
+    pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+    arrs["rev_seq"], arrs["rev_qual"] = pad(arrs["rev_seq"]), pad(arrs["rev_qual"])
+    fo.rev_seq, fo.rev_qual = ptr(arrs["rev_seq"], C.c_uint8), ptr(arrs["rev_qual"], C.c_uint8)
+    fo.rev_seq_bytes, fo.rev_qual_bytes = len(f["rev_seq"]), len(f["rev_qual"])
+    sa_off_c, sa_text_c = np.ascontiguousarray(sa_off, np.uint32), pad(np.ascontiguousarray(sa_text, np.uint8))
+    for sa in (abi.PloSaOut(res.n_items, ptr(sa_off_c, C.c_uint32), ptr(sa_text_c, C.c_uint8), int(sa_off[-1]), 0.0), None):
+        rb = win.build_records_finished_raw(o, fo, sa, ix.to_desc(), cn, rn, is_target_region=is_target_region, n_threads=3)
+        got_bytes = C.string_at(rb.bytes, rb.n_bytes) if rb.n_bytes else b""
+        roff = np.ctypeslib.as_array(rb.record_off, shape=(int(rb.n_records) + 1,))
+        got = [got_bytes[int(roff[i]):int(roff[i + 1])] for i in range(int(rb.n_records))]
+        assert len(got) == len(want)
+        for i, (a, e) in enumerate(zip(got, want)):
+            assert a == e, (i, sa is None, pr.record_from_bytes(a), pr.record_from_bytes(e))
+        assert (int(rb.n_lifted), int(rb.n_unmapped_copies)) == (n_lift, n_unm)
+    # an incomplete plo_finish_out is refused
+    bad = abi.PloFinishOut()
+    with pytest.raises(Exception):
+        win.build_records_finished_raw(o, bad, None, ix.to_desc(), cn, rn)
+    win.close()
+    rd.close()
+
+
 def test_hand_checked_record(tmp_path):
     """one read, two lifted records, every byte of the second written out by hand from the reference's statements"""
     seq, qual = "ACGTTGCAAC", "ABCDEFGHIJ"
@@ -386,10 +443,13 @@ def test_unmapped_record_placed_on_a_contig_is_a_data_error(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bam_to_bam_chr20_size_every_record(tmp_path):
+@pytest.mark.parametrize("device_finish", [False, True])
+def test_bam_to_bam_chr20_size_every_record(tmp_path, device_finish):
     """BASELINE configs[1] size (50 k reads): BAM file in -> pipeline.run_bam_to_bam (reader / two lift workers / writer, the path
     bench.py's end_to_end times) -> BAM file out; the written file, re-read with the independent reader, holds exactly the records
-    expected from the oracle's alignments and the Python restatement of the record logic (every window, every record)"""
+    expected from the oracle's alignments and the Python restatement of the record logic (every window, every record).
+    device_finish: flags / bin / primary / reversed bases and qualities / SA text from the device kernels (plo_finish_batch_dev,
+    plo_sa_segments_dev), copied into place by plo_records_build_finished"""
     from oracle import expect
     from portello_amd import pipeline
 
@@ -400,8 +460,8 @@ def test_bam_to_bam_chr20_size_every_record(tmp_path):
     index = api.Index(w.index_data_device())
     cn, rn = meta["contig_names"], bamsynth.ref_names(w)
     st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, [int(s.numel()) for s in w.chrom_seq], window_reads=5000, n_workers=2,
-                                 io_threads=8, unassembled_path=unp)
-    assert st.reads == w.n_reads
+                                 io_threads=8, unassembled_path=unp, device_finish=device_finish)
+    assert st.reads == w.n_reads and (st.finish_device_ms > 0) == device_finish
     v = expect.verify_lifted_bam(inp, outp, ixd, cn, rn, window=1000, every=1, threads=8, unassembled_bam=unp)
     assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st.records_out == v["records_in_output"], v
     assert v["unassembled_ok"]
