@@ -331,7 +331,10 @@ struct BgzfIn {
                 return PLO_OK;
             }
             bad = 0;
-            if (rc <= -100 && rc > -200) device = 0;  // no usable device: stay on the host from now on
+            if (rc <= -100 && rc > -200) {  // no usable device: stay on the host from now on
+                device = 0;
+                if (getenv("PLO_DEBUG_READER")) fprintf(stderr, "[plo] reader: device inflate unavailable on device %d (code %d), inflating on the host\n", dev_id, rc);
+            }
             // a block the device rejects is inflated again on the host, which reports what is wrong with it
         }
         parallel_ranges(blks.size(), threads, [&](size_t lo, size_t hi) {

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -2120,31 +2121,52 @@ struct InfSlot {
     size_t comp_bytes = 0, out_bytes = 0;
     bool busy = false;
 };
-InfSlot g_inf[2];
+struct InfDev {  // one set of slots per device (a reader inflates on the device it was opened for)
+    InfSlot slot[2];
+    int ok = -1;
+};
+std::map<int, InfDev> g_inf_devs;
+InfDev *g_inf_cur = nullptr;  // the set of the sequence in progress (under g_inf_mu)
+int g_inf_prev_dev = -1;      // the calling thread's device before set_device(), restored by release()
 std::mutex g_inf_mu;
-int g_inf_ok = -1;
 }  // namespace
-static int g_inf_dev = -1;  // the device the slots live on (the first one asked for)
-void plo_internal_bgzf_acquire(void) { g_inf_mu.lock(); }
-int plo_internal_bgzf_set_device(int dev) {  // under acquire(): makes `dev` the calling thread's device; -100 if the slots live elsewhere
+void plo_internal_bgzf_acquire(void) {
+    g_inf_mu.lock();
+    g_inf_cur = nullptr;
+    g_inf_prev_dev = -1;
+}
+int plo_internal_bgzf_set_device(int dev) {  // under acquire(): the sequence runs on `dev` (the calling thread's device until release())
     if (dev < 0) dev = 0;
-    if (g_inf_dev >= 0 && g_inf_dev != dev) return -100;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) return -100;
     if (hipSetDevice(dev) != hipSuccess) return -100;
-    g_inf_dev = dev;
+    g_inf_prev_dev = prev;
+    g_inf_cur = &g_inf_devs[dev];
     return 0;
 }
-void plo_internal_bgzf_release(void) { g_inf_mu.unlock(); }
+void plo_internal_bgzf_release(void) {
+    if (g_inf_prev_dev >= 0) (void)hipSetDevice(g_inf_prev_dev);
+    g_inf_cur = nullptr;
+    g_inf_prev_dev = -1;
+    g_inf_mu.unlock();
+}
 int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
     if (slot < 0 || slot > 1) return -101;
-    if (g_inf_ok < 0) {
-        int nd = 0;
-        g_inf_ok = (hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && hipStreamCreateWithFlags(&g_inf[0].st, hipStreamNonBlocking) == hipSuccess &&
-                    hipStreamCreateWithFlags(&g_inf[1].st, hipStreamNonBlocking) == hipSuccess)
-                       ? 1
-                       : 0;
+    if (!g_inf_cur) {  // no set_device(): the calling thread's current device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -100;
+        g_inf_cur = &g_inf_devs[dev];
     }
-    if (!g_inf_ok) return -100;
-    InfSlot &q = g_inf[slot];
+    InfDev &D = *g_inf_cur;
+    if (D.ok < 0) {
+        int nd = 0;
+        D.ok = (hipGetDeviceCount(&nd) == hipSuccess && nd > 0 && hipStreamCreateWithFlags(&D.slot[0].st, hipStreamNonBlocking) == hipSuccess &&
+                hipStreamCreateWithFlags(&D.slot[1].st, hipStreamNonBlocking) == hipSuccess)
+                   ? 1
+                   : 0;
+    }
+    if (!D.ok) return -100;
+    InfSlot &q = D.slot[slot];
     q.n = n;
     q.busy = false;
     if (!n) return 0;
@@ -2174,7 +2196,8 @@ int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, co
 }
 int plo_internal_bgzf_wait(int slot) {
     if (slot < 0 || slot > 1) return -101;
-    InfSlot &q = g_inf[slot];
+    if (!g_inf_cur) return 0;  // nothing was begun
+    InfSlot &q = g_inf_cur->slot[slot];
     if (!q.busy) return 0;
     q.busy = false;
     if (hipStreamSynchronize(q.st) != hipSuccess) return -105;
@@ -2192,8 +2215,11 @@ int plo_internal_bgzf_wait(int slot) {
 }
 int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
     std::lock_guard<std::mutex> g(g_inf_mu);
+    g_inf_cur = nullptr;
     int rc = plo_internal_bgzf_begin(0, comp, comp_bytes, blks, n, out, out_bytes);
-    return rc ? rc : plo_internal_bgzf_wait(0);
+    rc = rc ? rc : plo_internal_bgzf_wait(0);
+    g_inf_cur = nullptr;
+    return rc;
 }
 
 plo_status plo_host_alloc(size_t bytes, void **out) {

@@ -14,9 +14,9 @@ tools/pmc_pass.sh "FETCH_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA 
 tools/pmc_pass.sh "WRITE_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_write.csv 2>&1
 tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
 tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
-# stress: the workgroup-per-item kernel
+# stress: the lane-per-item kernel over heavy items (100 k heavy items: above its threshold)
 S="--workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0"
-SK=${PLO_PROFILE_STRESS_KERNEL:-k_lift_mid}
+SK=${PLO_PROFILE_STRESS_KERNEL:-k_lift_lanes_g}
 python bench.py $S > $o/stress_bench.json 2>/dev/null
 rm -rf /tmp/kt2; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 bench.py $S --no-cpu-baseline --overlap-workers 0 --window-calls 0 > $o/stress_bench_under_rocprof.json 2>/dev/null
 f=$(find /tmp/kt2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/stress_kernel_stats.csv

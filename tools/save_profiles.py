@@ -51,7 +51,7 @@ print(b["value"], b["ms_per_step"], b["cpu_baseline"]["value"])
 for r in eng[:4]:
     print(r[0][:40], r[1], r[3])
 
-# ---- stress workload: the workgroup-per-item kernel --------------------------------------------------------------------------
+# ---- stress workload: its dominant kernel (k_lift_lanes_g at 100 k reads) --------------------------------------------------------------------------
 if os.path.exists(f"{src}/stress_kernel_stats.csv"):
     pre = f"profiles/{rnd}_{ver}_stress"
     rows = list(csv.reader(open(f"{src}/stress_kernel_stats.csv")))
@@ -67,8 +67,9 @@ if os.path.exists(f"{src}/stress_kernel_stats.csv"):
     shutil.copy(f"{src}/stress_bench_under_rocprof.json", f"{pre}_bench_under_rocprof.json")
     sfe, swr = rd(f"{src}/stress_pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/stress_pmc_write.csv")["WRITE_SIZE"]
     with open(f"{pre}_pmc_summary.csv", "w") as f:
-        f.write("# rocprofv3 --pmc <counters> --kernel-include-regex k_lift_mid --output-format csv -- python3 bench.py --workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0 --no-cpu-baseline\n")
-        f.write("# one pass per counter group; value = mean over the launches of k_lift_mid; FETCH_SIZE / WRITE_SIZE in KiB\n")
+        sk = json.load(open(f"{src}/stress_bench.json"))["roofline"]["kernel"]
+        f.write(f"# rocprofv3 --pmc <counters> --kernel-include-regex {sk} --output-format csv -- python3 bench.py --workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0 --no-cpu-baseline\n")
+        f.write(f"# one pass per counter group; value = mean over the launches of {sk}; FETCH_SIZE / WRITE_SIZE in KiB\n")
         f.write("counter,mean_per_launch,launches\n")
         for p in ["stress_pmc_fetch", "stress_pmc_write", "stress_pmc_sq1"]:
             for l in open(f"{src}/{p}.csv"):
