@@ -314,6 +314,9 @@ PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, i
 // an L2 round trip on the loop's dependence chain: 15.9 ms against 13.1 ms of the workgroup-per-item kernel on the stress workload.)
 // Window element j of lane l is word j * 64 + l of the wave's LDS: whatever positions the lanes are at, lane l uses bank l.  The
 // windows are lane-private: no barrier between a lane's writes and its reads.
+// (Measured and dropped: a third window of eight block-map entries per lane for the liftover's cursor, so that a block crossing reads
+// LDS instead of global memory -- 9.98 ms either way on the stress workload; and k_chunk_sort over the heavy classes when their groups
+// outnumber the resident waves -- 16.3 ms either way at 250 k reads.)
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int LANE_RW = 20, LANE_WW = 28;  // dwords per lane; LANE_RW a multiple of 4
 constexpr int LANE_WIN_DWORDS = LANE_RW + LANE_WW;
