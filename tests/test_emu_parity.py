@@ -199,3 +199,17 @@ def test_lane_path_heavy_items_in_fixed_regions(oracle, per):
         rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=150, lane_capw=3072, lane_heavy_per=per, order_seed=per)
         assert rc == 0 and 0 < cnt[23] < res.n_items and cnt[2] == 0  # some light, some heavy, nothing through the tile kernels
         _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
+
+
+def test_lane_path_heavy_items_on_dense_block_maps(oracle):
+    """contigs with an indel every fifty bases: the liftover of a heavy item crosses a hundred blocks (two ops of room per block in its
+    region, a cursor step in nearly every iteration), through the heavy-item lane path at 16 items per wave"""
+    cfg = synth.config("tiny", n_reads=30, seed=135, read_len_mean=2500, read_len_sd=600, split_read_frac=0.2,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=1e-2, dele=1e-2, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    for stages in (abi.STAGES_ALL, abi.STAGE_STRAND | abi.STAGE_LIFTOVER):
+        rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=150, lane_capw=3072, lane_heavy_per=16, order_seed=3)
+        assert rc == 0 and cnt[2] == 0 and cnt[23] < res.n_items  # nothing through the tile kernels, heavy items present
+        _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
