@@ -70,7 +70,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                    ref_names: Sequence[str], ref_lens: Sequence[int], window_reads: int = 50_000, n_workers: int = 2,
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
                    cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
-                   device_finish: bool = False) -> PipelineStats:  # noqa: E501
+                   device_finish: bool = False, read_threads: Optional[int] = None, build_threads: Optional[int] = None,
+                   write_threads: Optional[int] = None) -> PipelineStats:  # noqa: E501
     """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
     (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
     plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
@@ -79,16 +80,21 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     the complete bases stay in the window's records for the engine's second look); None = dense bases.  device_inflate: the BGZF
     blocks of the input are inflated on the GPU (leaves the host cores to record assembly and output; falls back to the host without
     a device), None = as the environment says"""
+    # threads inside the stages (inflate / batch construction, record assembly per worker, BGZF output); default: io_threads each --
+    # the stages run at the same time, so on a host with few cores per GPU smaller shares avoid oversubscription
+    read_threads = read_threads or io_threads
+    build_threads = build_threads or io_threads
+    write_threads = write_threads or io_threads
     st = PipelineStats()
     ixd = index_data.to_desc()
-    rd = bam.BamReader(in_path, io_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))
+    rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
-    wr = bam.BamWriter(out_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level, n_threads=io_threads)
+    wr = bam.BamWriter(out_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level, n_threads=write_threads)
     un = None
     if unassembled_path:
         un = bam.BamWriter(unassembled_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level,
-                           n_threads=max(1, io_threads // 2))
+                           n_threads=max(1, write_threads // 2))
     q_in: "queue.Queue" = queue.Queue(maxsize=2 * n_workers)
     q_out: "queue.Queue" = queue.Queue(maxsize=2 * n_workers)
     lock = threading.Lock()
@@ -182,14 +188,14 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                             so = eng.sa_segments_dev(sa_in)
                             host = devbatch.HostResults(eng, out, fo, so, win.n_records)
                         t1 = time.perf_counter()
-                        rb = win.build_records_finished_raw(host.lift, host.fin, host.sa, ixd, contig_names, ref_names, is_target_region, io_threads)
+                        rb = win.build_records_finished_raw(host.lift, host.fin, host.sa, ixd, contig_names, ref_names, is_target_region, build_threads)
                         with lock:
                             st.finish_device_ms += float(fo.finish_ms) + float(fo.revcomp_ms) + float(so.sa_ms)
                         del up
                     else:
                         lift = eng.liftover_batch_host(desc)
                         t1 = time.perf_counter()
-                        rb = win.build_records_raw(lift, ixd, contig_names, ref_names, is_target_region, io_threads)
+                        rb = win.build_records_raw(lift, ixd, contig_names, ref_names, is_target_region, build_threads)
                     t2 = time.perf_counter()
                     tm = eng.timing()
                     with lock:
