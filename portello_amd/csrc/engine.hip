@@ -1006,10 +1006,12 @@ struct plo_ctx {
     int lane_capw = 3072;
     bool lane_sort = true;  // k_chunk_sort before the lane kernel
     int lane_sort_window = LANE_SORT_WINDOW;
-    // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows) for batches with at
-    // least that many heavy items; < 0: never.  Stress workload, heavy items -> k_lift_mid / k_lift_lanes_g: 20 k 2.8 / 7.9 ms,
-    // 60 k 8.0 / 9.6 ms, 80 k 10.5 / 9.6 ms, 100 k 13.1 / 9.9 ms, 250 k 32.5 / 19.7 ms.
-    int lane_heavy_min = 70000;
+    // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
+    // batches with at least that many heavy items; < 0 (default) = by lane_heavy_ratio, see the routing in liftover_core (0: never).
+    // Stress workload, heavy items -> k_lift_mid / k_lift_lanes_g: 20 k 2.8 / 7.9 ms, 60 k 8.0 / 9.6 ms, 80 k 10.5 / 9.6 ms,
+    // 100 k 13.1 / 9.9 ms, 250 k 32.5 / 16-20 ms.
+    int lane_heavy_min = -1;
+    int lane_heavy_ratio = 50000;
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1252,6 +1254,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = std::min(2048, std::max(64, atoi(e) & ~63));
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
+    if (const char *e = getenv("PLO_LANE_HEAVY_RATIO")) c->lane_heavy_ratio = std::max(0, atoi(e));
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1540,7 +1543,16 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     }
     // ---- items too heavy for an LDS region.  Many of them: the lane-per-item code again, regions in global scratch (k_lift_lanes_g).
     // A few: tiles of the wave-cooperative kernel (weight prefix, per-batch geometry).
-    const bool heavy_lanes = n_items > n_small && c->lane_max_w >= 0 && c->lane_heavy_min >= 0 && n_items - n_small >= (uint32_t)c->lane_heavy_min;
+    // The lane kernel takes as long as its longest item takes a wave (about 3.5 us per op), however many items there are; the
+    // workgroup-per-item kernel takes about 70 ps per op of the batch.  So: the lanes when the batch's ops (weights) outnumber the
+    // longest item's by lane_heavy_ratio -- 50 000, the measured crossing on the stress profile (67 k reads of 2 000 ops, longest
+    // 2 800 + 240 block-map allowance).  PLO_LANE_HEAVY_MIN: an item count instead (0: always).
+    const uint32_t n_heavy_all = n_items - n_small;
+    const bool heavy_lanes =
+        n_heavy_all > 0 && c->lane_max_w >= 0 &&
+        (c->lane_heavy_min >= 0 ? n_heavy_all >= (uint32_t)c->lane_heavy_min
+                                : (c->lane_heavy_ratio > 0 && n_heavy_all >= 8192u &&
+                                   all_ops >= (unsigned long long)c->lane_heavy_ratio * std::min<unsigned long long>(max_nin, 16384ull)));
     if (n_items > n_small && !heavy_lanes) {
         plo_status s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
@@ -1655,9 +1667,17 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t per = std::min(64u, std::max(8u, (n_heavy + slots - 1) / slots));
             if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
             const uint32_t groups = (n2 + per - 1) / per + (n3 + per - 1) / per;
-            // (regions start on 128-byte lines; 64: room for the liftover's gap, lane_region_gap -- an item that needs more is retried)
-            const int stride = (int)((max_nin + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
             uint32_t nblk = std::min<uint32_t>((groups + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ));
+            // Regions start on 128-byte lines and hold the heaviest item of the batch (64: room for the liftover's gap, lane_region_gap)
+            // -- unless that one is an outlier: the regions of all resident lanes together are kept within 8 GB, an item too long for
+            // its region then is handed to the retry list (wave-cooperative code, whatever its size) like any other that outgrows it.
+            int stride = (int)((max_nin + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+            {
+                const unsigned long long fit = (8ull << 30) / (4ull * per * LANE_G_WAVES * std::max(1u, nblk));
+                const int cap_stride = (int)std::max<unsigned long long>(1024ull, std::min<unsigned long long>(fit, 0x7fffffe0ull) & ~31ull);
+                stride = std::min(stride, cap_stride);
+                if (const char *e = getenv("PLO_LANE_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;
+            }
             const unsigned long long per_wave = (unsigned long long)per * (unsigned long long)stride * 4ull;
             nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_G_WAVES)));
             HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_G_WAVES * nblk)));

@@ -198,7 +198,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         if (heavy_lanes) {
             uint32_t max_w = 0;
             for (uint32_t i = 0; i < n_items; ++i) max_w = std::max(max_w, item_nin[i]);
-            const int stride = (int)((max_w + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+            int stride = (int)((max_w + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+            if (const char *e = getenv("PLO_EMU_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;  // (regions too small for the longer items: retry list)
             std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;

@@ -213,3 +213,18 @@ def test_lane_path_heavy_items_on_dense_block_maps(oracle):
         rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=150, lane_capw=3072, lane_heavy_per=16, order_seed=3)
         assert rc == 0 and cnt[2] == 0 and cnt[23] < res.n_items  # nothing through the tile kernels, heavy items present
         _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
+
+
+def test_lane_path_heavy_items_longer_than_their_region(oracle, monkeypatch):
+    """the heavy-item lane path with regions sized below the longer items (the engine caps the regions when one outlier would make
+    them huge): those items are handed to the retry list -> wave-cooperative code"""
+    monkeypatch.setenv("PLO_EMU_HEAVY_STRIDE", "288")
+    cfg = synth.config("tiny", n_reads=40, seed=136, read_len_mean=2500, read_len_sd=900, split_read_frac=0.2,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    rc, res, cnt = emu_lib.liftover_batch(ix, b, lane_max_w=150, lane_capw=3072, lane_heavy_per=8, order_seed=9, big_thresh=100, cap=512)
+    assert rc == 0 and cnt[7] > 0  # items handed on
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1), res)
+

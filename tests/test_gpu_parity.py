@@ -157,6 +157,24 @@ def test_synthetic_indel_dense_heavy_items_lane_per_item(oracle, monkeypatch, pe
     eng_ix.close()
 
 
+def test_heavy_items_longer_than_their_region_are_handed_on(oracle, monkeypatch):
+    """k_lift_lanes_g with regions smaller than the longer items of the batch (what the engine does when an outlier would make the
+    regions of all resident lanes exceed 8 GB): those items go to the retry list and through the wave-cooperative kernels"""
+    monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
+    monkeypatch.setenv("PLO_LANE_HEAVY_STRIDE", "640")
+    monkeypatch.setenv("PLO_LANE_MAX_W", "150")
+    w = _indel_dense_workload()
+    ix, b = w.index_data(), w.batch_data()
+    eng_ix = api.Index(ix)
+    eng = api.Engine(eng_ix)
+    got = eng.liftover_batch(b)
+    t = eng.timing()
+    assert t.n_heavy_lane_items > 0 and t.n_retry_items > 0
+    _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "heavy lanes, short regions")
+    eng.close()
+    eng_ix.close()
+
+
 def test_synthetic_indel_dense_adaptive_geometry(oracle):
     """default: the routing threshold / LDS slice follow the batch's weight distribution, the same items stay in tiles"""
     w = _indel_dense_workload()
