@@ -149,6 +149,32 @@ def test_emulated_workgroup_per_item_on_sparse_bases(oracle):
             assert n_miss == 0
 
 
+@pytest.mark.parametrize("path", ["lanes", "heavy lanes"])
+def test_emulated_lane_per_item_paths_on_sparse_bases(oracle, path):
+    """the lane-per-item code (`lane_tile<SP = true>`: synchronous probes through the granule look-up) -- regions in LDS, and heavy
+    items in global regions behind the LDS windows -- on sparse bases: same results, same items reported as missing bases"""
+    cfg = synth.config("tiny", n_reads=24, seed=141, read_len_mean=2500, read_len_sd=700, split_read_frac=0.2,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1).canonical()
+    kw = dict(lane_max_w=100000, lane_capw=60000) if path == "lanes" else dict(lane_max_w=150, lane_capw=3072, lane_heavy_per=16)
+    for margin in (8, 1 << 20):
+        sp = bam.sparse_pack(b, margin)
+        rc, res, counters = emu_lib.liftover_batch(ix, sp, order_seed=5, **kw)
+        assert rc == 0 and counters[2] == 0  # nothing through the wave-cooperative kernels
+        n_miss = 0
+        for x, y in zip(ref, res.canonical()):
+            if y[2] == abi.ITEM_NEED_BASES:
+                n_miss += 1
+            else:
+                assert x == y
+        assert n_miss == counters[21]
+        if margin > 8:
+            assert n_miss == 0
+
+
 def test_sparse_window_batch_equals_packing_the_dense_window_batch(tmp_path):
     """plo_bam_window_batch_sparse (granules straight from the BAM records) == plo_sparse_seq_pack of the window's dense batch;
     seq_full / read_seq_full_off point at the records' own packed bases"""
@@ -179,6 +205,33 @@ def test_sparse_window_batch_equals_packing_the_dense_window_batch(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_sparse_bases_heavy_items_lane_per_item(oracle, monkeypatch):
+    """indel-dense items on sparse bases through k_lift_lanes_g_sp (heavy items, global regions behind the LDS windows), items
+    that reached absent bases lifted again from the complete ones"""
+    from portello_amd import api
+    monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
+    monkeypatch.setenv("PLO_LANE_MAX_W", "150")
+    cfg = synth.config("tiny", n_reads=300, seed=142, read_len_mean=5000, read_len_sd=1500, split_read_frac=0.2,
+                       read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),
+                       contig_rates=synth.EditRates(mismatch=1e-3, ins=3e-3, dele=3e-3, hpol_frac=0.3, big_indel_prob=0.02))
+    w = synth.generate(cfg)
+    ixd, b = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ixd, b, abi.STAGES_ALL, 8).canonical()
+    index = api.Index(ixd, 0)
+    eng = api.Engine(index)
+    try:
+        for margin in (4, 32):
+            sp = bam.sparse_pack(b, margin)
+            got = abi.result_from_out(eng.liftover_batch_host(sp.to_desc())).canonical()
+            t = eng.timing()
+            assert t.n_heavy_lane_items > 0 and t.n_mid_items == 0
+            assert got == ref, margin
+    finally:
+        eng.close()
+        index.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("margin", [0, 32])
 def test_gpu_sparse_bases_second_look_gives_the_oracle_result(oracle, margin):
