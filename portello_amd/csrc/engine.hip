@@ -1,14 +1,19 @@
 // engine.hip -- gfx950 kernels + the C ABI of include/portello_liftover.h.
 //
 // Kernel pipeline of one batch (all on the context's stream):
-//   k_seg_count          four lanes per read split segment: batch validation, reference span, how many contig segments it touches (a8)
+//   k_seg_count          two lanes per read split segment, 16 ops per lane and step: batch validation, reference span, read length, op count
+//                        with match runs merged, how many contig segments it touches (a8)
 //   scan                 item offsets, n_items (host sync: buffer sizes)
 //   k_item_emit          thread per segment: resolved item descriptors (strand glue a9, block-map window a3), item class + weight
 //   k_cls_hist / k_cls_scan / k_permute2   class order (strand x light / heavy): groups and tiles are strand-homogeneous; the host reads
 //                        the class counts and the weight sum / maximum while k_permute2 runs
-//   k_lift_lanes         DOMINANT KERNEL on HiFi batches (lane_core.hpp): persistent waves, 64 light items per wave, one LANE per item,
-//                        the whole shift / liftover / length check / simplify pipeline in place in a ~180-byte LDS region per item
-//   (heavy items only)   scan of the weights, k_max_u32 (weight histogram -> tile geometry, host sync), k_tile_bounds,
+//   k_chunk_sort         light items by weight inside windows of 128 positions of the class order (groups of similar length)
+//   k_lift_lanes         DOMINANT KERNEL on HiFi batches (lane_core.hpp): persistent waves, 64 light items per wave (32 / 16 / 8 when the
+//                        batch has few), one LANE per item, the whole shift / liftover / length check / simplify pipeline in place in a
+//                        ~180-byte LDS region per item
+//   k_lift_lanes_g       heavy items of batches with many of them (dominant on the stress workload): the same lane-per-item code, the
+//                        regions in wave-private global scratch behind per-lane LDS windows (lane_core.hpp, LaneWin)
+//   (heavy items of smaller batches)   scan of the weights, k_max_u32 (weight histogram -> tile geometry, host sync), k_tile_bounds,
 //   k_lift_tiles         persistent waves, one wave per tile of items, the pipeline as wave scans over a flattened op stream in LDS
 //   k_lift_retry         items whose LDS region / slice overflowed (lanes or tiles): one item per wave, larger slice
 //   k_lift_mid           items heavier than the routing threshold: one WORKGROUP per item (8 or 16 waves share the item's op
@@ -603,7 +608,9 @@ __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 // resident wave has its 64, and the workgroup-per-item kernel is the faster one for fewer than some 70 k heavy items
 // (lane_heavy_min).  Measured and dropped: the heavy classes sorted by weight (k_chunk_sort's idea without its windows), long
 // groups paired with short ones on a SIMD -- 7 % slower at 100 k reads, 11 % at 250 k: neighbours in the batch share reference and
-// block-map lines, and a group of items from all over the genome gives that up.
+// block-map lines, and a group of items from all over the genome gives that up.  Nor did ordering whole GROUPS by the length of their
+// longest item (items left where they are), long ones paired with short ones on a SIMD in workgroups of 8 waves: 9.68 against 9.85 ms
+// at 100 k reads, and 8-wave workgroups cost 20 % at 250 k (19.7 against 16.3 ms with two 4-wave workgroups per CU).
 template <bool SP>
 PLO_DEV void lift_lanes_g_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t lo, uint32_t mid, uint32_t hi,
                                  uint32_t per, uint32_t *scratch, int stride) {

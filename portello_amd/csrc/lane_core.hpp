@@ -15,8 +15,9 @@
 //     block, the one after it in flight), so that a crossing costs no search and no wait;
 //   * the left shift's homology probes ISSUED at the end of an indel cluster and CONSUMED at the next one (the emission of a
 //     cluster is deferred until then): the HBM round trip runs under the walk of the following ops.
-// Items whose region overflows, or that are too heavy for a region, go to the wave-cooperative code of lift_core.hpp (retry /
-// large-item lists), which remains the general path.
+// Items whose region overflows go to the wave-cooperative code of lift_core.hpp (retry list), which remains the general path.  Items
+// too heavy for an LDS region: the same code with the region in global memory behind two small LDS windows per lane (lane_tile<SP, WIN>,
+// "Heavy items" below) when a batch has many of them, else the wave-cooperative kernels (large-item lists).
 //
 // All citations are relative to /root/reference.
 #pragma once
