@@ -80,11 +80,13 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     the complete bases stay in the window's records for the engine's second look); None = dense bases.  device_inflate: the BGZF
     blocks of the input are inflated on the GPU (leaves the host cores to record assembly and output; falls back to the host without
     a device), None = as the environment says"""
-    # threads inside the stages (inflate / batch construction, record assembly per worker, BGZF output); default: io_threads each --
-    # the stages run at the same time, so on a host with few cores per GPU smaller shares avoid oversubscription
-    read_threads = read_threads or io_threads
-    build_threads = build_threads or io_threads
-    write_threads = write_threads or io_threads
+    # threads inside the stages (inflate / batch construction, record assembly per worker, BGZF output).  The stages run at the same
+    # time: half of io_threads each by default (tools/bench_e2e_threads.py on the 16-core GPU box, best of three runs: 80.6-81.4 k reads/s
+    # with 8 / 4-8 / 6-8 threads against 77.1 k with 16 each; the input and output stages are bound by the page cache either way)
+    half = max(2, io_threads // 2)
+    read_threads = read_threads or half
+    build_threads = build_threads or half
+    write_threads = write_threads or half
     st = PipelineStats()
     ixd = index_data.to_desc()
     rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))

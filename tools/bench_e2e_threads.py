@@ -26,16 +26,15 @@ try:
     cn, rn = meta["contig_names"], bamsynth.ref_names(w)
     rl = [int(s.numel()) for s in w.chrom_seq]
     pipeline.run_bam_to_bam(inp, os.path.join(d, "o.bam"), index, ixd, cn, rn, rl, window_reads=2000, n_workers=1)
-    combos = [dict(), dict(read_threads=8, build_threads=4, write_threads=6), dict(read_threads=10, build_threads=3, write_threads=6),
-              dict(read_threads=6, build_threads=4, write_threads=8), dict(read_threads=8, build_threads=8, write_threads=8),
-              dict(read_threads=8, build_threads=4, write_threads=6, window_reads=5000), dict(read_threads=8, build_threads=4, write_threads=6, window_reads=3750),
-              dict(read_threads=8, build_threads=4, write_threads=6, n_workers=3), dict(read_threads=12, build_threads=4, write_threads=8)]
+    combos = [dict(), dict(read_threads=8, build_threads=4, write_threads=6), dict(read_threads=8, build_threads=8, write_threads=8),
+              dict(window_reads=5000), dict(window_reads=3750), dict(window_reads=2500), dict(window_reads=3750, n_workers=3),
+              dict(window_reads=3750, read_threads=8, build_threads=8, write_threads=8)]
     for dfin in (True, False):
         for c in combos:
             kw = dict(window_reads=7500, n_workers=2, io_threads=16)
             kw.update(c)
             best = None
-            for _ in range(2):
+            for _ in range(3):
                 st = pipeline.run_bam_to_bam(inp, os.path.join(d, "o.bam"), index, ixd, cn, rn, rl, device_finish=dfin, **kw)
                 if best is None or st.seconds < best.seconds:
                     best = st
