@@ -686,12 +686,32 @@ static plo_status records_build(plo_bam_window *w, const plo_batch_out *lift, co
         return sz;
     };
     // pass 1: flags, primary, text lengths, sizes
+    std::atomic<bool> fin_bad{false};
     parallel_for(n, threads, [&](size_t r) {
         Rec rec = w->record((uint32_t)r);
         const uint32_t lo = seg_item_lo[w->read_seg_off[r]], hi = seg_item_lo[w->read_seg_off[r + 1]];
         uint32_t n_lift = 0, prim = UINT32_MAX;
         if (fin) {
-            n_lift = fin->read_n_lifted[r];
+            // the finished arrays must describe this very result: the record counts (the output is laid out by them) and every
+            // offset into the reversed bases / qualities / SA text are checked before anything is copied from there
+            for (uint32_t i = lo; i < hi; ++i) n_lift += item_lifted(i) ? 1 : 0;
+            const uint64_t sb = (uint64_t)(rec.l_seq() + 1) / 2, qb = rec.l_seq();
+            bool ok = n_lift == fin->read_n_lifted[r];
+            if (n_lift == 0)
+                ok = ok && (fin->read_seq_off[r] == PLO_NO_FLIP ||
+                            (fin->read_seq_off[r] <= fin->rev_seq_bytes && sb <= fin->rev_seq_bytes - fin->read_seq_off[r] &&
+                             fin->read_qual_off[r] <= fin->rev_qual_bytes && qb <= fin->rev_qual_bytes - fin->read_qual_off[r]));
+            for (uint32_t i = lo; i < hi && ok; ++i) {
+                if (!item_lifted(i)) continue;
+                ok = fin->item_seq_off[i] == PLO_NO_FLIP ||
+                     (fin->item_seq_off[i] <= fin->rev_seq_bytes && sb <= fin->rev_seq_bytes - fin->item_seq_off[i] &&
+                      fin->item_qual_off[i] <= fin->rev_qual_bytes && qb <= fin->rev_qual_bytes - fin->item_qual_off[i]);
+                if (ok && sa) ok = sa->item_sa_off[i] <= sa->item_sa_off[i + 1] && sa->item_sa_off[i + 1] <= sa->sa_bytes;
+            }
+            if (!ok) {
+                fin_bad.store(true);
+                return;
+            }
         } else {
             for (uint32_t i = lo; i < hi; ++i) {
                 if (!item_lifted(i)) continue;
@@ -738,6 +758,9 @@ static plo_status records_build(plo_bam_window *w, const plo_batch_out *lift, co
         }
         read_bytes[r + 1] = bytes;
     });
+    if (fin_bad.load())
+        return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: the finished arrays do not belong to this lift result (record counts or offsets into the reversed "
+                                         "bases / qualities / SA text disagree)");
     for (uint32_t r = 0; r < n; ++r) {
         read_bytes[r + 1] += read_bytes[r];
         read_nrec[r + 1] += read_nrec[r];

@@ -224,6 +224,19 @@ def test_records_from_device_finished_batch_are_the_same_bytes(small_bam, oracle
     bad = abi.PloFinishOut()
     with pytest.raises(Exception):
         win.build_records_finished_raw(o, bad, None, ix.to_desc(), cn, rn)
+    # ... and so are finished arrays that do not fit the lift result: a wrong record count, an offset beyond the reversed bases
+    good = arrs["read_n_lifted"].copy()
+    arrs["read_n_lifted"][int(np.argmax(good > 0))] += 1
+    with pytest.raises(Exception, match="do not belong"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
+    arrs["read_n_lifted"][:] = good
+    flipped = int(np.argmax(arrs["item_seq_off"] != abi.NO_FLIP))
+    keep_off = int(arrs["item_seq_off"][flipped])
+    arrs["item_seq_off"][flipped] = fo.rev_seq_bytes - 1
+    with pytest.raises(Exception, match="do not belong"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
+    arrs["item_seq_off"][flipped] = keep_off
+    win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)  # (restored: fine again)
     win.close()
     rd.close()
 
