@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLO_API_VERSION 3
+#define PLO_API_VERSION 4 /* 4: plo_timing starts with struct_size (the callee fills no more than the caller's struct holds) */
 
 typedef enum plo_status {
     PLO_OK = 0,
@@ -200,8 +200,11 @@ typedef struct plo_batch_out {
                                           buffer is slab-allocated on the device and may contain unused gaps)  */
 } plo_batch_out;
 
-/* Per-call device timing measured with HIP events on the context's stream */
+/* Per-call device timing measured with HIP events on the context's stream.
+   `struct_size`: set by the CALLER to sizeof(plo_timing) of the header it was built against before plo_ctx_timing;
+   the library writes at most that many bytes (fields are only ever appended), and stores the size it filled. */
 typedef struct plo_timing {
+    uint32_t struct_size;
     float total_ms;      /* first kernel start -> last kernel end                                   */
     float enumerate_ms;  /* item enumeration + scans                                                */
     float lift_ms;       /* the wave-cooperative tile kernel (longer CIGARs)                         */
@@ -225,6 +228,8 @@ typedef struct plo_timing {
     float heavy_lanes_ms;        /* the lane-per-item kernel over heavy items (k_lift_lanes_g: regions in global scratch
                                     behind LDS windows); lift_ms / mid_ms are 0 then                                   */
     uint32_t n_heavy_lane_items;
+    float lane_utilisation;      /* lane-per-item kernels: lanes at work / (64 x loop trips), summed over the liftover loop and the
+                                    shift stage's event rounds of all waves (0 when no such kernel ran)                      */
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);
@@ -342,6 +347,8 @@ plo_status plo_ctx_download(plo_ctx *ctx, void *host_dst, const void *dev_src, s
 plo_status plo_ctx_timing(plo_ctx *ctx, plo_timing *out);
 const char *plo_last_error(const plo_ctx *ctx);
 const char *plo_version(void);
+/* PLO_API_VERSION the library was built with */
+uint32_t plo_api_version(void);
 /* Device self-test of the wavefront primitives (DPP scans, cross-lane reads): 0 = ok. */
 int plo_selftest(int device);
 

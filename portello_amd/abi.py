@@ -112,8 +112,12 @@ class PloBatchOut(C.Structure):
     ]
 
 
+PLO_API_VERSION = 4  # include/portello_liftover.h
+
+
 class PloTiming(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("total_ms", C.c_float),
         ("enumerate_ms", C.c_float),
         ("lift_ms", C.c_float),
@@ -135,6 +139,7 @@ class PloTiming(C.Structure):
         ("tile_window", C.c_uint32),
         ("heavy_lanes_ms", C.c_float),
         ("n_heavy_lane_items", C.c_uint32),
+        ("lane_utilisation", C.c_float),
     ]
 
 

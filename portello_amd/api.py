@@ -50,6 +50,8 @@ def load_library(path: Optional[str] = None):
         pass
     L = C.CDLL(path)
     vp = C.c_void_p
+    if not hasattr(L, "plo_api_version") or L.plo_api_version() != abi.PLO_API_VERSION:
+        raise PortelloError(abi.PLO_ERR_INVALID_ARG, f"{path} was built for another PLO_API_VERSION than this binding ({abi.PLO_API_VERSION}): rebuild it")
     L.plo_index_create.restype = C.c_int
     L.plo_index_create.argtypes = [C.POINTER(abi.PloIndexDesc), C.c_int, C.POINTER(vp)]
     L.plo_index_destroy.restype = None
@@ -78,6 +80,7 @@ def load_library(path: Optional[str] = None):
     L.plo_ctx_sync.argtypes = [vp]
     L.plo_ctx_download.restype = C.c_int
     L.plo_ctx_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.plo_api_version.restype = C.c_uint32
     L.plo_ctx_timing.restype = C.c_int
     L.plo_ctx_timing.argtypes = [vp, C.POINTER(abi.PloTiming)]
     L.plo_last_error.restype = C.c_char_p
@@ -198,6 +201,7 @@ class Engine:
 
     def timing(self) -> abi.PloTiming:
         t = abi.PloTiming()
+        t.struct_size = C.sizeof(abi.PloTiming)
         self._check(self.lib.plo_ctx_timing(self.handle, C.byref(t)), "plo_ctx_timing")
         return t
 

@@ -589,7 +589,7 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
         ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)capw, capw, ctx);
+    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx);
     wave_ctx_flush(wk, ctx, wave);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
@@ -616,7 +616,7 @@ PLO_DEV void lift_lanes_g_kernel(const DevIndex &ix, const DevBatch &bt, const D
                                  uint32_t per, uint32_t *scratch, int stride) {
     const uint32_t k = threadIdx.x >> 6, n_waves = gridDim.x * LANE_G_WAVES;
     const uint32_t wave = blockIdx.x * LANE_G_WAVES + k;
-    __shared__ uint32_t windows[LANE_G_WAVES][64 * LANE_WIN_DWORDS];
+    __shared__ uint32_t windows[LANE_G_WAVES][64 * LANE_WIN_DWORDS + LANE_KVS_DWORDS];
     WaveCtx ctx;
     lane_heavy_persistent<SP>(ix, bt, wk, stages, wave, n_waves, lo, mid, hi, per, windows[k], scratch + (size_t)wave * (size_t)per * (size_t)stride, stride, ctx);
     wave_ctx_flush(wk, ctx, wave);
@@ -731,25 +731,27 @@ __global__ void k_miss_patch(const uint32_t *list, uint32_t n, const uint64_t *v
 
 // sums (and clears) the per-wave statistic slots of the lift kernels that have run since the last call into the batch counters
 __global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint32_t n_slots, unsigned long long *counters) {
-    __shared__ unsigned long long acc[3];
-    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __shared__ unsigned long long acc[5];
+    if (threadIdx.x < 5) acc[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long a = 0, b = 0, c = 0;
+    unsigned long long a[5] = {0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
-        unsigned long long *w = ws + (size_t)i * 4;
-        a += w[0];
-        b += w[1];
-        c += w[2];
-        w[0] = w[1] = w[2] = 0;
+        unsigned long long *w = ws + (size_t)i * STAT_WORDS;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            a[k] += w[k];
+            w[k] = 0;
+        }
     }
-    atomicAdd(&acc[0], a);
-    atomicAdd(&acc[1], b);
-    atomicAdd(&acc[2], c);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) atomicAdd(&acc[k], a[k]);
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&counters[CNT_ALGO_BYTES], acc[0]);
         atomicAdd(&counters[CNT_IN_OPS], acc[1]);
         atomicAdd(&counters[CNT_OUT_OPS], acc[2]);
+        atomicAdd(&counters[CNT_LANE_ACT], acc[3]);
+        atomicAdd(&counters[CNT_LANE_TRIPS], acc[4]);
     }
 }
 
@@ -1054,6 +1056,7 @@ static hipError_t upload(std::vector<void *> &owned, const std::vector<T> &v, co
 extern "C" {
 
 const char *plo_version(void) { return "portello-liftover-mi355x 0.1 (gfx950)"; }
+uint32_t plo_api_version(void) { return PLO_API_VERSION; }
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out) {
     if (!desc || !out) return PLO_ERR_INVALID_ARG;
@@ -1476,7 +1479,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.cig_len = c->o_clen.as<uint32_t>();
     wk.counters = c->counters.as<unsigned long long>();
     {   // statistic slots of the lift kernels' waves: zeroed once, cleared again by every k_sum_stats
-        const size_t want = (size_t)STAT_SLOTS * 4 * 8;
+        const size_t want = (size_t)STAT_SLOTS * STAT_WORDS * 8;
         if (c->wave_stats.cap < want) {
             HIP_TRY(c, c->wave_stats.ensure(want));
             HIP_TRY(c, hipMemsetAsync(c->wave_stats.p, 0, want, st));
@@ -1643,7 +1646,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
                                    (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
             }
-            const size_t lds = (size_t)c->lane_capw * 4 * LANE_WAVES;
+            const size_t lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;  // slices + staged block-map entries
             int occ = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lds) != hipSuccess || occ < 1)
                 occ = 1;
@@ -1894,6 +1897,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_in_ops = hc[CNT_IN_OPS];
     c->timing.n_out_ops = hc[CNT_OUT_OPS];
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
+    c->timing.lane_utilisation = hc[CNT_LANE_TRIPS] ? (float)((double)hc[CNT_LANE_ACT] / (64.0 * (double)hc[CNT_LANE_TRIPS])) : 0.0f;
     for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
 
     out->n_items = n_items;
@@ -2281,7 +2285,15 @@ plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     c->timing.mid_ms = md;
     c->timing.big_ms = g;
     c->timing.total_ms = a + l + b + r + md + g;
-    *t = c->timing;
+    // the caller says how much of the struct it knows (API version 4): never write past that
+    const uint32_t have = t->struct_size;
+    if (have < 8u || have > (1u << 16)) {
+        c->err = "plo_ctx_timing: plo_timing::struct_size must be set to sizeof(plo_timing) by the caller";
+        return PLO_ERR_INVALID_ARG;
+    }
+    const uint32_t n = std::min<uint32_t>(have, (uint32_t)sizeof(plo_timing));
+    c->timing.struct_size = n;
+    memcpy(t, &c->timing, n);
     return PLO_OK;
 }
 

@@ -166,14 +166,30 @@ struct XW16 {
 // Straight-line: every lane loads (lanes without a usable window from the start of `safe`, which must be readable for 20 bytes),
 // and nothing looks at the loaded words before xw16_decode -- a select on them would put the wait for the round trip right here.
 // Returns whether the lane's window is usable.
-PLO_DEV bool xw16_issue(bool on, const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, const uint8_t *safe, XW16 &w) {
-    bool ok = on & (rd.fmt != PLO_SEQ_BAM4_SPARSE);  // (granule look-ups first: those batches probe synchronously)
-    ok = ok & (r0 >= 0) & (q0 >= 0) & (q0 <= rd.len - 16);
+// Sparse bases (PLO_SEQ_BAM4_SPARSE): the granule look-up (sparse_locate, lift_core.hpp) comes first -- the header pair(s) of the
+// window's granules, three words of the read's own header line, which its earlier probes have brought into the caches -- and the
+// window's loads follow at the granule's place; `miss`: a granule of the window is absent (the item ends PLO_ITEM_NEED_BASES).
+PLO_DEV bool xw16_issue(bool on, const uint8_t *ref, int ref_len, int r0, const ReadSeq &rd, int q0, const uint8_t *safe, XW16 &w, bool &miss) {
+    bool ok = on & (r0 >= 0) & (q0 >= 0) & (q0 <= rd.len - 16);
     const int rsh = (int)(((unsigned)(uintptr_t)ref + (unsigned)r0) & 3u);
     ok = ok & (r0 - rsh >= 0) & (r0 - rsh <= ref_len - 20);
     const int jmin = rd.flip ? rd.len - q0 - 16 : q0;
     const bool bam4 = rd.fmt != PLO_SEQ_ASCII;
-    const int b0 = bam4 ? (jmin >> 1) : jmin;
+    int b0 = bam4 ? (jmin >> 1) : jmin;
+    miss = false;
+    if (rd.fmt == PLO_SEQ_BAM4_SPARSE) {
+        const int j0 = ok ? jmin : 0, j1 = ok ? jmin + 15 : 0;
+        const int g0 = j0 >> 5, g1 = j1 >> 5;
+        const PLO_GLOBAL uint32_t *hdr = (const PLO_GLOBAL uint32_t *)(ok ? rd.p : safe);
+        const uint32_t m0 = hdr[2 * (g0 >> 5)], rk0 = hdr[2 * (g0 >> 5) + 1], m1 = hdr[2 * (g1 >> 5)];
+        const bool present = (((m0 >> (g0 & 31)) & (m1 >> (g1 & 31))) & 1u) != 0u;
+        const unsigned rank = rk0 + (unsigned)__builtin_popcount(m0 & ((1u << (g0 & 31)) - 1u));
+        const long long off = (long long)rd.data + (long long)rank * 16 + ((j0 >> 1) & 15);
+        const bool bad = !present | (rank > 0x3ffffffu) | (off + (g1 - g0) * 16 + 20 > (long long)rd.hi);
+        miss = ok & bad;
+        ok = ok & !bad;
+        b0 = (int)off;
+    }
     const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
     ok = ok & (b0 - qsh >= rd.lo) & (b0 - qsh + 20 <= rd.hi);  // five words, whatever the format needs
     const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ok ? ref + (r0 - rsh) : safe);
@@ -230,28 +246,35 @@ PLO_DEV void xw16_decode(const ReadSeq &rd, const XW16 &wx, unsigned X[4]) {
     }
 }
 
-// The left breakend homology of one indel cluster (left_homology, lift_core.hpp), split in two: lane_probe_issue() does the
-// index checks of indel_breakend_homology.rs:32-39 and sends the loads of the first 16-base window; lane_probe_finish() turns
-// them into the match run and continues window by window (synchronously) in the rare case that all 16 bases agree.
+// The left breakend homology of one indel cluster (left_homology, lift_core.hpp), split in three: lane_probe_arm() does the
+// index checks of indel_breakend_homology.rs:32-39 when the cluster ends; lane_probe_load() sends the loads of the first 16-base
+// window -- at the top of the lane's NEXT round, so that the loads and their use (lane_probe_finish, at that round's event) lie in
+// one loop iteration with the scan between them: loads in flight across the loop's back edge are waited for right there (the
+// compiler copies loop-carried values at the back edge), which is what the first version of this stage did without meaning to;
+// lane_probe_finish() turns the words into the match run and continues window by window (synchronously) in the rare case that
+// all 16 bases agree.
 struct LaneProbe {
     XW16 w;
     int re = 0, qe = 0, maxk = 0;
     bool async_ok = false;
+    bool miss = false;  // sparse bases: the window's granule is absent
 };
-// Wave-uniform call that overwrites the probe of EVERY lane (none is pending when it is made: an event resolves the lane's pending
-// cluster first).  `on`: the lanes whose cluster ends; sets their `panic` where the reference's slice index would.
-PLO_DEV void lane_probe_issue(LaneProbe &p, bool on, const uint8_t *ref, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins,
-                              int bound, const uint8_t *safe, bool &panic) {
+// Wave-uniform call that overwrites the probe parameters of EVERY lane (none is pending when it is made: an event resolves the
+// lane's pending cluster first).  `on`: the lanes whose cluster ends; sets their `panic` where the reference's slice index would.
+PLO_DEV void lane_probe_arm(LaneProbe &p, bool on, int ref_len, int rs, int del, const ReadSeq &rd, int qs, int ins, int bound, bool &panic) {
     const int re = rs + del, qe = qs + ins;
     const int max_left = wv::imin(rs, qs);  // max_left_offset (:32)
     int maxk = wv::imin(max_left, bound);
     const bool bad = (max_left > 0) & ((re - 1 >= ref_len) | (qe - 1 >= rd.len));  // slice-index panic (:38-39)
     panic = panic | (on & bad);
     maxk = (bad | !on) ? 0 : maxk;
-    p.async_ok = xw16_issue(on & (maxk > 0), ref, ref_len, re - 16, rd, qe - 16, safe, p.w);
     p.re = re;
     p.qe = qe;
     p.maxk = maxk;
+}
+// wave-uniform call; `on`: the lanes with an armed cluster
+PLO_DEV void lane_probe_load(LaneProbe &p, bool on, const uint8_t *ref, int ref_len, const ReadSeq &rd, const uint8_t *safe) {
+    p.async_ok = xw16_issue(on & (p.maxk > 0), ref, ref_len, p.re - 16, rd, p.qe - 16, safe, p.w, p.miss);
 }
 PLO_DEV int match_run_back_from(const uint8_t *ref, int ref_len, int re, ReadSeq &rd, int qe, int maxk, int k, int &probes) {
     while (k < maxk) {
@@ -293,7 +316,8 @@ PLO_DEV int lane_probe_finish(const LaneProbe &p, bool on, const uint8_t *ref, i
     xw16_decode(rd, p.w, X);  // (registers only: harmless where nothing was loaded)
     const int n = wv::imin(16, p.maxk);
     const int m = wv::imin(top_zero_bytes(X), n);
-    const bool live = on & (p.maxk > 0);
+    rd.miss = rd.miss | (on & p.miss);  // absent bases: no homology is reported, the item is lifted again from the complete read
+    const bool live = on & (p.maxk > 0) & !p.miss;
     const bool fast = live & p.async_ok;
     int h = fast ? m : 0;
     probes += fast ? wv::imin(m + 1, n) : 0;
@@ -397,10 +421,18 @@ PLO_DEV void win_flush(LaneWin &w, bool on, int end) {
 // LDS and stored coalesced -- 37 % slower than every lane reading / writing its own 16 bytes: the extra LDS round trips cost more
 // than the scattered requests.)
 // -------------------------------------------------------------------------------------------------------------------
+// The block-map entries a group's liftover cursors read, staged in LDS: the items of a group are neighbours on a contig, their
+// windows into the block map overlap almost entirely, and the union -- a dozen entries or two -- goes into LANE_KVS entries of the
+// wave's LDS with one coalesced load per group.  The cursor then reads LDS (one ds_read_b64 per crossing, asked for at the top of
+// the iteration and used at its end) instead of global memory: the first version requested the entry after next from global memory at
+// every crossing and, because the value was carried across the loop's back edge, waited for it at the end of the same iteration --
+// an L2 round trip in every iteration of every group.  Items whose window lies outside the staged range keep the global loads.
+constexpr int LANE_KVS = 128;                  // staged entries per wave
+constexpr int LANE_KVS_DWORDS = 2 * LANE_KVS;  // behind the wave's slice (lds + capw) / windows (lds + 64 * LANE_WIN_DWORDS)
 template <bool SP, bool WIN = false>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
                        uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre,
-                       uint32_t *greg = nullptr) {
+                       uint32_t *greg = nullptr, uint32_t *kvs = nullptr) {
     // WIN (heavy items): `lds` = 64 x LANE_WIN_DWORDS dwords of LDS for the lanes' windows, `greg` = 64 regions of fixed_stride dwords
     // in global memory; else: `lds` = the wave's slice of capw dwords, the regions themselves.
     const int lane = wv::lane();
@@ -451,6 +483,22 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     const int n_ld = merges ? n_m : n_in;
     const int gap = has ? lane_region_gap(W0, W1) : 0;
     const int W = n_ld + gap + LANE_SLACK;  // dwords
+
+    // ---- block-map entries of the group -> LDS (loads now; the stores follow the LOAD pass, whose round trip covers this one) ----
+    int kvs_base = 0;
+    bool kv_lds = false, kvs_store = false;
+    KV kvs_e0 = {0, 0}, kvs_e1 = {0, 0};
+    if (kvs != nullptr && (stages & PLO_STAGE_LIFTOVER)) {
+        // the cursor of an item reads the entries [W0, min(kv1, W1 + 2)): its window and the look-ahead behind it
+        const int need_hi = wv::imin(kv1, W1 + 2);
+        kvs_base = -wv::reduce_max(has ? -W0 : -IMAX);
+        const int top = wv::reduce_max(has ? need_hi : 0);
+        const int cnt = wv::imax(0, wv::imin(top - kvs_base, LANE_KVS));
+        kv_lds = has & (need_hi <= kvs_base + cnt);
+        if (lane < cnt) kvs_e0 = ix.kv[kvs_base + lane];
+        if (lane + 64 < cnt) kvs_e1 = ix.kv[kvs_base + lane + 64];
+        kvs_store = true;
+    }
 
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
@@ -567,10 +615,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             const bool merge = ld & merges;
             const int inb = shift_on ? W - n_ld : gap;
             const int nmax = wv::reduce_max(ld ? n_in : 0);
+            const int n_cig = (int)bt.seg_cigar_off[bt.n_segs];  // ops in the batch's CIGAR buffer (wave-uniform)
             uint32_t run = 0;
             bool has_run = false;
             int w = 0;
-            // 16 bytes per load and lane (every lane reads its own CIGAR: four ops per request instead of one), two in flight
             if constexpr (WIN) win.wbase = inb;
             auto put = [&](bool on, uint32_t v) {
                 if constexpr (WIN) {
@@ -579,32 +627,49 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (on) R[inb + w] = v;
                 }
             };
-            for (int k0 = 0; k0 < nmax; k0 += 8) {
+            // LB ops per round trip: LB / 4 loads of 16 bytes per lane (every lane reads its own CIGAR), ALL of them in flight together.
+            // The loads are unconditional (lanes without a quad read plo_safe_words): a load inside a lane-divergent branch is waited
+            // for at the branch's end, one round trip per load -- the first version of this pass did that twice per eight ops.  A quad
+            // that reaches past its item (the item's last one) is read whole, the neighbour's ops masked below; only a quad that would
+            // leave the batch's buffer (first / last ops of the batch) sends the wave through the op-by-op loads.
+            constexpr int LB = 16;
+            for (int k0 = 0; k0 < nmax; k0 += LB) {
                 PLO_LC(10, 1)
                 if constexpr (WIN) {
-                    if (wv::ballot(ld & (inb + w - win.wbase > LANE_WW - 9)) != 0ull) win_flush(win, ld, inb + w);
+                    if (wv::ballot(ld & (inb + w - win.wbase > LANE_WW - (LB + 1))) != 0ull) win_flush(win, ld, inb + w);
                 }
-                uint32_t r[8];
+                uint32_t r[LB];
+                const uint32_t *qa[LB / 4];
+                bool edge = false;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < LB / 4; ++q) {
                     const int kq = k0 + 4 * q;
-                    uint32_t a[4] = {0u, 0u, 0u, 0u};
-                    if (ld && kq + 3 < n_in) {  // the ops kq .. kq+3 in walking order are four neighbours in memory
-                        const Ops4 v = *(const PLO_GLOBAL Ops4 *)(bt.cigar + (in_off + (rev ? n_in - 4 - kq : kq)));
-                        a[0] = rev ? v.w : v.x;
-                        a[1] = rev ? v.z : v.y;
-                        a[2] = rev ? v.y : v.z;
-                        a[3] = rev ? v.x : v.w;
-                    } else {
+                    const bool want = ld & (kq < n_in);
+                    const int gi = in_off + (rev ? n_in - 4 - kq : kq);  // the ops kq .. kq+3 in walking order are four neighbours in memory
+                    const bool inside = (gi >= 0) & (gi <= n_cig - 4);
+                    edge = edge | (want & !inside);
+                    qa[q] = (want & inside) ? bt.cigar + gi : (const uint32_t *)plo_safe_words;
+                }
+                if (wv::ballot(edge) == 0ull) {
+                    Ops4 v[LB / 4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ld && kq + j < n_in) a[j] = bt.cigar[in_off + (rev ? (n_in - 1 - kq - j) : kq + j)];
+                    for (int q = 0; q < LB / 4; ++q) v[q] = *(const PLO_GLOBAL Ops4 *)qa[q];
+#pragma unroll
+                    for (int q = 0; q < LB / 4; ++q) {
+                        r[4 * q] = rev ? v[q].w : v[q].x;
+                        r[4 * q + 1] = rev ? v[q].z : v[q].y;
+                        r[4 * q + 2] = rev ? v[q].y : v[q].z;
+                        r[4 * q + 3] = rev ? v[q].x : v[q].w;
                     }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) r[4 * q + j] = a[j];
+                    for (int j = 0; j < LB; ++j) {
+                        r[j] = 0u;
+                        if (ld && k0 + j < n_in) r[j] = bt.cigar[in_off + (rev ? (n_in - 1 - k0 - j) : k0 + j)];
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < LB; ++j) {
                     const bool have = ld & (k0 + j < n_in);
                     const uint32_t c = r[j];
                     const bool join = merge & have & has_run & b_is_match(op_type(c)) & b_is_match(op_type(run));
@@ -620,6 +685,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             if constexpr (WIN) win_flush(win, ld, inb + w);
             n = ld ? w : 0;
             cur_off = ld ? inb : 0;
+        }
+        if (kvs_store) {  // (wave-uniform; once per group)
+            kvs[2 * lane] = (uint32_t)kvs_e0.key;
+            kvs[2 * lane + 1] = (uint32_t)kvs_e0.val;
+            kvs[2 * (lane + 64)] = (uint32_t)kvs_e1.key;
+            kvs[2 * (lane + 64) + 1] = (uint32_t)kvs_e1.val;
+            kvs_store = false;
         }
         wv::sync();
 
@@ -646,9 +718,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             int p_match = 0, p_ins = 0, p_del = 0, msince = 0, probes = 0;
             LaneProbe pr;
             PLO_MARK("SHIFT LOOP BEGIN");
-            while (wv::ballot(!fin) != 0ull) {
+            for (unsigned long long bm; (bm = wv::ballot(!fin)) != 0ull;) {
                 PLO_LC(8, 1)
+                ctx.u_act += (unsigned)__builtin_popcountll(bm);
+                ctx.u_trips += 1;
                 wr_room(o, shift_on, gap);
+                // the probes of the clusters that ended at the lanes' last events go out now: their round trips run under this round's scan
+                if (wv::ballot(pend) != 0ull) lane_probe_load(pr, pend, sref, shift_ref_len, rd, (const uint8_t *)plo_safe_words);
                 // scan to the next event (not consumed)
                 bool stop = fin, ev_other = false, ev_end = false;
                 int ev_t = 0, ev_L = 0;
@@ -700,16 +776,20 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     msince = on ? 0 : msince;
                     pend = pend & !on;
                 };
-                // Pass 0: the pending cluster first (every event needs the builder's match run), then this cluster's probe -- the match
-                // run is exact there, nothing is pending.  Pass 1 (rare): a cluster directly in front of a flushing op or of the end has
-                // no ops to hide its probe under and is resolved at once.  One copy of the code for both (the probe's slow paths are large).
+                // Pass 0: the pending cluster first (every event needs the builder's match run), then this cluster's probe is armed -- the
+                // match run is exact there, nothing is pending; its loads go out at the top of the next round.  Pass 1 (rare): a cluster
+                // directly in front of a flushing op or of the end has no ops to hide its probe under: loads and resolution at once.  One
+                // copy of the resolving code for both (the probe's slow paths are large).
 #pragma nounroll
                 for (int pass = 0; pass < 2; ++pass) {
                     const bool res = (pass == 0 ? evl : flushing) & pend;
-                    if (wv::ballot(res) != 0ull) resolve(res);
+                    if (wv::ballot(res) != 0ull) {
+                        if (pass == 1) lane_probe_load(pr, res, sref, shift_ref_len, rd, (const uint8_t *)plo_safe_words);
+                        resolve(res);
+                    }
                     if (pass == 1) break;
                     if (wv::ballot(endc) != 0ull) {
-                        lane_probe_issue(pr, endc, sref, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, (const uint8_t *)plo_safe_words, panic);
+                        lane_probe_arm(pr, endc, shift_ref_len, blk_ref, del, rd, blk_read, ins, match, panic);
                         p_match = endc ? match : p_match;
                         p_ins = endc ? ins : p_ins;
                         p_del = endc ? del : p_del;
@@ -769,21 +849,32 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             int t = 0, seg_start = pos, seg_end = 0, block_pos = 0, r2s = 0, r2e = 0;
             int kb = 0, vb = NONE32, kn = IMAX, vn = NONE32, kf = IMAX, vf = NONE32;
             int ni = W0 + 2;  // index of the entry to request at the next crossing
-            if (lo_on) {
-                if (W0 < kv1) {
-                    const KV e = ix.kv[W0];
-                    kn = e.key;
-                    vn = e.val;
+            // entry `idx` of the block map for the lanes `on`: from the staged copy, or (items outside it) from global memory
+            auto kv_fetch = [&](bool on, int idx, int &key, int &val) {
+                if (kvs != nullptr) {
+                    const bool l = on & kv_lds & ((unsigned)(idx - kvs_base) < (unsigned)LANE_KVS);
+                    const uint32_t *q = kvs + 2 * (l ? idx - kvs_base : 0);
+                    const int lk = (int)q[0], lv = (int)q[1];
+                    key = l ? lk : key;
+                    val = l ? lv : val;
+                    on = on & !l;
                 }
-                if (W0 + 1 < kv1) {
-                    const KV e = ix.kv[W0 + 1];
-                    kf = e.key;
-                    vf = e.val;
+                const bool gl = on;
+                if (wv::ballot(gl) != 0ull) {
+                    if (gl) {
+                        const KV e = ix.kv[idx];
+                        key = e.key;
+                        val = e.val;
+                    }
                 }
-            }
+            };
+            kv_fetch(lo_on & (W0 < kv1), W0, kn, vn);
+            kv_fetch(lo_on & (W0 + 1 < kv1), W0 + 1, kf, vf);
             PLO_MARK("LIFTOVER LOOP BEGIN");
-            while (wv::ballot(lo_on & ((k < n) | in_op)) != 0ull) {
+            for (unsigned long long bm; (bm = wv::ballot(lo_on & ((k < n) | in_op))) != 0ull;) {
                 PLO_LC(7, 1)
+                ctx.u_act += (unsigned)__builtin_popcountll(bm);
+                ctx.u_trips += 1;
                 // the next op, unless one is being cut into pieces
                 const bool fetch = lo_on & !in_op & (k < n);
                 wr_room(o, lo_on, 0);
@@ -801,18 +892,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 // the piece starts in the next block (get_ref_range walks on, read_to_ref_map.rs:79-84)
                 const bool adv = in_op & (kn <= block_pos);
                 int fk = IMAX, fv = NONE32;
-                if (adv && ni < kv1) {
-                    const KV e = ix.kv[ni];
-                    fk = e.key;
-                    fv = e.val;
-                }
+                kv_fetch(adv & (ni < kv1), ni, fk, fv);  // (used at the end of the iteration)
                 kb = adv ? kn : kb;
                 vb = adv ? vn : vb;
                 bvalid = bvalid | adv;
                 kn = adv ? kf : kn;
                 vn = adv ? vf : vn;
-                kf = adv ? fk : kf;
-                vf = adv ? fv : vf;
                 ni += adv ? 1 : 0;
                 // (kn <= block_pos still: the shift stage moved the start past another key; the walk goes on next iteration)
                 const bool piece = in_op & (kn > block_pos);
@@ -837,6 +922,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 const int wl = ext ? W : cur_off + k;  // ops below R[cur_off + k] have been read
                 lane_push<false, ST>(o, e0, OP_D, d, wl);
                 lane_push<false, ST>(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
+                kf = adv ? fk : kf;  // the entry after next (kv_fetch above)
+                vf = adv ? fv : vf;
             }
             PLO_MARK("LIFTOVER LOOP END");
             PLO_LT(3)
@@ -1086,7 +1173,7 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         if (t < t0 + t1) {
             uint32_t lo, hi;
             group(t, lo, hi);
-            lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g);
+            lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
             wv::sync();
         }
     }
@@ -1103,7 +1190,7 @@ PLO_DEV void lane_heavy_persistent(const DevIndex &ix, const DevBatch &bt, const
         const bool c1 = t >= t0;
         const uint32_t b = c1 ? mid + (t - t0) * per : lo + t * per, e = c1 ? hi : mid;
         const uint32_t n = e - b < per ? e - b : per;
-        lane_tile<SP, true>(ix, bt, wk, stages, b, (int)n, windows, 0x7fffffff, stride, ctx, wk.perm, false, 0u, regions);
+        lane_tile<SP, true>(ix, bt, wk, stages, b, (int)n, windows, 0x7fffffff, stride, ctx, wk.perm, false, 0u, regions, windows + 64 * LANE_WIN_DWORDS);
         wv::sync();
     }
 }

@@ -754,11 +754,15 @@ struct WaveCtx {
     unsigned algo_bytes = 0;
     unsigned in_ops = 0;
     unsigned out_ops = 0;
+    // lane-per-item kernels: lanes at work and trips of the liftover loop and of the shift stage's event rounds (wave-uniform; from the
+    // loops' own ballots, scalar instructions only) -> plo_timing::lane_utilisation
+    unsigned long long u_act = 0, u_trips = 0;
 #ifdef PLO_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader cycles per pipeline phase, flushed once per wave
 #endif
 };
 constexpr unsigned long long SLAB_OPS = 16384;
+constexpr int STAT_WORDS = 8;  // 64-bit words per statistics slot of a wave (five in use)
 
 // A retiring wave leaves its statistics in its own slot (plain stores): 3 atomics per wave on one cache line used to cost a
 // fixed ~75 us per launch (3 072 waves x 3 atomics at ~88 per microsecond and address).  k_sum_stats adds the slots up.
@@ -770,11 +774,15 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx, uint32_t slot) {
     unsigned olo = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops & 0xffffffu));
     unsigned ohi = (unsigned)wv::reduce_add((int)(unsigned)(ctx.out_ops >> 24));
     if (wv::lane() == 0) {
-        unsigned long long *w = wk.wave_stats + (size_t)(wk.stat_base + slot) * 4;
+        unsigned long long *w = wk.wave_stats + (size_t)(wk.stat_base + slot) * STAT_WORDS;
         w[0] = (unsigned long long)lo + ((unsigned long long)hi << 24);
         w[1] = (unsigned long long)nlo + ((unsigned long long)nhi << 24);
         w[2] = (unsigned long long)olo + ((unsigned long long)ohi << 24);
+        w[3] = ctx.u_act;
+        w[4] = ctx.u_trips;
     }
+    ctx.u_act = 0;
+    ctx.u_trips = 0;
     ctx.algo_bytes = 0;
     ctx.in_ops = 0;
     ctx.out_ops = 0;

@@ -52,7 +52,7 @@ struct DevBatch {
     uint32_t n_reads, n_segs;
 };
 
-enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_NHUGE = 20, CNT_NMISS = 21, CNT_N = 24 };
+enum { CNT_CIGAR = 0, CNT_OVERFLOW = 1, CNT_NBIG = 2, CNT_ALGO_BYTES = 3, CNT_IN_OPS = 4, CNT_ERROR = 5, CNT_OUT_OPS = 6, CNT_NRETRY = 7, CNT_PHASE0 = 8, CNT_NHUGE = 20, CNT_NMISS = 21, CNT_LANE_ACT = 22, CNT_LANE_TRIPS = 23, CNT_N = 24 };
 
 // Resolved per-item descriptors, written once per batch by the item kernels (thread per item, full occupancy) so that
 // the tile kernel starts from ONE level of coalesced loads instead of chasing item -> segment -> contig -> block map.

@@ -134,13 +134,15 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.cig_off = o->cig_off.data();
     wk.cig_len = o->cig_len.data();
     wk.counters = counters;
-    unsigned long long wave_stats[4] = {0, 0, 0, 0};  // the emulated waves run one after another: one slot, summed after each
+    unsigned long long wave_stats[STAT_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};  // the emulated waves run one after another: one slot, summed after each
     wk.wave_stats = wave_stats;
     auto sum_stats = [&]() {  // k_sum_stats
         counters[CNT_ALGO_BYTES] += wave_stats[0];
         counters[CNT_IN_OPS] += wave_stats[1];
         counters[CNT_OUT_OPS] += wave_stats[2];
-        wave_stats[0] = wave_stats[1] = wave_stats[2] = 0;
+        counters[CNT_LANE_ACT] += wave_stats[3];
+        counters[CNT_LANE_TRIPS] += wave_stats[4];
+        wave_stats[0] = wave_stats[1] = wave_stats[2] = wave_stats[3] = wave_stats[4] = 0;
     };
     wk.big_list = big_list.data();
     wk.huge_list = huge_list.data();
@@ -200,7 +202,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             for (uint32_t i = 0; i < n_items; ++i) max_w = std::max(max_w, item_nin[i]);
             int stride = (int)((max_w + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
             if (const char *e = getenv("PLO_EMU_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;  // (regions too small for the longer items: retry list)
-            std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS, 0xdeadbeefu);
+            std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS + LANE_KVS_DWORDS, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
@@ -216,7 +218,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         // (items per group as the host picks them for small batches: 64 without an order seed, else 64 / 32 / 16 / 8 by the seed)
         const uint32_t lane_group = order_seed ? 64u >> (order_seed % 4u) : 64u;
         if (n_small) {  // k_lift_lanes: persistent waves over the groups of the two lane classes
-            std::vector<uint32_t> llds((size_t)lane_capw + 16, 0xdeadbeefu);
+            std::vector<uint32_t> llds((size_t)lane_capw + LANE_KVS_DWORDS + 16, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;

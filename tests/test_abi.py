@@ -40,10 +40,27 @@ def test_version_string(lib_path):
     assert b"gfx950" in L.plo_version()
 
 
+def test_api_version_matches_header(lib_path):
+    text = open(os.path.join(ROOT, "include", "portello_liftover.h")).read()
+    v = int(re.search(r"#define PLO_API_VERSION (\d+)", text).group(1))
+    L = api.load_library(lib_path)
+    assert L.plo_api_version() == v == abi.PLO_API_VERSION
+
+
+def test_timing_getter_respects_struct_size(lib_path):
+    # API version 4: the callee writes no more than the caller's struct holds; without a size it refuses.  (No device needed:
+    # a NULL context is rejected first, so only the argument contract is visible from here.)
+    L = api.load_library(lib_path)
+    t = abi.PloTiming()
+    assert L.plo_ctx_timing(None, C.byref(t)) == abi.PLO_ERR_INVALID_ARG
+
+
 def test_ctypes_struct_layout_matches_header():
     # sizes implied by the header on LP64
     assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8
-    assert C.sizeof(abi.PloTiming) == 4 * 4 + 2 * 4 + 3 * 8 + 4 * 4 + 2 * 4 + 2 * 4 + 2 * 4 + 2 * 4
+    # struct_size + 4 floats + 2 u32 | 3 u64 | 4 + 2 + 2 + 2 + 2 + 1 four-byte fields (+ tail padding to 8)
+    assert C.sizeof(abi.PloTiming) == 8 * 4 + 3 * 8 + 14 * 4
+    assert abi.PloTiming.struct_size.offset == 0 and abi.PloTiming.n_in_ops.offset == 32
     assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8 + 2 * 8
     assert C.sizeof(abi.PloIndexDesc) == 8 + 2 * 8 + 8 + 8 * 8 + 8 + 3 * 8 + 8
 
