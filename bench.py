@@ -375,6 +375,31 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
     index.close()
 
 
+
+def finalize(result) -> int:
+    """A result whose records differ from the checker's is not a measurement: `parity_sample_ok` false, a failed `end_to_end`
+    verification or a gathered record set that differs from the single-GPU one => "parity_failed": true, "value": null (the number
+    stays in `value_unverified`) and a non-zero exit code."""
+    result.setdefault("value_kind", "hbm_resident_kernel_rate")  # `value` is NOT an end-to-end BAM->BAM rate (that is `end_to_end`)
+    why = []
+    if result.get("parity_sample_ok") is False:
+        why.append("sampled items differ from the oracle")
+    e2e = result.get("end_to_end") or {}
+    if e2e.get("records_verified") == 0 and "verification" in e2e:
+        why.append("end_to_end: the written BAM differs from the expected records")
+    if (e2e.get("device_finished") or {}).get("records_verified") == 0:
+        why.append("end_to_end (device-finished records): the written BAM differs from the expected records")
+    if (result.get("verify") or {}).get("gathered_equals_single_gpu_result") is False:
+        why.append("gathered records differ from the single-GPU result")
+    if why:
+        result["parity_failed"] = True
+        result["parity_failure"] = why
+        result["value_unverified"] = result.get("value")
+        result["value"] = None
+        return 3
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,7 +466,10 @@ def main():
     cfg = synth.config(args.workload, **over)
     chunk_reads = args.chunk_reads or (250_000 if cfg.name.startswith("stress") else 8_000_000)
     if world == 1 and dist is None and cfg.n_reads > chunk_reads:
-        return stream_main(args, cfg, dev, dev_index, chunk_reads)
+        rc = stream_main(args, cfg, dev, dev_index, chunk_reads)
+        if rc:
+            sys.exit(rc)
+        return
     t0 = time.perf_counter()
     w = synth.generate(cfg, device=dev)
     torch.cuda.synchronize()
@@ -844,13 +872,17 @@ def main():
         except Exception as e:  # the baseline must never hide the measurement
             log(f"[bench] cpu_baseline failed: {e!r}")
             result["cpu_baseline"] = None
+    rc = 0
     if rank == 0:
+        rc = finalize(result)
         print(json.dumps(result), flush=True)
     for e in engs:
         e.close()
     index.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -56,7 +56,10 @@ void plo_bam_close(plo_bam_reader *r);
 plo_status plo_bam_header(const plo_bam_reader *r, const char **text, uint32_t *l_text, uint32_t *n_ref,
                           const char *const **ref_names, const uint32_t **ref_lens);
 
-/* Next window of the file: at most max_records primary records (fewer at the end of the file; 0 = end).
+/* Next window of the file: at most max_records primary records.  A window also ends after 4 x max_records + 1024 unmapped
+ * records or 1 GB of records, so a window with 0 primary records is NOT the end of the file (the unmapped tail of a sorted BAM
+ * comes as several such windows).  The end of the file is a window with 0 primary AND 0 unmapped records -- or, without
+ * counting, plo_bam_window_eof() != 0: the stream ended inside or right behind this window (its records, if any, are the last).
  * Records are classified as the reference does:
  *   unmapped flag set, no reference id    -> pass-through list (scan_unmapped_reads :551-555)
  *   unmapped flag set, reference id >= 0  -> PLO_ERR_DATA (the reference's window loop asserts !is_unmapped(), :396)
@@ -72,6 +75,8 @@ void plo_bam_set_device_inflate(plo_bam_reader *r, int device); /* HIP device in
 plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_window **out);
 void plo_bam_window_free(plo_bam_window *w);
 uint32_t plo_bam_window_n_records(const plo_bam_window *w);
+/* 1: the reader reached the end of the file while collecting this window (nothing follows it), 0: more windows follow */
+int plo_bam_window_eof(const plo_bam_window *w);
 /* unmapped records of the window's stretch of the file as BAM record bytes (block_size prefixed), ready for
    plo_bam_write to the "unassembled" output */
 void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records);

@@ -296,6 +296,8 @@ typedef struct plo_finish_out {
     const uint8_t *rev_qual;
     uint64_t rev_seq_bytes, rev_qual_bytes;
     float finish_ms, revcomp_ms;   /* HIP-event times of the two kernels groups                        */
+    uint32_t n_items, n_reads;     /* extents of the per-item / per-read arrays: the batch they were made for (API version 4;
+                                      plo_records_build_finished refuses arrays of another batch before indexing them) */
 } plo_finish_out;
 
 plo_status plo_finish_batch_dev(plo_ctx *ctx, const plo_batch_in *in, const plo_finish_in *fin, plo_finish_out *out);

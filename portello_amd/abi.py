@@ -159,6 +159,7 @@ class PloFinishOut(C.Structure):
         ("read_seq_off", _u64p), ("read_qual_off", _u64p),
         ("rev_seq", _u8p), ("rev_qual", _u8p), ("rev_seq_bytes", C.c_uint64), ("rev_qual_bytes", C.c_uint64),
         ("finish_ms", C.c_float), ("revcomp_ms", C.c_float),
+        ("n_items", C.c_uint32), ("n_reads", C.c_uint32),
     ]
 
 

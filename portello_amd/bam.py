@@ -44,6 +44,8 @@ def lib():
         L.plo_bam_window_free.argtypes = [vp]
         L.plo_bam_window_n_records.restype = C.c_uint32
         L.plo_bam_window_n_records.argtypes = [vp]
+        L.plo_bam_window_eof.restype = C.c_int
+        L.plo_bam_window_eof.argtypes = [vp]
         L.plo_bam_window_unmapped.restype = None
         L.plo_bam_window_unmapped.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.plo_bam_window_batch.restype = C.c_int
@@ -116,6 +118,11 @@ class Window:
     @property
     def n_records(self) -> int:
         return int(lib().plo_bam_window_n_records(self.handle))
+
+    @property
+    def eof(self) -> bool:
+        """the reader reached the end of the file while collecting this window: nothing follows it"""
+        return bool(lib().plo_bam_window_eof(self.handle))
 
     def unmapped_bytes(self) -> Tuple[bytes, int]:
         p, n, k = C.POINTER(C.c_uint8)(), C.c_uint64(), C.c_uint32()

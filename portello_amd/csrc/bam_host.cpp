@@ -31,6 +31,8 @@ struct plo_bam_window {
     std::vector<uint64_t> rec_at;   // [n] offset (of the block_size word) of every primary record inside raw
     std::vector<uint8_t> unmapped;
     uint32_t n_unmapped = 0;
+    bool eof = false;           // the stream ended while this window was collected
+    int batch_kind = 0;         // 0: no batch built yet, 1: plo_bam_window_batch (dense bases), 2: plo_bam_window_batch_sparse
     // batch (plo_batch_in) arrays
     HostBuf b_rev, b_len, b_soff, b_seq, b_seg_read, b_seg_contig, b_seg_pos, b_seg_fwd, b_coff, b_cigar, b_flags, b_qual, b_qoff, b_full_off;
     std::vector<uint32_t> read_seg_off;  // [n + 1] first segment of every read
@@ -136,7 +138,10 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     while (w->rec_at.size() < max_records) {
         if (unm_at.size() >= unm_cap || (at >= byte_cap && w->rec_at.size() + unm_at.size() > 0)) break;
         if (r->in.avail() < at + 4 && (st = timed_fill(at + 4)) != PLO_OK) break;
-        if (r->in.avail() == at) break;  // end of file
+        if (r->in.avail() == at) {  // end of file
+            w->eof = true;
+            break;
+        }
         if (r->in.avail() < at + 4) {
             st = fail(PLO_ERR_IO, "truncated BAM record");
             break;
@@ -197,6 +202,7 @@ void plo_bam_set_device_inflate(plo_bam_reader *r, int device) {
 }
 void plo_bam_window_free(plo_bam_window *w) { delete w; }
 uint32_t plo_bam_window_n_records(const plo_bam_window *w) { return w ? w->n_records() : 0; }
+int plo_bam_window_eof(const plo_bam_window *w) { return (w && w->eof) ? 1 : 0; }
 void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records) {
     if (bytes) *bytes = w ? w->unmapped.data() : nullptr;
     if (n_bytes) *n_bytes = w ? w->unmapped.size() : 0;
@@ -486,6 +492,7 @@ static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finis
         fin->read_qual_off = qoff;
         fin->qual_bytes = n_qual[n];
     }
+    w->batch_kind = sparse ? 2 : 1;
     return PLO_OK;
 }
 
@@ -706,6 +713,8 @@ static plo_status records_build(plo_bam_window *w, const plo_batch_out *lift, co
                 ok = fin->item_seq_off[i] == PLO_NO_FLIP ||
                      (fin->item_seq_off[i] <= fin->rev_seq_bytes && sb <= fin->rev_seq_bytes - fin->item_seq_off[i] &&
                       fin->item_qual_off[i] <= fin->rev_qual_bytes && qb <= fin->rev_qual_bytes - fin->item_qual_off[i]);
+                // a record has flipped bases exactly when the lift says it needs them (a stale array would give silently wrong bases)
+                ok = ok && ((fin->item_seq_off[i] != PLO_NO_FLIP) == (lift->item_need_flipped[i] != 0));
                 if (ok && sa) ok = sa->item_sa_off[i] <= sa->item_sa_off[i + 1] && sa->item_sa_off[i + 1] <= sa->sa_bytes;
             }
             if (!ok) {
@@ -939,6 +948,13 @@ extern "C" plo_status plo_records_build_finished(plo_bam_window *w, const plo_ba
         return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: incomplete plo_finish_out (host copies of every array are needed)");
     if (sa && (sa->n_items != lift->n_items || !sa->item_sa_off || (sa->sa_bytes && !sa->sa_text)))
         return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: plo_sa_out does not belong to this result");
+    // the finished arrays carry their extents (API version 4): arrays of another (smaller) batch are refused before they are indexed
+    if (!w || !lift || fin->n_items != lift->n_items || fin->n_reads != w->n_records())
+        return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: the finished arrays do not belong to this lift result (plo_finish_out::n_items / n_reads "
+                                         "differ from the result's items / the window's reads)");
+    if (w->batch_kind == 2)
+        return fail(PLO_ERR_INVALID_ARG, "plo_records_build_finished: the window's batch was built with sparse bases (plo_bam_window_batch_sparse); records "
+                                         "finished on the device need the dense batch (plo_bam_window_batch)");
     return records_build(w, lift, fin, sa, pr, out);
 }
 

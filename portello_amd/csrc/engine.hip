@@ -236,14 +236,14 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_t
 // which also reduces the weights the host sizes buffers by), an exclusive scan of the block counts (k_cls_scan, one workgroup),
 // and the permutation itself from block offset + rank inside the block (k_permute2).
 constexpr uint32_t CLS_THREADS = 256, CLS_PER = 8, CLS_BLOCK = CLS_THREADS * CLS_PER;
-// partial: [5][nb] per block: items of class 0 / 1 / 2, heaviest item, sum of the weights (a block's 2 048 weights of < 2^21 fit 32 bits);
-// totals (k_cls_scan): [0..2] class counts, [3] heaviest item, [4..5] 64-bit sum of the weights
+// partial: [6][nb] per block: items of class 0 / 1 / 2, heaviest item, sum of the weights (exact, 64 bits as two words: the batch-size
+// guard and the output sizing rest on it); totals (k_cls_scan): [0..2] class counts, [3] heaviest item, [4..5] 64-bit sum of the weights
 __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial) {
-    __shared__ uint32_t acc[5];
-    if (threadIdx.x < 5) acc[threadIdx.x] = 0;
+    __shared__ uint32_t acc[6];
+    if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
-    uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0, sw = 0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0, sl = 0, sh = 0;  // sl / sh: sums of the weights' low / high 16 bits (a block's fit 32 bits each)
     for (uint32_t k = 0; k < CLS_PER; ++k) {
         if (base + k < n) {
             const uint32_t c = item_cls[base + k], w = item_w[base + k];
@@ -251,21 +251,23 @@ __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_c
             c1 += c == 1;
             c2 += c == 2;
             mw = w > mw ? w : mw;
-            sw += w < 0x1fffffu ? w : 0x1fffffu;  // (heavier items are beyond every kernel's reach anyway; the sum only sizes buffers)
+            sl += w & 0xffffu;
+            sh += w >> 16;
         }
     }
     // (counts of a wave fit 16 bits: 64 threads x 8 items)
     const int p01 = wv::reduce_add((int)(c0 | (c1 << 16))), p2 = wv::reduce_add((int)c2), pm = wv::reduce_max((int)(mw & 0x7fffffffu));
-    const int ps = wv::reduce_add((int)sw);
+    const int psl = wv::reduce_add((int)sl), psh = wv::reduce_add((int)sh);
     if ((threadIdx.x & 63u) == 0) {
         atomicAdd(&acc[0], (uint32_t)p01 & 0xffffu);
         atomicAdd(&acc[1], (uint32_t)p01 >> 16);
         atomicAdd(&acc[2], (uint32_t)p2);
         atomicMax(&acc[3], (uint32_t)pm);
-        atomicAdd(&acc[4], (uint32_t)ps);
+        atomicAdd(&acc[4], (uint32_t)psl);
+        atomicAdd(&acc[5], (uint32_t)psh);
     }
     __syncthreads();
-    if (threadIdx.x < 5) partial[threadIdx.x * nb + blockIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x < 6) partial[threadIdx.x * nb + blockIdx.x] = acc[threadIdx.x];
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, uint32_t nb, uint32_t *totals) {
     __shared__ unsigned wt[4];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, ui
     unsigned long long sum = 0;
     for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS) {
         mx = partial[3 * nb + i] > mx ? partial[3 * nb + i] : mx;
-        sum += partial[4 * nb + i];
+        sum += (unsigned long long)partial[4 * nb + i] + ((unsigned long long)partial[5 * nb + i] << 16);
     }
     __shared__ unsigned long long ssum;
     __shared__ unsigned smax;
@@ -1522,7 +1524,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     {
         HIP_TRY(c, c->misc.ensure(256));
         HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
-        HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 5 * 4));
+        HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 6 * 4));
         uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;  // clear of h[0..47] below
         memset(m_, 0, 8 * 4);
         if (n_items) {
@@ -1620,8 +1622,25 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     wk.n_small = n_small;
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
+    // launch geometry of the lane-per-item kernel (light items), needed here already: its waves own one output slab each from the start
+    uint32_t lane_gs = 64, lane_nblk = 0;
+    const size_t lane_lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;  // slices + staged block-map entries
+    if (n_small) {
+        int occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lane_lds) != hipSuccess || occ < 1)
+            occ = 1;
+        // items per group: 64, fewer when that leaves resident waves without a group (small batches; the few light items of an
+        // indel-dense batch, whose regions would also take a wave's LDS slice several rounds at 64 a group)
+        const uint32_t n0 = h_cls[0], n1 = h_cls[1];
+        const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
+        while (lane_gs > 8u && (n0 + lane_gs / 2 - 1) / (lane_gs / 2) + (n1 + lane_gs / 2 - 1) / (lane_gs / 2) <= slots) lane_gs >>= 1;
+        if (const char *e = getenv("PLO_LANE_GROUP")) lane_gs = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
+        const uint32_t groups = (n0 + lane_gs - 1) / lane_gs + (n1 + lane_gs - 1) / lane_gs;
+        lane_nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
+        lane_nblk = (lane_nblk + 7u) & ~7u;
+    }
     size_t want_cigar = (size_t)all_ops * 2 + (size_t)n_items * 8 + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS +
-                        (n_small ? (size_t)std::min<uint32_t>((n_small >> 8) + 8, (uint32_t)c->n_cus * 16) * LANE_WAVES * SLAB_OPS : 0);
+                        (size_t)lane_nblk * LANE_WAVES * SLAB_OPS;  // (exactly the slabs the lane kernel's waves pre-own: slab_offset below)
     if (c->o_cigar.cap < want_cigar * 4) HIP_TRY(c, c->o_cigar.ensure(want_cigar * 4));
 
     if (c->seq_pending) {  // (plo_liftover_batch: the read bases arrive on the copy stream)
@@ -1646,21 +1665,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
                                    (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
             }
-            const size_t lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;  // slices + staged block-map entries
-            int occ = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lds) != hipSuccess || occ < 1)
-                occ = 1;
-            // items per group: 64, fewer when that leaves resident waves without a group (small batches; the few light items of an
-            // indel-dense batch, whose regions would also take a wave's LDS slice several rounds at 64 a group)
-            uint32_t gs = 64;
-            {
-                const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
-                while (gs > 8u && (n0 + gs / 2 - 1) / (gs / 2) + (n1 + gs / 2 - 1) / (gs / 2) <= slots) gs >>= 1;
-                if (const char *e = getenv("PLO_LANE_GROUP")) gs = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
-            }
-            const uint32_t groups = (n0 + gs - 1) / gs + (n1 + gs - 1) / gs;
-            uint32_t nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
-            nblk = (nblk + 7u) & ~7u;
+            const size_t lds = lane_lds;
+            const uint32_t gs = lane_gs, nblk = lane_nblk;
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
@@ -1735,12 +1741,19 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             // Items of tiles whose intermediates overflowed the slice (and items the lane kernel handed on), one per wave with a slice of twice the threshold (the shift /
             // simplify stages at most double an item's ops).  Launched without asking the host how many there are: the kernel reads
             // the count the tile kernel left (mostly zero -- a few microseconds -- and a host round trip less when it is not).
-            const int retry_cap = std::min(4096, std::max(c->cap, (2 * c->big_thresh + 64 + 63) & ~63));
+            // Batches without tiles (light items only, or heavy items through the lane code) have computed no tile geometry: the routing
+            // threshold then comes from the batch's heaviest item, not from whatever an earlier batch left in the context.
+            int r_thresh = c->big_thresh, r_cap = c->cap;
+            if (c->adaptive && !(n_items > n_small && !heavy_lanes)) {
+                r_thresh = heavy_lanes ? (int)std::min<uint32_t>(std::max<uint32_t>(256u, max_nin), 2016u) : 256;
+                r_cap = 320;
+            }
+            const int retry_cap = std::min(4096, std::max(r_cap, (2 * r_thresh + 64 + 63) & ~63));
             uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15);
             uint32_t nw = (uint32_t)c->n_cus * 2u;
             PLO_STAT_RANGE(nw);
-            if (sp) hipLaunchKernelGGL(k_lift_retry_sp, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, c->big_thresh, retry_cap);
-            else hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, c->big_thresh, retry_cap);
+            if (sp) hipLaunchKernelGGL(k_lift_retry_sp, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, r_thresh, retry_cap);
+            else hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, r_thresh, retry_cap);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[5], st));
@@ -2037,6 +2050,8 @@ plo_status plo_finish_batch_dev(plo_ctx *c, const plo_batch_in *in, const plo_fi
     out->rev_qual = f.rev_qual;
     out->rev_seq_bytes = sb;
     out->rev_qual_bytes = qb;
+    out->n_items = n;
+    out->n_reads = nr;
     c->have_finish = true;
     return PLO_OK;
 }

@@ -527,7 +527,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         uint32_t *R = WIN ? nullptr : lds + (act0 ? incl - wv_ : 0);
         LaneWin win;
         if constexpr (WIN) {
-            win.G = greg + (size_t)lane * (size_t)fixed_stride;
+            // (lanes without an item point at the wave's first region: the writer's clean-up reads o.R[0] unconditionally, and with fewer
+            // than 64 items per wave the regions of the lanes beyond them lie outside the wave's -- for the last wave, outside the buffer's --
+            // scratch; found by tests/test_fuzz_parity.py::test_fuzz_hip_heavy_lane_kernel[5] as a GPU memory fault)
+            win.G = greg + (size_t)(has ? lane : 0) * (size_t)fixed_stride;
             win.rw = lds + lane;
             win.ww = lds + LANE_RW * 64 + lane;
         }

@@ -254,6 +254,7 @@ class HostResults:
         self.fin.rev_seq = dl(fo.rev_seq, np.uint8, int(fo.rev_seq_bytes), C.c_uint8)
         self.fin.rev_qual = dl(fo.rev_qual, np.uint8, int(fo.rev_qual_bytes), C.c_uint8)
         self.fin.finish_ms, self.fin.revcomp_ms = fo.finish_ms, fo.revcomp_ms
+        self.fin.n_items, self.fin.n_reads = n, n_reads
         self.sa = None
         if so is not None:
             self.sa = abi.PloSaOut()

@@ -161,17 +161,20 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 put(q_in, None)
 
     def lifter(k):
-        if device_finish:
-            import torch
-
-            from . import devbatch
-            dev = torch.device("cuda", index.device)
-            tstream = torch.cuda.Stream(device=dev)  # uploads, kernels and downloads of this worker, in order
-            eng = api.Engine(index, stream=tstream.cuda_stream)
-            sa_in, _sa_keep = devbatch.sa_inputs(ref_names, dev)
-        else:
-            eng = api.Engine(index)
+        eng = None
         try:
+            # the set-up is inside the try: a failure here (no CUDA torch, out of memory, a bad device) must set `abort` and still post
+            # the worker's sentinel, or the writer waits for it forever and the run hangs instead of raising
+            if device_finish:
+                import torch
+
+                from . import devbatch
+                dev = torch.device("cuda", index.device)
+                tstream = torch.cuda.Stream(device=dev)  # uploads, kernels and downloads of this worker, in order
+                eng = api.Engine(index, stream=tstream.cuda_stream)
+                sa_in, _sa_keep = devbatch.sa_inputs(ref_names, dev)
+            else:
+                eng = api.Engine(index)
             while True:
                 item = get(q_in)
                 if item is None:
@@ -215,7 +218,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.errors.append(f"lift worker {k}: {e!r}")
             abort.set()
         finally:
-            eng.close()
+            if eng is not None:
+                eng.close()
             put(q_out, None)
 
     def writer():

@@ -445,6 +445,7 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
     out->read_primary_item = f.read_primary_item; out->read_unmapped_flag = f.read_unmapped_flag; out->read_seq_off = f.read_seq_off;
     out->read_qual_off = f.read_qual_off_out; out->rev_seq = rs; out->rev_qual = rq;
     out->rev_seq_bytes = (uint64_t)o->soff[ne] * 16u; out->rev_qual_bytes = (uint64_t)o->qoff[ne] * 16u;
+    out->n_items = n; out->n_reads = ne - n;
     return 0;
 }
 

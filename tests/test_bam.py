@@ -3,6 +3,7 @@
  - oracle/pyrecords.py, the pure-Python restatement of the record logic (byte for byte),
  - tests/bamcheck.py, an independent reader of the files the BGZF writer produces.
 CPU tests use the C oracle for the lifted alignments; the GPU test runs the same window through the HIP engine."""
+import ctypes as C
 import os
 import struct
 
@@ -210,6 +211,7 @@ def test_records_from_device_finished_batch_are_the_same_bytes(small_bam, oracle
     arrs["rev_seq"], arrs["rev_qual"] = pad(arrs["rev_seq"]), pad(arrs["rev_qual"])
     fo.rev_seq, fo.rev_qual = ptr(arrs["rev_seq"], C.c_uint8), ptr(arrs["rev_qual"], C.c_uint8)
     fo.rev_seq_bytes, fo.rev_qual_bytes = len(f["rev_seq"]), len(f["rev_qual"])
+    fo.n_items, fo.n_reads = res.n_items, b.n_reads
     sa_off_c, sa_text_c = np.ascontiguousarray(sa_off, np.uint32), pad(np.ascontiguousarray(sa_text, np.uint8))
     for sa in (abi.PloSaOut(res.n_items, ptr(sa_off_c, C.c_uint32), ptr(sa_text_c, C.c_uint8), int(sa_off[-1]), 0.0), None):
         rb = win.build_records_finished_raw(o, fo, sa, ix.to_desc(), cn, rn, is_target_region=is_target_region, n_threads=3)
@@ -236,7 +238,24 @@ def test_records_from_device_finished_batch_are_the_same_bytes(small_bam, oracle
     with pytest.raises(Exception, match="do not belong"):
         win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
     arrs["item_seq_off"][flipped] = keep_off
+    # arrays of another batch are refused by their extents before anything is indexed ...
+    fo.n_items = res.n_items - 1
+    with pytest.raises(Exception, match="do not belong"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
+    fo.n_items, fo.n_reads = res.n_items, b.n_reads + 1
+    with pytest.raises(Exception, match="do not belong"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
+    fo.n_reads = b.n_reads
+    # ... a record marked as keeping its bases although the lift says it is flipped (a stale array) is refused ...
+    arrs["item_seq_off"][flipped] = abi.NO_FLIP
+    with pytest.raises(Exception, match="do not belong"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
+    arrs["item_seq_off"][flipped] = keep_off
     win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)  # (restored: fine again)
+    # ... and so is a window whose batch was last built with sparse bases
+    win.batch_desc(sparse_margin=32)
+    with pytest.raises(Exception, match="sparse"):
+        win.build_records_finished_raw(o, fo, None, ix.to_desc(), cn, rn)
     win.close()
     rd.close()
 
@@ -504,3 +523,60 @@ def test_long_tail_of_unmapped_reads_comes_in_bounded_windows(tmp_path):
         win.close()
     rd.close()
     assert n_prim == 1 and n_windows == 3 and got == b"".join(tail)
+
+
+def test_c_caller_sees_windows_without_primaries_before_the_end(tmp_path):
+    """through the C ABI alone (no BamReader logic) -- a window with 0 primary records is not the end of the file when the
+    unmapped tail is longer than 4 x max_records + 1024; the end is 0 primary AND 0 unmapped records, or plo_bam_window_eof()"""
+    p = str(tmp_path / "tail.bam")
+    wr = bam.BamWriter(p, "@HD\tVN:1.6\n", ["ctg0"], [1000], level=1)
+    recs = [_sam_record(0, 5, "10M", "ACGTACGTAC", "IIIIIIIIII")]
+    n_tail = 4 * 50 + 1024 + 700  # > 4 * max_records + 1024 for max_records = 50
+    tail = [bamsynth.encode_record(-1, -1, 0, 0x4, b"u%06d" % i, np.zeros(0, np.uint32), bytes(5), 10, b"\x20" * 10, b"") for i in range(n_tail)]
+    wr.write(b"".join(recs + tail))
+    wr.close()
+    L = bam.lib()
+    rd = C.c_void_p()
+    assert L.plo_bam_open(p.encode(), 2, C.byref(rd)) == 0
+    seen, zero_primary_before_end, eof_flags = 0, 0, []
+    for _ in range(10):
+        h = C.c_void_p()
+        assert L.plo_bam_read_window(rd, 50, C.byref(h)) == 0
+        nrec = L.plo_bam_window_n_records(h)
+        pb, nb, k = C.POINTER(C.c_uint8)(), C.c_uint64(), C.c_uint32()
+        L.plo_bam_window_unmapped(h, C.byref(pb), C.byref(nb), C.byref(k))
+        eof = L.plo_bam_window_eof(h)
+        L.plo_bam_window_free(h)
+        eof_flags.append(eof)
+        if nrec == 0 and k.value == 0:
+            assert eof == 1  # the documented end: 0 primary AND 0 unmapped
+            break
+        if nrec == 0:
+            zero_primary_before_end += 1
+        seen += k.value
+        if eof:
+            break
+    L.plo_bam_close(rd)
+    assert seen == n_tail and zero_primary_before_end >= 1  # a caller stopping at the first 0-primary window would have lost records
+    assert eof_flags[-1] == 1 and not any(eof_flags[:-1])
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("device_finish", [False, True])
+def test_pipeline_raises_instead_of_hanging_when_a_lift_worker_cannot_start(tmp_path, device_finish):
+    """the lift worker's set-up (stream, engine, SA inputs) runs inside its try -- when it fails, the worker records the
+    error, sets the abort flag and still posts its sentinel, so run_bam_to_bam raises; before, the writer waited for the sentinel
+    forever.  (No GPU needed: an index without a library handle makes the engine's creation fail.)"""
+    from portello_amd import pipeline
+
+    w = synth.generate(synth.config("tiny", n_reads=40, seed=3))
+    inp, outp = str(tmp_path / "reads.bam"), str(tmp_path / "lifted.bam")
+    meta = bamsynth.write_read_bam(w, inp, level=1, n_threads=2)
+
+    class NoIndex:  # what api.Engine / torch.device need is missing
+        device = 0
+        handle = None
+
+    with pytest.raises(RuntimeError, match="lift worker"):
+        pipeline.run_bam_to_bam(inp, outp, NoIndex(), w.index_data(), meta["contig_names"], bamsynth.ref_names(w), [int(s.numel()) for s in w.chrom_seq],
+                                window_reads=20, n_workers=2, io_threads=2, device_inflate=False, device_finish=device_finish)
