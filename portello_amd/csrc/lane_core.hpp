@@ -192,8 +192,13 @@ PLO_DEV bool xw16_issue(bool on, const uint8_t *ref, int ref_len, int r0, const 
     }
     const int qsh = (int)(((unsigned)(uintptr_t)rd.p + (unsigned)b0) & 3u);
     ok = ok & (b0 - qsh >= rd.lo) & (b0 - qsh + 20 <= rd.hi);  // five words, whatever the format needs
+#ifdef PLO_EXP_PROBE_NOMEM  // timing experiment (tools/): every probe reads the same 32 bytes -- what do the probes' HBM round trips cost?  (results are wrong)
+    const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)safe;
+    const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)safe;
+#else
     const PLO_GLOBAL uint32_t *pr = (const PLO_GLOBAL uint32_t *)(ok ? ref + (r0 - rsh) : safe);
     const PLO_GLOBAL uint32_t *pq = (const PLO_GLOBAL uint32_t *)(ok ? rd.p + (b0 - qsh) : safe);
+#endif
     w.r4 = *(const PLO_GLOBAL Ops4 *)pr;
     w.r1 = pr[4];
     w.q4 = *(const PLO_GLOBAL Ops4 *)pq;

@@ -42,6 +42,7 @@ def _worker(rank, world, port, outdir, n_reads, segment_size):
     assert len(wins) >= 2 * world and all(len(d) > 0 for d in deal)
     ranges = shard.rank_read_ranges(wins, deal, rank)
     db = devbatch.DeviceBatch.from_read_ranges(w, ranges)
+    torch.cuda.synchronize()  # (torch's default stream is handle 0 = "create a private stream" for the engine: the inputs must be complete)
     out = eng.liftover_batch_dev(db.desc())
     eng.compact_output_dev(out)
     eng.sync()
@@ -54,6 +55,7 @@ def _worker(rank, world, port, outdir, n_reads, segment_size):
         assert sum(int(m.numel()) for m in seg_maps) == int(w.seg_read.numel())  # every read segment belongs to exactly one rank
         allr = gather.combine(got, seg_maps)
         whole_db = devbatch.DeviceBatch.from_workload(w)
+        torch.cuda.synchronize()
         whole_out = eng.liftover_batch_dev(whole_db.desc())
         eng.compact_output_dev(whole_out)
         eng.sync()
