@@ -374,26 +374,44 @@ PLO_DEV void win_fill(LaneWin &w, bool on, int idx) {
 }
 // the same from the batch's input CIGAR `src` (n_in ops), walked backwards for reverse-mapped contig segments: window element j =
 // op idx + j in walking order.  Heavy items whose first stage can read the input as it is skip the LOAD pass.
-PLO_DEV void win_fill_input(LaneWin &w, bool on, int idx, const uint32_t *src, int n_in, bool rev) {
-    if (on) {
-        w.rbase = idx;
-        uint32_t a[LANE_RW];
+PLO_DEV void win_fill_input(LaneWin &w, bool on, int idx, const uint32_t *src, int n_in, bool rev, int lo_ok, int hi_ok) {
+    // [lo_ok, hi_ok): indices relative to `src` that lie inside the batch's CIGAR buffer (a quad that reaches past the item's ends reads its
+    // neighbours' ops, masked below; only one that would leave the buffer takes the op-by-op loads).  All LANE_RW / 4 loads are in flight
+    // together: inside lane-divergent branches every one of them was waited for on its own (five round trips per refill).
+    uint32_t a[LANE_RW];
+    const uint32_t *qa[LANE_RW / 4];
+    bool edge = false;
+#pragma unroll
+    for (int q = 0; q < LANE_RW / 4; ++q) {
+        const int kq = idx + 4 * q;
+        const bool want = on & (kq < n_in);
+        const int gi = rev ? n_in - 4 - kq : kq;
+        const bool inside = (gi >= lo_ok) & (gi + 4 <= hi_ok);
+        edge = edge | (want & !inside);
+        qa[q] = (want & inside) ? src + gi : (const uint32_t *)plo_safe_words;
+    }
+    if (wv::ballot(edge) == 0ull) {
+        Ops4 v[LANE_RW / 4];
+#pragma unroll
+        for (int q = 0; q < LANE_RW / 4; ++q) v[q] = *(const PLO_GLOBAL Ops4 *)qa[q];
 #pragma unroll
         for (int q = 0; q < LANE_RW / 4; ++q) {
-            const int kq = idx + 4 * q;
-            if (kq + 3 < n_in) {  // four neighbours in memory
-                const Ops4 v = *(const PLO_GLOBAL Ops4 *)(src + (rev ? n_in - 4 - kq : kq));
-                a[4 * q] = rev ? v.w : v.x;
-                a[4 * q + 1] = rev ? v.z : v.y;
-                a[4 * q + 2] = rev ? v.y : v.z;
-                a[4 * q + 3] = rev ? v.x : v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[4 * q + j] = kq + j < n_in ? src[rev ? n_in - 1 - kq - j : kq + j] : 0u;
-            }
+            a[4 * q] = rev ? v[q].w : v[q].x;
+            a[4 * q + 1] = rev ? v[q].z : v[q].y;
+            a[4 * q + 2] = rev ? v[q].y : v[q].z;
+            a[4 * q + 3] = rev ? v[q].x : v[q].w;
         }
+    } else {
 #pragma unroll
-        for (int j = 0; j < LANE_RW; ++j) w.rw[j * 64] = a[j];
+        for (int j = 0; j < LANE_RW; ++j) {
+            a[j] = 0u;
+            if (on && idx + j < n_in) a[j] = src[rev ? n_in - 1 - idx - j : idx + j];
+        }
+    }
+    if (on) {
+        w.rbase = idx;
+#pragma unroll
+        for (int j = 0; j < LANE_RW; ++j) w.rw[j * 64] = (idx + j < n_in) ? a[j] : 0u;
     }
 }
 // region indices [wbase, end) are in the window: out with them
@@ -561,11 +579,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // WIN, stages with the liftover: the first stage of an item -- the shift or the liftover, which take =, X and M ops alike --
         // reads the batch's input through the window; `ext`: the lane's current CIGAR is still that input (cur_off = 0)
         const bool direct = WIN && (stages & PLO_STAGE_LIFTOVER) != 0u;
+        const int n_cig_all = WIN ? (int)bt.seg_cigar_off[bt.n_segs] : 0;  // ops in the batch's CIGAR buffer
         bool ext = false;
         auto rd_fill = [&](bool on, int idx) {
             if constexpr (WIN) {
                 if (direct) {
-                    if (wv::ballot(on & ext) != 0ull) win_fill_input(win, on & ext, idx, bt.cigar + in_off, n_in, rev);
+                    if (wv::ballot(on & ext) != 0ull) win_fill_input(win, on & ext, idx, bt.cigar + in_off, n_in, rev, -in_off, n_cig_all - in_off);
                     if (wv::ballot(on & !ext) != 0ull) win_fill(win, on & !ext, idx);
                 } else {
                     win_fill(win, on, idx);
