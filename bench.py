@@ -106,6 +106,73 @@ def pipeline_cpus() -> int:
     return pipeline.effective_cpus()
 
 
+
+def host_rates(threads: int, tmpdir: str = None) -> dict:
+    """what the box's host cores move per second, beside the pipeline's per-stage rates: memcpy and CRC-32 (zlib's, and libdeflate's
+    carry-less-multiply one the BGZF reader / writer use when the runtime is there), one thread and `threads` threads"""
+    import ctypes
+    import threading
+    import zlib
+
+    import numpy as np
+
+    n = 256 << 20
+    src = np.full(n, 7, dtype=np.uint8)
+    dst = np.empty_like(src)
+    libc = ctypes.CDLL(None)
+    libc.memcpy.restype = ctypes.c_void_p
+    libc.memcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    ld = None
+    for name in ("libdeflate.so.0", "libdeflate.so", "libdeflate.so.1"):
+        try:
+            ld = ctypes.CDLL(name)
+            ld.libdeflate_crc32.restype = ctypes.c_uint32
+            ld.libdeflate_crc32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+            break
+        except OSError:
+            ld = None
+
+    def run(fn, nt):
+        part = n // nt
+        ths = [threading.Thread(target=fn, args=(k * part, part)) for k in range(nt)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return n / (time.perf_counter() - t0) / 1e9
+
+    cp = lambda o, m: libc.memcpy(dst.ctypes.data + o, src.ctypes.data + o, m)
+    crc_z = lambda o, m: zlib.crc32(memoryview(src)[o:o + m])
+    out = {"threads": threads, "buffer_MB": n >> 20}
+    cp(0, n)  # touch the pages
+    out["memcpy_GBps_1_thread"] = max(run(cp, 1) for _ in range(2))
+    out["memcpy_GBps_all_threads"] = max(run(cp, threads) for _ in range(2))
+    out["crc32_zlib_GBps_1_thread"] = run(crc_z, 1)
+    if ld is not None:
+        crc_l = lambda o, m: ld.libdeflate_crc32(0, src.ctypes.data + o, m)
+        out["crc32_libdeflate_GBps_1_thread"] = run(crc_l, 1)
+        out["crc32_libdeflate_GBps_all_threads"] = run(crc_l, threads)
+    if tmpdir:  # what the output file's page cache takes: positional writes of 8 MB pieces from `threads` threads (the BGZF writer's pattern)
+        path = os.path.join(tmpdir, "rate_probe.bin")
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            mv = memoryview(src)
+
+            def wr(o, m):
+                p = o
+                while p < o + m:
+                    k = min(8 << 20, o + m - p)
+                    os.pwrite(fd, mv[p:p + k], p)
+                    p += k
+
+            out["page_cache_pwrite_GBps_all_threads"] = max(run(wr, threads) for _ in range(2))
+        finally:
+            os.close(fd)
+            os.unlink(path)
+    return out
+
+
 def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: int, io_threads: int, pcie_reads: int = 60000, verify: bool = True):
     """BAM file in -> lifted BAM file out on a bounded sample of the workload (a block of consecutive reads from the middle of
     the coordinate-sorted read set, written as a real BGZF-compressed read->contig BAM first): BGZF inflate + record parsing +
@@ -141,6 +208,12 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                "sample": f"reads [{lo}, {lo + n}) of the workload as a BGZF level-1 read->contig BAM (synthetic qualities / aux tags, "
                          f"written in {t_write:.1f} s outside the timed run); output BGZF level 0",
                "note": "supplementary: one GPU, one node's host cores; `value` of the bench line stays the HBM-resident kernel rate"}
+        e2e["stage_GBps"] = {"decode: compressed BAM in": in_bytes / 1e9 / max(st.read_s, 1e-9), "record assembly: record bytes out": st.bytes_out / 1e9 / max(st.build_s, 1e-9),
+                             "bgzf write: record bytes out": st.bytes_out / 1e9 / max(st.write_s, 1e-9), "whole run: bytes in + out": (in_bytes + st.bytes_out) / 1e9 / st.seconds}
+        try:
+            e2e["host_rates"] = host_rates(pipeline_cpus(), d)
+        except Exception as e:  # noqa: BLE001
+            e2e["host_rates"] = {"error": repr(e)}
         # the same run with the records finished on the device (flags, bin, primary, reversed bases / qualities: plo_finish_batch_dev;
         # SA text: plo_sa_segments_dev; the host only copies them into place, plo_records_build_finished): dense bases go up, the
         # reversed ones come back
@@ -181,6 +254,26 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] end_to_end verification could not run: {e!r}")
                 e2e["records_verified"] = None
+            # the CPU pipeline beside it (cpu_baseline leg only): the same reader / batch / record / writer stages with the oracle lifting on
+            # the host cores, same input file, same window size, all of the box's cores for the lift (oracle/cpu_pipeline.py)
+            try:
+                from oracle import cpu_pipeline, expect
+
+                outp_cpu = os.path.join(d, "lifted_cpu.bam")
+                cores = pipeline_cpus()
+                cs = cpu_pipeline.run_bam_to_bam_cpu(inp, outp_cpu, ixd, cn, rn, rl, window_reads=window_reads, io_threads=io_threads, lift_threads=cores,
+                                                     unassembled_path=os.path.join(d, "unassembled_cpu.bam"))
+                vc = expect.verify_lifted_bam(inp, outp_cpu, ixd, cn, rn, window=500, every=max(1, (n // 500) // 12), threads=min(16, io_threads),
+                                              unassembled_bam=os.path.join(d, "unassembled_cpu.bam"))
+                e2e["cpu_pipeline"] = {"value": cs["reads"] / cs["seconds"], "unit": "reads/s", "cores": cores, "kind": "port", "seconds": cs["seconds"],
+                                       "reads": cs["reads"], "records_out": cs["records_out"], "records_verified": vc["records_verified"] if vc["ok"] else 0,
+                                       "stage_busy_s": {"decode": cs["read_s"], "batch construction": cs["batch_s"], f"lift (oracle, {cores} threads)": cs["lift_s"],
+                                                        "record assembly": cs["build_s"], "bgzf write": cs["write_s"]},
+                                       "note": "BAM -> BAM with the CPU restatement of the reference algorithm lifting on the host cores (not the reference "
+                                               "binary): same input file, windows, reader, record builder and BGZF writer as the GPU pipeline"}
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] cpu pipeline baseline failed: {e!r}")
+                e2e["cpu_pipeline"] = None
         # the host-buffer entry point alone: whole sample in one window, dense bases and sparse bases (margin 32)
         rd = bam.BamReader(inp, io_threads)
         eng = api.Engine(index)
@@ -864,6 +957,8 @@ def main():
         try:
             got = devbatch.download(eng, last_out[0])
             cb, ok, n_checked = cpu_baseline(w, got, ixd=ixd_host)
+            if cb is not None and (result.get("end_to_end") or {}).get("cpu_pipeline"):
+                cb["end_to_end"] = result["end_to_end"]["cpu_pipeline"]  # the CPU figure beside the GPU `end_to_end`
             result["cpu_baseline"] = cb
             result["parity_sample_items"] = n_checked
             result["parity_sample_ok"] = bool(ok)

@@ -57,7 +57,7 @@ plo_status plo_bam_header(const plo_bam_reader *r, const char **text, uint32_t *
                           const char *const **ref_names, const uint32_t **ref_lens);
 
 /* Next window of the file: at most max_records primary records.  A window also ends after 4 x max_records + 1024 unmapped
- * records or 1 GB of records, so a window with 0 primary records is NOT the end of the file (the unmapped tail of a sorted BAM
+ * records or max(1 GB, 64 KB x max_records) of records, so a window with 0 primary records is NOT the end of the file (the unmapped tail of a sorted BAM
  * comes as several such windows).  The end of the file is a window with 0 primary AND 0 unmapped records -- or, without
  * counting, plo_bam_window_eof() != 0: the stream ended inside or right behind this window (its records, if any, are the last).
  * Records are classified as the reference does:

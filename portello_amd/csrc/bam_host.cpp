@@ -132,9 +132,12 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
     // walk the records of the inflated stream (no copies), then take the whole stretch with one parallel copy
     size_t at = 0;  // offset from r->in.bpos
     std::vector<uint64_t> unm_at;
-    // A window also ends after 4 x max_records unmapped records or 1 GB of records: the tail of unmapped reads of a sorted
+    // A window also ends after 4 x max_records unmapped records or 1 GB (or more, below) of records: the tail of unmapped reads of a sorted
     // read->contig BAM (often gigabytes) then comes in windows of bounded size instead of one
-    const size_t unm_cap = 4 * (size_t)max_records + 1024, byte_cap = (size_t)1 << 30;
+    // (the byte bound follows the window asked for -- 64 KB per record, at least 1 GB -- so that it cuts the unmapped tail and runs of
+    // oversized records, not an ordinary window of HiFi reads: 60 000 records of 15 kb reads are 1.9 GB)
+    const size_t unm_cap = 4 * (size_t)max_records + 1024;
+    const size_t byte_cap = std::max<size_t>((size_t)1 << 30, std::min<size_t>((size_t)8 << 30, (size_t)max_records << 16));
     while (w->rec_at.size() < max_records) {
         if (unm_at.size() >= unm_cap || (at >= byte_cap && w->rec_at.size() + unm_at.size() > 0)) break;
         if (r->in.avail() < at + 4 && (st = timed_fill(at + 4)) != PLO_OK) break;

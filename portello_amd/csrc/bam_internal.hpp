@@ -76,6 +76,61 @@ void parallel_ranges(size_t n, int threads, F fn) {
     for (auto &t : th) t.join();
 }
 
+// Large blocks of pageable host memory are RECYCLED process-wide: a window's record bytes and its output records are a few hundred MB each,
+// and taking them from malloc means an mmap, a page fault and a kernel-side clear per 4 KB page on first touch and an munmap at the end
+// -- about 40 ms per block on the GPU box, in the reader's and the writer's threads (the writer's "busy" time was more than half
+// frees).  Blocks of at least BIG_BLOCK bytes come from / return to a small free list (first fit within 2 x the size asked for).
+namespace bigpool {
+constexpr size_t BIG_BLOCK = (size_t)1 << 20;
+constexpr size_t KEEP_BYTES = (size_t)6 << 30;  // most the list keeps (the rest is freed)
+struct Blk {
+    uint8_t *p;
+    size_t cap;
+};
+inline std::mutex &mu() {
+    static std::mutex m;
+    return m;
+}
+inline std::vector<Blk> &list() {
+    static std::vector<Blk> l;
+    return l;
+}
+inline size_t &kept() {
+    static size_t k = 0;
+    return k;
+}
+inline uint8_t *take(size_t want, size_t &cap) {
+    if (want >= BIG_BLOCK) {
+        std::lock_guard<std::mutex> g(mu());
+        auto &l = list();
+        size_t best = l.size();
+        for (size_t i = 0; i < l.size(); ++i)
+            if (l[i].cap >= want && l[i].cap <= 2 * want && (best == l.size() || l[i].cap < l[best].cap)) best = i;
+        if (best < l.size()) {
+            Blk b = l[best];
+            l.erase(l.begin() + (long)best);
+            kept() -= b.cap;
+            cap = b.cap;
+            return b.p;
+        }
+    }
+    cap = want >= BIG_BLOCK ? (want + (want >> 3) + 4095) & ~(size_t)4095 : want;  // an eighth of headroom: windows of a run differ a little
+    return (uint8_t *)malloc(cap ? cap : 1);
+}
+inline void give(uint8_t *p, size_t cap) {
+    if (!p) return;
+    if (cap >= BIG_BLOCK) {
+        std::lock_guard<std::mutex> g(mu());
+        if (kept() + cap <= KEEP_BYTES) {
+            list().push_back({p, cap});
+            kept() += cap;
+            return;
+        }
+    }
+    free(p);
+}
+}  // namespace bigpool
+
 // growable byte buffer that does not zero what it allocates (the inflated stream and the output records are written once, in
 // parallel, right after the allocation)
 struct RawBuf {
@@ -87,7 +142,7 @@ struct RawBuf {
     RawBuf &operator=(const RawBuf &) = delete;
     ~RawBuf() {
         if (pinned) plo_host_free(p);
-        else free(p);
+        else bigpool::give(p, cap);
     }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
@@ -102,9 +157,13 @@ struct RawBuf {
                 plo_host_free(p);
                 p = (uint8_t *)q;
             } else {
-                uint8_t *q = (uint8_t *)realloc(p, nc ? nc : 1);
+                size_t got = 0;
+                uint8_t *q = bigpool::take(nc ? nc : 1, got);
                 if (!q) return false;
+                if (n) memcpy(q, p, std::min(n, want));
+                bigpool::give(p, cap);
                 p = q;
+                nc = got;
             }
             cap = nc;
         }

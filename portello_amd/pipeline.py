@@ -71,7 +71,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
                    cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
                    device_finish: bool = False, read_threads: Optional[int] = None, build_threads: Optional[int] = None,
-                   write_threads: Optional[int] = None) -> PipelineStats:  # noqa: E501
+                   write_threads: Optional[int] = None, ramp: bool = True) -> PipelineStats:  # noqa: E501
     """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
     (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
     plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
@@ -125,9 +125,14 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
 
     def reader():
         try:
+            # the first windows are small and double up to window_reads: the stages behind the reader start after milliseconds instead of
+            # after a whole window's decode -- a five-stage pipeline over a handful of full windows is mostly ramp otherwise
+            n_win = 0
             while True:
                 t = time.perf_counter()
-                win = rd.read_window(window_reads)
+                size = window_reads if not ramp else min(window_reads, max(256, window_reads >> max(0, 4 - n_win)))
+                n_win += 1
+                win = rd.read_window(size)
                 if win is None:
                     break
                 st.read_s += time.perf_counter() - t

@@ -580,3 +580,20 @@ def test_pipeline_raises_instead_of_hanging_when_a_lift_worker_cannot_start(tmp_
     with pytest.raises(RuntimeError, match="lift worker"):
         pipeline.run_bam_to_bam(inp, outp, NoIndex(), w.index_data(), meta["contig_names"], bamsynth.ref_names(w), [int(s.numel()) for s in w.chrom_seq],
                                 window_reads=20, n_workers=2, io_threads=2, device_inflate=False, device_finish=device_finish)
+
+
+def test_cpu_pipeline_baseline_writes_the_expected_records(tmp_path):
+    """oracle/cpu_pipeline.py (bench.py's `cpu_baseline.end_to_end` leg: the host reader / batch / record / writer stages with the oracle
+    in place of the engine) writes the same records as the expectation -- the figure it produces is a measurement of a correct run"""
+    from oracle import cpu_pipeline, expect
+
+    w = synth.generate(synth.config("tiny", n_reads=150, seed=11, split_read_frac=0.2))
+    inp, outp, unp = str(tmp_path / "reads.bam"), str(tmp_path / "lifted.bam"), str(tmp_path / "un.bam")
+    meta = bamsynth.write_read_bam(w, inp, level=1, n_threads=2)
+    ixd = w.index_data()
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    st = cpu_pipeline.run_bam_to_bam_cpu(inp, outp, ixd, cn, rn, [int(s.numel()) for s in w.chrom_seq], window_reads=40, io_threads=4, lift_threads=2,
+                                         unassembled_path=unp)
+    assert st["reads"] == w.n_reads and st["windows"] >= 3
+    v = expect.verify_lifted_bam(inp, outp, ixd, cn, rn, window=50, every=1, threads=2, unassembled_bam=unp)
+    assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st["records_out"], v
