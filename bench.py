@@ -280,6 +280,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
         wins = []
         win = rd.read_window(pcie_reads)
         pcie = None
+        has_rev = bam.contig_has_reverse_segment(ixd)  # (reads on forward-only contigs send their insertions' bases only)
         if win is not None and win.n_records:
             wins.append((win, None))
 
@@ -291,7 +292,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                 tb = []
                 for _ in range(3):
                     t0 = time.perf_counter()
-                    desc = win.batch_desc(sparse_margin=sparse_margin)
+                    desc = win.batch_desc(sparse_margin=sparse_margin, contig_has_rev=(has_rev if sparse_margin is not None else None))
                     tb.append(time.perf_counter() - t0)
                 eng.liftover_batch_host(desc)
                 reps = 5
@@ -310,7 +311,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
             two = None
             try:
                 import threading as _th
-                desc2 = win.batch_desc(sparse_margin=32)  # (the window's arrays as the last run(32) left them)
+                desc2 = win.batch_desc(sparse_margin=32, contig_has_rev=has_rev)  # (the window's arrays as the last run(32) left them)
                 eng2 = api.Engine(index)
                 eng2.liftover_batch_host(desc2)
                 reps2 = 6
@@ -332,7 +333,8 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] two-worker host-buffer measurement failed: {e!r}")
             pcie = dict(sparse)
-            pcie.update({"two_workers": two, "reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel)",
+            pcie.update({"two_workers": two, "reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel; reads on contigs without a reverse-mapped segment: "
+                                                                                                  "the granules of their insertions only, plo_bam_window_batch_sparse_strand)",
                          "dense_bases": dense,
                          "note": "plo_liftover_batch on page-locked host arrays, one context, synchronous: H2D of read bases + CIGARs, kernels, "
                                  "second look at items whose comparisons left the granules sent, D2H of the dense result.  batch_build_ms = "
@@ -720,7 +722,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
                          "enumerate_ms": float(np.mean(times["enum"])), "enumerate_pass": enum_obj, "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"],
-                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_lanes_ms": kms["k_lift_lanes_g"]},
+                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_lanes_ms": kms["k_lift_lanes_g"],
+                         "lane_utilisation": float(tm.lane_utilisation)},  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
         }
         return result
 

@@ -226,25 +226,30 @@ inline uint32_t sparse_words(uint32_t len) { return (len + 1023u) >> 10; }
 // sides, in the coordinates of the stored sequence (a segment on the other strand than the record counts from the far end:
 // `changes`, src/read_alignment_scanner.rs:153-157).  These are the places the homology probes of left_shift_indels and the
 // cluster trimming of simplify_alignment_indels start from; probes that run further are caught on the device.
+// `seg_contig` + `contig_has_rev` (optional): a segment on a contig WITHOUT a reverse-mapped contig segment never goes through the left
+// shift (its homology probes are what the margins and the deletions' flanks are for); the only bases the path can compare there are the
+// inserted ones of a complex indel cluster (simplify_alignment_indels.rs:55-85) -- its insertions' own intervals are marked, nothing else.
 void sparse_mark(uint32_t len, bool read_rev, uint32_t s0, uint32_t s1, const uint8_t *seg_fwd, const uint32_t *coff, const uint32_t *cigar,
-                 uint32_t margin, uint32_t *mask) {
+                 uint32_t margin, uint32_t *mask, const uint32_t *seg_contig = nullptr, const uint8_t *contig_has_rev = nullptr, uint32_t n_contigs = 0) {
     const uint32_t nw = sparse_words(len);
     for (uint32_t k = 0; k < nw; ++k) mask[k] = 0;
     if (!len) return;
     for (uint32_t s = s0; s < s1; ++s) {
         const bool changes = read_rev == (seg_fwd[s] != 0);
+        const bool ins_only = seg_contig && contig_has_rev && seg_contig[s] < n_contigs && !contig_has_rev[seg_contig[s]];
+        const uint32_t margin_s = ins_only ? std::min(margin, 16u) : margin;  // (the comparisons read 16-base windows)
         int64_t q = 0;
         for (uint32_t o = coff[s]; o < coff[s + 1]; ++o) {
             const uint32_t t = cigar[o] & 15u, L = cigar[o] >> 4;
-            if (t == 1 || t == 2) {
+            if ((t == 1 || t == 2) && !(ins_only && t == 2)) {
                 int64_t a = q, b = q + (t == 1 ? (int64_t)L : 0);
                 if (changes) {
                     const int64_t a2 = (int64_t)len - b;
                     b = (int64_t)len - a;
                     a = a2;
                 }
-                a = std::max<int64_t>(0, a - (int64_t)margin);
-                b = std::min<int64_t>((int64_t)len, b + (int64_t)margin);
+                a = std::max<int64_t>(0, a - (int64_t)margin_s);
+                b = std::min<int64_t>((int64_t)len, b + (int64_t)margin_s);
                 if (b > a)
                     for (int64_t g = a >> 5; g <= (b - 1) >> 5; ++g) mask[g >> 5] |= 1u << (g & 31);
             }
@@ -353,13 +358,18 @@ extern "C" plo_status plo_sparse_seq_pack(const plo_batch_in *dense, uint32_t ma
     return PLO_OK;
 }
 
-static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin);
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const uint8_t *contig_has_rev = nullptr,
+                               uint32_t n_contigs = 0);
 extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin) { return window_batch(w, batch, fin, -1); }
 extern "C" plo_status plo_bam_window_batch_sparse(plo_bam_window *w, uint32_t margin, plo_batch_in *batch, plo_finish_in *fin) {
     return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20));
 }
+extern "C" plo_status plo_bam_window_batch_sparse_strand(plo_bam_window *w, uint32_t margin, const uint8_t *contig_has_rev, uint32_t n_contigs, plo_batch_in *batch,
+                                                         plo_finish_in *fin) {
+    return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20), contig_has_rev, contig_has_rev ? n_contigs : 0u);
+}
 
-static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin) {
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const uint8_t *contig_has_rev, uint32_t n_contigs) {
     if (!w || !batch) return PLO_ERR_INVALID_ARG;
     memset(batch, 0, sizeof(*batch));
     const bool sparse = sparse_margin >= 0;
@@ -457,7 +467,8 @@ static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finis
         std::vector<uint32_t> masks(woff[n] + 1);
         parallel_ranges(n, w->threads, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
-                sparse_mark(rlen[i], rev[i] != 0, n_seg[i], n_seg[i + 1], seg_fwd, coff, cigar, (uint32_t)sparse_margin, masks.data() + woff[i]);
+                sparse_mark(rlen[i], rev[i] != 0, n_seg[i], n_seg[i + 1], seg_fwd, coff, cigar, (uint32_t)sparse_margin, masks.data() + woff[i], seg_contig, contig_has_rev,
+                            n_contigs);
                 boff[i + 1] = sparse_hdr_bytes(rlen[i]) + 16ull * sparse_granules(rlen[i], masks.data() + woff[i]);
             }
         });

@@ -306,6 +306,11 @@ def test_gpu_sparse_window_batch_from_bam(tmp_path, oracle):
         assert int(desc.seq_fmt) == abi.SEQ_BAM4_SPARSE and int(desc.seq_bytes) < d_bytes
         sparse = abi.result_from_out(eng.liftover_batch_host(desc)).canonical()
         assert sparse == dense
+        s_bytes = int(desc.seq_bytes)
+        # strand-aware: forward-only contigs send their insertions' bases only; the result is the same (second look included)
+        desc2 = win.batch_desc(sparse_margin=32, contig_has_rev=bam.contig_has_reverse_segment(ixd))
+        assert int(desc2.seq_bytes) < s_bytes
+        assert abi.result_from_out(eng.liftover_batch_host(desc2)).canonical() == dense
         win.close()
     finally:
         rd.close()
