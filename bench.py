@@ -280,7 +280,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
         wins = []
         win = rd.read_window(pcie_reads)
         pcie = None
-        has_rev = bam.contig_has_reverse_segment(ixd)  # (reads on forward-only contigs send their insertions' bases only)
+        ixd_c = ixd.to_desc()  # (read segments that touch no reverse-mapped contig segment send their insertions' bases only)
         if win is not None and win.n_records:
             wins.append((win, None))
 
@@ -292,7 +292,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                 tb = []
                 for _ in range(3):
                     t0 = time.perf_counter()
-                    desc = win.batch_desc(sparse_margin=sparse_margin, contig_has_rev=(has_rev if sparse_margin is not None else None))
+                    desc = win.batch_desc(sparse_margin=sparse_margin, index_desc=(ixd_c if sparse_margin is not None else None))
                     tb.append(time.perf_counter() - t0)
                 eng.liftover_batch_host(desc)
                 reps = 5
@@ -311,7 +311,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
             two = None
             try:
                 import threading as _th
-                desc2 = win.batch_desc(sparse_margin=32, contig_has_rev=has_rev)  # (the window's arrays as the last run(32) left them)
+                desc2 = win.batch_desc(sparse_margin=32, index_desc=ixd_c)  # (the window's arrays as the last run(32) left them)
                 eng2 = api.Engine(index)
                 eng2.liftover_batch_host(desc2)
                 reps2 = 6
@@ -333,7 +333,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] two-worker host-buffer measurement failed: {e!r}")
             pcie = dict(sparse)
-            pcie.update({"two_workers": two, "reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel; reads on contigs without a reverse-mapped segment: "
+            pcie.update({"two_workers": two, "reads_per_call": win.n_records, "seq_fmt": "bam4_sparse (granules of 32 bases within 32 bases of a read->contig indel; read segments that touch no reverse-mapped contig segment: "
                                                                                                   "the granules of their insertions only, plo_bam_window_batch_sparse_strand)",
                          "dense_bases": dense,
                          "note": "plo_liftover_batch on page-locked host arrays, one context, synchronous: H2D of read bases + CIGARs, kernels, "

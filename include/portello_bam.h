@@ -92,14 +92,14 @@ plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_fini
  * comparison runs past what was sent.  For the path that finishes records on the host (plo_records_build); the result of
  * plo_liftover_batch is the same as with plo_bam_window_batch whatever the margin. */
 plo_status plo_bam_window_batch_sparse(plo_bam_window *w, uint32_t margin, plo_batch_in *batch, plo_finish_in *fin);
-/* The same, told which contigs have a reverse-mapped contig segment (contig_has_rev[c] != 0; c = the read->contig BAM's reference id =
- * the index's contig; from the plo_index_desc the index was made of: any seg_is_fwd_strand == 0 among the contig's segments).  Read
- * segments on the other contigs never take the left shift (src/read_alignment_scanner.rs:159-176 runs it for reverse-mapped contig
- * segments only), so only the inserted bases of their CIGARs' insertions are sent -- what simplify_alignment_indels may compare -- and
- * neither margins nor the deletions' flanks: about a third of the bytes for such reads.  As with every sparse batch the result does not
- * depend on what was sent (an item that reaches an absent granule is lifted again from the complete bases). */
-plo_status plo_bam_window_batch_sparse_strand(plo_bam_window *w, uint32_t margin, const uint8_t *contig_has_rev, uint32_t n_contigs,
-                                              plo_batch_in *batch, plo_finish_in *fin);
+/* The same, told where the reverse-mapped contig segments are (`index`: the description the plo_index was made of; read: contig_seg_off,
+ * seg_seq_order_start / _end, seg_is_fwd_strand).  A read segment that touches no reverse-mapped contig segment (the overlap rule of
+ * src/read_alignment_scanner.rs:80-103) never takes the left shift (:159-176 runs it for reverse-mapped contig segments only), so only
+ * the bases of its CIGAR's insertions (+ 16 on either side) are sent -- what simplify_alignment_indels may compare -- and neither the
+ * margins nor the deletions' flanks: about a third of the bytes for such reads.  As with every sparse batch the result does not depend on
+ * what was sent (an item that reaches an absent granule is lifted again from the complete bases). */
+plo_status plo_bam_window_batch_sparse_strand(plo_bam_window *w, uint32_t margin, const plo_index_desc *index, plo_batch_in *batch,
+                                              plo_finish_in *fin);
 
 /* The same transformation for a batch that already exists with dense PLO_SEQ_BAM4 bases in host memory (seg_read non-decreasing).
  * `out` needs plo_sparse_seq_bound(dense) bytes (page-locked memory from plo_host_alloc makes the upload faster), out_read_off

@@ -51,7 +51,7 @@ def lib():
         L.plo_bam_window_batch.restype = C.c_int
         L.plo_bam_window_batch.argtypes = [vp, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
         L.plo_bam_window_batch_sparse_strand.restype = C.c_int
-        L.plo_bam_window_batch_sparse_strand.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
+        L.plo_bam_window_batch_sparse_strand.argtypes = [vp, C.c_uint32, C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
         L.plo_bam_open_device.restype = C.c_int
         L.plo_bam_open_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.plo_bam_set_device_inflate.restype = None
@@ -131,17 +131,16 @@ class Window:
         lib().plo_bam_window_unmapped(self.handle, C.byref(p), C.byref(n), C.byref(k))
         return (C.string_at(p, n.value) if n.value else b""), int(k.value)
 
-    def batch_desc(self, with_finish: bool = False, sparse_margin: Optional[int] = None, contig_has_rev: Optional[np.ndarray] = None):
+    def batch_desc(self, with_finish: bool = False, sparse_margin: Optional[int] = None, index_desc: Optional[abi.PloIndexDesc] = None):
         """plo_batch_in (host arrays owned by the window) [+ plo_finish_in].  sparse_margin: read bases as PLO_SEQ_BAM4_SPARSE --
         only the granules within that many bases of an indel of a read->contig CIGAR, the complete bases stay in the records
         (plo_bam_window_batch_sparse)"""
         b = abi.PloBatchIn()
         f = abi.PloFinishIn()
-        if sparse_margin is not None and contig_has_rev is not None:
-            # (contig_has_rev: uint8 per contig, see contig_has_reverse_segment(); forward-only contigs send their insertions' bases only)
-            chr_ = np.ascontiguousarray(contig_has_rev, dtype=np.uint8)
-            _check(lib().plo_bam_window_batch_sparse_strand(self.handle, int(sparse_margin), chr_.ctypes.data_as(C.POINTER(C.c_uint8)), len(chr_), C.byref(b),
-                                                            C.byref(f) if with_finish else None), "plo_bam_window_batch_sparse_strand")
+        if sparse_margin is not None and index_desc is not None:
+            # (read segments that touch no reverse-mapped contig segment send the bases of their insertions only)
+            _check(lib().plo_bam_window_batch_sparse_strand(self.handle, int(sparse_margin), C.byref(index_desc), C.byref(b), C.byref(f) if with_finish else None),
+                   "plo_bam_window_batch_sparse_strand")
         elif sparse_margin is not None:
             _check(lib().plo_bam_window_batch_sparse(self.handle, int(sparse_margin), C.byref(b), C.byref(f) if with_finish else None),
                    "plo_bam_window_batch_sparse")
@@ -243,14 +242,6 @@ class BamReader:
             self.close()
         except Exception:
             pass
-
-
-def contig_has_reverse_segment(index_data: abi.IndexData) -> np.ndarray:
-    """uint8 per contig: 1 when one of its contig split segments maps to the reverse strand (its read segments take the left shift)"""
-    off = np.asarray(index_data.contig_seg_off, dtype=np.int64)
-    fwd = np.asarray(index_data.seg_is_fwd_strand, dtype=np.uint8)
-    n_rev = np.concatenate([[0], np.cumsum(fwd == 0)])
-    return (n_rev[off[1:]] - n_rev[off[:-1]] > 0).astype(np.uint8)
 
 
 def output_header(ref_names: Sequence[str], ref_lens: Sequence[int], program_name="portello", program_version="0.6.1", cmdline="") -> str:

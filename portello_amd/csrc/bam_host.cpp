@@ -226,17 +226,27 @@ inline uint32_t sparse_words(uint32_t len) { return (len + 1023u) >> 10; }
 // sides, in the coordinates of the stored sequence (a segment on the other strand than the record counts from the far end:
 // `changes`, src/read_alignment_scanner.rs:153-157).  These are the places the homology probes of left_shift_indels and the
 // cluster trimming of simplify_alignment_indels start from; probes that run further are caught on the device.
-// `seg_contig` + `contig_has_rev` (optional): a segment on a contig WITHOUT a reverse-mapped contig segment never goes through the left
-// shift (its homology probes are what the margins and the deletions' flanks are for); the only bases the path can compare there are the
-// inserted ones of a complex indel cluster (simplify_alignment_indels.rs:55-85) -- its insertions' own intervals are marked, nothing else.
+// `seg_contig` + `seg_pos` + `ixd` (optional): a read segment that touches no reverse-mapped contig segment (the overlap rule of
+// get_contig_split_segments_from_read_mapping, src/read_alignment_scanner.rs:80-103) never goes through the left shift (its homology
+// probes are what the margins and the deletions' flanks are for); the only bases the path can compare there are the inserted ones of a
+// complex indel cluster (simplify_alignment_indels.rs:55-85) -- its insertions' own intervals (+ 16 bases) are marked, nothing else.
 void sparse_mark(uint32_t len, bool read_rev, uint32_t s0, uint32_t s1, const uint8_t *seg_fwd, const uint32_t *coff, const uint32_t *cigar,
-                 uint32_t margin, uint32_t *mask, const uint32_t *seg_contig = nullptr, const uint8_t *contig_has_rev = nullptr, uint32_t n_contigs = 0) {
+                 uint32_t margin, uint32_t *mask, const uint32_t *seg_contig = nullptr, const int64_t *seg_pos = nullptr, const plo_index_desc *ixd = nullptr) {
     const uint32_t nw = sparse_words(len);
     for (uint32_t k = 0; k < nw; ++k) mask[k] = 0;
     if (!len) return;
     for (uint32_t s = s0; s < s1; ++s) {
         const bool changes = read_rev == (seg_fwd[s] != 0);
-        const bool ins_only = seg_contig && contig_has_rev && seg_contig[s] < n_contigs && !contig_has_rev[seg_contig[s]];
+        bool ins_only = false;
+        if (ixd && seg_contig && seg_pos && seg_contig[s] < ixd->n_contigs) {
+            int64_t ref_len = 0;
+            for (uint32_t o = coff[s]; o < coff[s + 1]; ++o)
+                if ((0x18Du >> (cigar[o] & 15u)) & 1u) ref_len += (int64_t)(cigar[o] >> 4);
+            const int64_t r_start = seg_pos[s], r_end = r_start + ref_len;
+            ins_only = true;
+            for (uint32_t g = ixd->contig_seg_off[seg_contig[s]]; g < ixd->contig_seg_off[seg_contig[s] + 1]; ++g)
+                if (r_end >= ixd->seg_seq_order_start[g] && r_start < ixd->seg_seq_order_end[g] && !ixd->seg_is_fwd_strand[g]) ins_only = false;
+        }
         const uint32_t margin_s = ins_only ? std::min(margin, 16u) : margin;  // (the comparisons read 16-base windows)
         int64_t q = 0;
         for (uint32_t o = coff[s]; o < coff[s + 1]; ++o) {
@@ -358,18 +368,18 @@ extern "C" plo_status plo_sparse_seq_pack(const plo_batch_in *dense, uint32_t ma
     return PLO_OK;
 }
 
-static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const uint8_t *contig_has_rev = nullptr,
-                               uint32_t n_contigs = 0);
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const plo_index_desc *ixd = nullptr);
 extern "C" plo_status plo_bam_window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin) { return window_batch(w, batch, fin, -1); }
 extern "C" plo_status plo_bam_window_batch_sparse(plo_bam_window *w, uint32_t margin, plo_batch_in *batch, plo_finish_in *fin) {
     return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20));
 }
-extern "C" plo_status plo_bam_window_batch_sparse_strand(plo_bam_window *w, uint32_t margin, const uint8_t *contig_has_rev, uint32_t n_contigs, plo_batch_in *batch,
-                                                         plo_finish_in *fin) {
-    return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20), contig_has_rev, contig_has_rev ? n_contigs : 0u);
+extern "C" plo_status plo_bam_window_batch_sparse_strand(plo_bam_window *w, uint32_t margin, const plo_index_desc *index, plo_batch_in *batch, plo_finish_in *fin) {
+    if (index && (!index->contig_seg_off || !index->seg_seq_order_start || !index->seg_seq_order_end || !index->seg_is_fwd_strand))
+        return fail(PLO_ERR_INVALID_ARG, "plo_bam_window_batch_sparse_strand: the index description lacks its segment arrays");
+    return window_batch(w, batch, fin, (int)std::min<uint32_t>(margin, 1u << 20), index);
 }
 
-static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const uint8_t *contig_has_rev, uint32_t n_contigs) {
+static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finish_in *fin, int sparse_margin, const plo_index_desc *ixd) {
     if (!w || !batch) return PLO_ERR_INVALID_ARG;
     memset(batch, 0, sizeof(*batch));
     const bool sparse = sparse_margin >= 0;
@@ -467,8 +477,7 @@ static plo_status window_batch(plo_bam_window *w, plo_batch_in *batch, plo_finis
         std::vector<uint32_t> masks(woff[n] + 1);
         parallel_ranges(n, w->threads, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
-                sparse_mark(rlen[i], rev[i] != 0, n_seg[i], n_seg[i + 1], seg_fwd, coff, cigar, (uint32_t)sparse_margin, masks.data() + woff[i], seg_contig, contig_has_rev,
-                            n_contigs);
+                sparse_mark(rlen[i], rev[i] != 0, n_seg[i], n_seg[i + 1], seg_fwd, coff, cigar, (uint32_t)sparse_margin, masks.data() + woff[i], seg_contig, seg_pos, ixd);
                 boff[i + 1] = sparse_hdr_bytes(rlen[i]) + 16ull * sparse_granules(rlen[i], masks.data() + woff[i]);
             }
         });

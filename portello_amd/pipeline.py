@@ -89,7 +89,6 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     write_threads = write_threads or half
     st = PipelineStats()
     ixd = index_data.to_desc()
-    has_rev = bam.contig_has_reverse_segment(index_data)  # (forward-only contigs: only their insertions' bases go up)
     rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
@@ -156,7 +155,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 elif device_finish:
                     desc = win.batch_desc(with_finish=True)  # (plo_batch_in, plo_finish_in), dense bases
                 else:
-                    desc = win.batch_desc(sparse_margin=sparse_margin, contig_has_rev=has_rev if sparse_margin is not None else None)
+                    desc = win.batch_desc(sparse_margin=sparse_margin, index_desc=ixd if sparse_margin is not None else None)
                 st.batch_s += time.perf_counter() - t
                 put(q_in, (win, desc))
         except BaseException as e:  # noqa: BLE001

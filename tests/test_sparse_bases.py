@@ -308,7 +308,7 @@ def test_gpu_sparse_window_batch_from_bam(tmp_path, oracle):
         assert sparse == dense
         s_bytes = int(desc.seq_bytes)
         # strand-aware: forward-only contigs send their insertions' bases only; the result is the same (second look included)
-        desc2 = win.batch_desc(sparse_margin=32, contig_has_rev=bam.contig_has_reverse_segment(ixd))
+        desc2 = win.batch_desc(sparse_margin=32, index_desc=ixd.to_desc())
         assert int(desc2.seq_bytes) < s_bytes
         assert abi.result_from_out(eng.liftover_batch_host(desc2)).canonical() == dense
         win.close()
