@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
     stale = (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
     if not (force or stale):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-unused-const-variable",
            "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + LIBS + (extra or [])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -348,9 +348,17 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
 // shorter ones.  One workgroup per window, counting sort in LDS.
 constexpr uint32_t LANE_SORT_WINDOW = 128;
 constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SORT_PER = LANE_SORT_MAX_CHUNK / LANE_SORT_THREADS;
-__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk) {
+// `glist` != NULL: the sorted window is also cut into the lane kernel's groups by LDS budget (lane_groups_cut, enumerate.hpp: consecutive
+// items while there are fewer than 64 and their regions fit `cap` dwords) and the groups are appended to the list ({first position, count};
+// *n_groups zeroed by the host).  A window sorted by weight has its long items together; as fixed groups of 64 those need more LDS than a
+// wave's slice and run in several rounds -- which is what made windows larger than 128 slower although they level the lanes better.
+__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk,
+                                                                  const uint32_t *region, uint32_t cap, uint32_t *glist, uint32_t *n_groups) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
+    __shared__ uint16_t reg[LANE_SORT_MAX_CHUNK], nxt[LANE_SORT_MAX_CHUNK];
+    __shared__ uint32_t pre[LANE_SORT_MAX_CHUNK + 1];
+    __shared__ uint32_t starts[LANE_SORT_MAX_CHUNK + 1], g_base, g_cnt;
     const uint32_t c0 = (n0 + chunk - 1) / chunk;
     uint32_t lo, hi;
     if (blockIdx.x < c0) {  // chunks do not straddle the two lane classes
@@ -388,7 +396,63 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
 #pragma unroll
     for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
         const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
-        if (p < hi) perm[lo + atomicAdd(&hist[k[j]], 1u)] = g[j];
+        if (p < hi) {
+            const uint32_t pos = atomicAdd(&hist[k[j]], 1u);
+            perm[lo + pos] = g[j];
+            if (glist) reg[pos] = (uint16_t)(region[g[j]] < 0xffffu ? region[g[j]] : 0xffffu);
+        }
+    }
+    if (!glist) return;
+    const uint32_t n = hi - lo;
+    __syncthreads();
+    {   // exclusive prefix of the regions in sorted order: thread t owns positions [t * PER, t * PER + PER)
+        uint32_t loc[LANE_SORT_PER], tot = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+            const uint32_t i = threadIdx.x * LANE_SORT_PER + j;
+            loc[j] = tot;
+            tot += i < n ? (uint32_t)reg[i] : 0u;
+        }
+        const uint32_t inc2 = (uint32_t)wv::scan_add((int)tot);
+        __syncthreads();  // (wsum is reused)
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc2;
+        __syncthreads();
+        uint32_t base = inc2 - tot;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
+#pragma unroll
+        for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
+            const uint32_t i = threadIdx.x * LANE_SORT_PER + j;
+            if (i < n) pre[i] = base + loc[j];
+        }
+        if (threadIdx.x == LANE_SORT_THREADS - 1) pre[n] = base + tot;  // (positions beyond n add nothing)
+    }
+    __syncthreads();
+    // the group that starts at position i ends at the largest j <= i + 64 with pre[j] - pre[i] <= cap (at least one item)
+#pragma unroll
+    for (uint32_t jj = 0; jj < LANE_SORT_PER; ++jj) {
+        const uint32_t i = jj * LANE_SORT_THREADS + threadIdx.x;
+        if (i < n) {
+            uint32_t a = i, b = i + 64u < n ? i + 64u : n;  // invariant: a fits, everything above b does not (or is out of range)
+            while (a < b) {
+                const uint32_t m = (a + b + 1u) >> 1;
+                if (pre[m] - pre[i] <= cap) a = m;
+                else b = m - 1u;
+            }
+            nxt[i] = (uint16_t)(a > i ? a : i + 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ng = 0;
+        for (uint32_t i = 0; i < n; i = nxt[i]) starts[ng++] = i;
+        starts[ng] = n;
+        g_cnt = ng;
+        g_base = atomicAdd(n_groups, ng);
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < g_cnt; q += LANE_SORT_THREADS) {
+        glist[2 * (g_base + q)] = lo + starts[q];
+        glist[2 * (g_base + q) + 1] = starts[q + 1] - starts[q];
     }
 }
 
@@ -981,6 +1045,7 @@ struct plo_ctx {
     DevBatch last_bt{};
     bool have_last = false, have_finish = false;
     hipEvent_t fev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf item_region, lane_groups;
     DevBuf misc, whist, cls_partial, lane_scratch, item_cls, retry_list, perm, nin_p, seg_reflen, seg_readlen, seg_nm, seg_cnt, seg_off, scan_partial, item_seg, item_cseg, item_nin, op_prefix, counters, big_list, huge_list, scratch, tile_lo, verr, miss_list, miss_info, miss_vals, miss_seq_off, miss_side;
     DevBuf d_n_m, d_in_off, d_n_in, d_pos1, d_w0, d_w1, d_kv0, d_kv1, d_flags, d_contig, d_seq_len, d_seq_off, d_shift_ref, d_shift_ref_len,
         d_chrom_ref, d_chrom_ref_len, d_read_len;
@@ -1017,6 +1082,9 @@ struct plo_ctx {
     int lane_capw = 3072;
     bool lane_sort = true;  // k_chunk_sort before the lane kernel
     int lane_sort_window = LANE_SORT_WINDOW;
+    // groups cut by LDS budget inside larger sort windows (k_chunk_sort, lane_groups_cut): on for batches whose groups are of 64
+    bool lane_budget = false;  // (measured, MI355X, wgs30x 2 M reads: 1.42 ms with windows of 512 against 1.29 ms with fixed groups in windows of 128 -- DESIGN.md section 6)
+    int lane_budget_window = 512;
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
     // batches with at least that many heavy items; < 0 (default) = by lane_heavy_ratio, see the routing in liftover_core (0: never).
     // Stress workload, heavy items -> k_lift_mid / k_lift_lanes_g: 20 k 2.8 / 7.9 ms, 60 k 8.0 / 9.6 ms, 80 k 10.5 / 9.6 ms,
@@ -1264,7 +1332,8 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
     if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
-    if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = std::min(2048, std::max(64, atoi(e) & ~63));
+    if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = c->lane_budget_window = std::min(2048, std::max(64, atoi(e) & ~63));
+    if (const char *e = getenv("PLO_LANE_BUDGET")) c->lane_budget = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
     if (const char *e = getenv("PLO_LANE_HEAVY_RATIO")) c->lane_heavy_ratio = std::max(0, atoi(e));
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
@@ -1283,7 +1352,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_nm, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->item_region, &c->lane_groups, &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_nm, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_n_m, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -1506,6 +1575,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipStreamSynchronize(st));                                                                                        \
     } while (0)
     wk.big_list = c->big_list.as<uint32_t>();
+    if (c->lane_sort && c->lane_budget && c->lane_max_w >= 0) {
+        HIP_TRY(c, c->item_region.ensure(ni * 4));
+        wk.item_region = c->item_region.as<uint32_t>();
+    }
     wk.miss_list = c->miss_list.as<uint32_t>();
     if (n_items) {
         if (in->item_seg)
@@ -1659,12 +1732,24 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         wk.slab_offset = 0;
         if (n_small) {
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
+            // groups cut by LDS budget (wider sort windows without the extra rounds of over-full groups) when the groups are of 64
+            const bool budget = c->lane_sort && wk.item_region && lane_gs == 64u;
             if (attempt == 0 && c->lane_sort) {
-                const uint32_t ch = (uint32_t)c->lane_sort_window;
+                const uint32_t ch = (uint32_t)(budget ? c->lane_budget_window : c->lane_sort_window);
                 const uint32_t chunks = (n0 + ch - 1) / ch + (n1 + ch - 1) / ch;
+                uint32_t *n_groups_dev = c->misc.as<uint32_t>() + 32;  // (misc was cleared before the class kernels)
+                if (budget) {
+                    // most groups a window can have: every group holds at least cap / (largest region) items
+                    const uint32_t per_group = std::max<uint32_t>(1u, (uint32_t)c->lane_capw / (uint32_t)std::max(1, c->lane_max_w));
+                    const size_t max_groups = (size_t)chunks * (ch / per_group + 2);
+                    HIP_TRY(c, c->lane_groups.ensure(max_groups * 8));
+                }
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
-                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch);
+                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch, (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
+                                   budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev);
             }
+            wk.lane_groups = budget ? c->lane_groups.as<uint32_t>() : nullptr;
+            wk.lane_n_groups = c->misc.as<uint32_t>() + 32;
             const size_t lds = lane_lds;
             const uint32_t gs = lane_gs, nblk = lane_nblk;
             wk.slab_pre = 1u;  // first slab by wave id

@@ -205,8 +205,9 @@ PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWo
     const bool do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
     const uint32_t n_m = wk.seg_nm ? wk.seg_nm[seg] : segment_n_merged(bt, seg);
     const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);  // (the lane kernel's LOAD merges match runs for these stages)
-    wk.item_cls[i] = (do_shift ? 1u : 0u) |
-                     ((wk.lane_max_w < 0 || lane_region_dwords((int)(merges ? n_m : n_in), w0, w1) > wk.lane_max_w) ? 2u : 0u);
+    const int region = lane_region_dwords((int)(merges ? n_m : n_in), w0, w1);
+    wk.item_cls[i] = (do_shift ? 1u : 0u) | ((wk.lane_max_w < 0 || region > wk.lane_max_w) ? 2u : 0u);
+    if (wk.item_region) wk.item_region[i] = (uint32_t)region;
     wk.d.n_m[i] = n_m;
     wk.d.in_off[i] = in_off;
     wk.d.n_in[i] = n_in;
@@ -261,6 +262,24 @@ PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint3
         }
     }
     return n;
+}
+
+// Groups of the lane-per-item kernel cut by LDS budget: `reg[0 .. n)` = region dwords of the items of one sorted window, in order.  A
+// group takes consecutive items while there are fewer than 64 of them and their regions fit `cap` dwords (at least one item: an item no
+// slice holds goes to the retry list inside the kernel).  Returns the number of groups; group k = items [start[k], start[k + 1]).
+// (A window sorted by weight has its long items together: cut into fixed 64s their group needs more LDS than the slice has and runs in
+// several rounds -- cut by budget it simply has fewer lanes.)
+template <class Reg>
+PLO_HD uint32_t lane_groups_cut(const Reg *reg, uint32_t n, uint32_t cap, uint32_t *start, uint32_t max_groups) {
+    uint32_t ng = 0, i = 0;
+    while (i < n && ng < max_groups) {
+        start[ng++] = i;
+        uint32_t j = i, tot = 0;
+        while (j < n && j - i < 64u && tot + (uint32_t)reg[j] <= cap) tot += (uint32_t)reg[j++];
+        i = j > i ? j : i + 1;
+    }
+    start[ng] = n;  // (max_groups reached with items left over cannot happen for max_groups >= n: callers size it by the window)
+    return ng;
 }
 
 // position of item i in class order, given the exclusive counts r0,r1,r2 of class-0/1/2 items before it and the class

@@ -1167,9 +1167,15 @@ template <bool SP>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
                                    uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx) {
     const uint32_t lane = (uint32_t)wv::lane();
+    // groups: cut by LDS budget (k_chunk_sort's list, wk.lane_groups) or fixed: `gs` items each from the start of either class
+    const bool listed = wk.lane_groups != nullptr;
     const uint32_t t0 = (n0 + gs - 1u) / gs, t1 = (n1 + gs - 1u) / gs;
+    const uint32_t n_groups = listed ? wv::bcast_first(*wk.lane_n_groups) : t0 + t1;
     auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
-        if (t < t0) {
+        if (listed) {
+            lo = wk.lane_groups[2 * t];
+            hi = lo + wk.lane_groups[2 * t + 1];
+        } else if (t < t0) {
             lo = t * gs;
             hi = lo + gs < n0 ? lo + gs : n0;
         } else {
@@ -1181,25 +1187,22 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
     // a wave does not keep drawing the longer (or the shorter) half of every sorted window (k_chunk_sort) when the number of waves
     // is even
     auto slot = [&](uint32_t j) { return j * stride + (first + j) % stride; };
-    uint32_t j = 0, t = slot(0);
+    // software pipeline over a wave's rounds: the bounds of the group after next, the item indices of the next group
+    uint32_t lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;  // group of round j (lo1, hi1 after the shift below), of round j + 1
     uint32_t g_next = 0;
-    if (t < t0 + t1) {
-        uint32_t lo, hi;
-        group(t, lo, hi);
-        g_next = lo + lane < hi ? wk.perm[lo + lane] : 0u;
+    if (slot(0) < n_groups) {
+        group(slot(0), lo1, hi1);
+        g_next = lo1 + lane < hi1 ? wk.perm[lo1 + lane] : 0u;
     }
-    for (; j * stride < t0 + t1; ++j) {
-        t = slot(j);
-        const uint32_t tn = slot(j + 1);
-        const uint32_t g = g_next;
-        if (tn < t0 + t1) {
-            uint32_t lo2, hi2;
-            group(tn, lo2, hi2);
-            g_next = lo2 + lane < hi2 ? wk.perm[lo2 + lane] : 0u;
-        }
-        if (t < t0 + t1) {
-            uint32_t lo, hi;
-            group(t, lo, hi);
+    if (slot(1) < n_groups) group(slot(1), lo2, hi2);
+    for (uint32_t j = 0; j * stride < n_groups; ++j) {
+        const uint32_t t = slot(j), tn = slot(j + 1), tnn = slot(j + 2);
+        const uint32_t g = g_next, lo = lo1, hi = hi1;
+        lo1 = lo2;
+        hi1 = hi2;
+        if (tn < n_groups) g_next = lo1 + lane < hi1 ? wk.perm[lo1 + lane] : 0u;
+        if (tnn < n_groups) group(tnn, lo2, hi2);
+        if (t < n_groups) {
             lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
             wv::sync();
         }

@@ -114,6 +114,11 @@ struct DevWork {
     uint32_t *huge_list;           // items too heavy for that one too: one wave per item in global scratch (k_lift_big)
     uint32_t stat_base;            // first statistic slot of the launch (every lift launch of a batch has its own range)
     uint32_t *miss_list;           // PLO_SEQ_BAM4_SPARSE: items whose probes needed absent bases (PLO_ITEM_NEED_BASES)
+    // lane-per-item kernel, groups cut by LDS budget (k_chunk_sort): the dwords of every light item's region (lane_region_dwords; written by
+    // build_item_desc when non-NULL), the groups {first position of the class order, items} and their number (device memory; NULL: fixed groups)
+    uint32_t *item_region;
+    const uint32_t *lane_groups;    // [2 * n]: lo, count
+    const uint32_t *lane_n_groups;  // [1]
 };
 
 }  // namespace plo

@@ -26,7 +26,7 @@ struct Out {
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
                                   int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, int lane_max_w, int lane_capw,
-                                  int lane_heavy_per, plo_batch_out *out, unsigned long long *counters_out) {
+                                  int lane_heavy_per, int lane_budget, plo_batch_out *out, unsigned long long *counters_out) {
     // lane_max_w >= 0: items up to that weight run through the lane-per-item code (lane_core.hpp) with an LDS slice of lane_capw
     // dwords per wave; what it cannot hold goes to the retry list like on the GPU
     // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
@@ -109,6 +109,8 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
     wk.item_cseg = o->item_cseg.data();
     wk.item_nin = item_nin.data();
     wk.item_cls = item_cls.data();
+    std::vector<uint32_t> item_region(a, 0);
+    wk.item_region = item_region.data();
     wk.d.in_off = d_in_off.data();
     wk.d.n_in = d_n_in.data();
     wk.d.pos1 = d_pos1.data();
@@ -217,6 +219,28 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         }
         // (items per group as the host picks them for small batches: 64 without an order seed, else 64 / 32 / 16 / 8 by the seed)
         const uint32_t lane_group = order_seed ? 64u >> (order_seed % 4u) : 64u;
+        // lane_budget: the groups cut by LDS budget inside windows of 128 positions of either class, as k_chunk_sort does on the GPU
+        // (lane_groups_cut, enumerate.hpp) -- listed groups of fewer than 64 items instead of fixed ones
+        std::vector<uint32_t> glist;
+        uint32_t n_glist = 0;
+        if (n_small && lane_budget && lane_group == 64u) {
+            for (int cls = 0; cls < 2; ++cls) {
+                const uint32_t c_lo = cls ? r0[n_items] : 0u, c_hi = cls ? n_small : r0[n_items];
+                for (uint32_t lo = c_lo; lo < c_hi; lo += 128u) {
+                    const uint32_t n = std::min(128u, c_hi - lo);
+                    std::vector<uint32_t> reg(n), start(n + 1);
+                    for (uint32_t k = 0; k < n; ++k) reg[k] = item_region[perm[lo + k]];
+                    const uint32_t ng = lane_groups_cut(reg.data(), n, (uint32_t)lane_capw, start.data(), n);
+                    for (uint32_t k = 0; k < ng; ++k) {
+                        glist.push_back(lo + start[k]);
+                        glist.push_back(start[k + 1] - start[k]);
+                    }
+                    n_glist += ng;
+                }
+            }
+            wk.lane_groups = glist.data();
+            wk.lane_n_groups = &n_glist;
+        }
         if (n_small) {  // k_lift_lanes: persistent waves over the groups of the two lane classes
             std::vector<uint32_t> llds((size_t)lane_capw + LANE_KVS_DWORDS + 16, 0xdeadbeefu);
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {

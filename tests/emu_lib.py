@@ -34,7 +34,7 @@ def lib():
         L = C.CDLL(_LIB)
         L.emu_liftover_batch.restype = C.c_int
         L.emu_liftover_batch.argtypes = [C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.PloBatchOut), C.POINTER(C.c_ulonglong)]
+                                         C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.PloBatchOut), C.POINTER(C.c_ulonglong)]
         L.emu_finish_batch.restype = C.c_int
         L.emu_finish_batch.argtypes = [C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloBatchOut), C.c_int,
                                        C.POINTER(abi.PloFinishOut)]
@@ -44,12 +44,12 @@ def lib():
 
 
 def liftover_batch(index: abi.IndexData, batch: abi.BatchData, stages=abi.STAGES_ALL, cap=768, window=256, big_thresh=256,
-                   big_cap=1 << 16, order_seed=0, mid_waves=0, mid_cap=2048, lane_max_w=-1, lane_capw=3072, lane_heavy_per=0):
+                   big_cap=1 << 16, order_seed=0, mid_waves=0, mid_cap=2048, lane_max_w=-1, lane_capw=3072, lane_heavy_per=0, lane_budget=0):
     d = index.to_desc()
     b = batch.to_desc()
     out = abi.PloBatchOut()
     counters = (C.c_ulonglong * 24)()
-    rc = lib().emu_liftover_batch(C.byref(d), C.byref(b), stages, cap, window, big_thresh, big_cap, order_seed, mid_waves, mid_cap, lane_max_w, lane_capw, lane_heavy_per, C.byref(out), counters)
+    rc = lib().emu_liftover_batch(C.byref(d), C.byref(b), stages, cap, window, big_thresh, big_cap, order_seed, mid_waves, mid_cap, lane_max_w, lane_capw, lane_heavy_per, lane_budget, C.byref(out), counters)
     res = abi.result_from_out(out)
     lib().emu_free_last()
     return rc, res, list(counters)

@@ -174,6 +174,20 @@ def test_lane_path_small_slices_rounds_and_overflow(oracle):
         _assert_same(ref, res)
 
 
+def test_lane_path_groups_cut_by_lds_budget(oracle):
+    """the lane kernel's groups as k_chunk_sort lists them when it cuts a sorted window by LDS budget (lane_groups_cut): consecutive items
+    while fewer than 64 and their regions fit the slice -- slices of 3072, 600 and 96 dwords (groups of 64, of a dozen, of one or two
+    items; an item no slice holds still goes to the retry list), fixed order and shuffled lanes"""
+    w = synth.generate(synth.config("tiny", n_reads=200, seed=135, split_read_frac=0.2, read_len_mean=2500, read_len_sd=900))
+    ix, b = w.index_data(), w.batch_data()
+    for stages in (abi.STAGES_ALL, abi.STAGE_STRAND | abi.STAGE_LIFTOVER):
+        ref = oracle.liftover_batch(ix, b, stages, 1)
+        for capw, seed in ((3072, 0), (600, 0), (96, 0), (600, 4712)):
+            rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=4096, lane_capw=capw, order_seed=seed, lane_budget=1)
+            assert rc == 0
+            _assert_same(ref, res)
+
+
 def test_lane_path_indel_dense(oracle):
     cfg = synth.config("tiny", n_reads=48, seed=133, read_len_mean=1500, read_len_sd=300,
                        read_rates=synth.EditRates(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1),

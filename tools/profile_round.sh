@@ -14,6 +14,9 @@ tools/pmc_pass.sh "FETCH_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA 
 tools/pmc_pass.sh "WRITE_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_write.csv 2>&1
 tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
 tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
+tools/pmc_pass.sh "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_tcc.csv 2>&1
+# what FETCH_SIZE counts for scattered 16-byte loads (tools/calib_fetch.hip): the factor save_profiles.py applies
+tools/calib_fetch.sh $o/fetch_calibration.json > $o/fetch_calibration.log 2>&1
 # stress: the lane-per-item kernel over heavy items (100 k heavy items: above its threshold)
 S="--workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0"
 SK=${PLO_PROFILE_STRESS_KERNEL:-k_lift_lanes_g}

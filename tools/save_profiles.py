@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ver = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = f"gpurun_out/{ver}"
 pre = f"profiles/{rnd}_{ver}_wgs30x"
 rows = list(csv.reader(open(f"{src}/kernel_stats.csv")))
@@ -35,13 +35,29 @@ with open(f"{pre}_pmc_summary.csv", "w") as f:
     f.write("# rocprofv3 --pmc <counters> --kernel-include-regex <dominant kernel> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-workers 0 --window-calls 0 --e2e-reads 0\n")
     f.write("# one pass per counter group (tools/pmc_pass.sh, tools/profile_round.sh); value = mean over the 3 launches of the dominant kernel (k_lift_lanes for this workload); FETCH_SIZE / WRITE_SIZE in KiB\n")
     f.write("counter,mean_per_launch,launches\n")
-    for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"]:
-        for l in open(f"{src}/{p}.csv"):
-            if "," in l:
-                f.write(l)
+    for p in ["pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_tcc"]:
+        if os.path.exists(f"{src}/{p}.csv"):
+            for l in open(f"{src}/{p}.csv"):
+                if "," in l:
+                    f.write(l)
+# the factor between FETCH_SIZE and bytes moved, MEASURED for scattered 16-byte loads (tools/calib_fetch.hip; 2.0 = the L2 fetches whole
+# 128-byte lines and tallies 64 bytes per request, for scattered accesses as for streaming ones)
+fetch_factor, calib = 2.0, None
+if os.path.exists(f"{src}/fetch_calibration.json"):
+    calib = json.load(open(f"{src}/fetch_calibration.json"))
+    shutil.copy(f"{src}/fetch_calibration.json", f"profiles/{rnd}_{ver}_fetch_calibration.json")
+    if "_conclusion" in calib:
+        fetch_factor = float(calib["_conclusion"]["factor_scattered"])
 h = json.load(open("profiles/hbm_traffic.json"))
 b = json.load(open(f"{src}/bench.json"))
-h["wgs30x"] = {b["roofline"]["kernel"]: int((2 * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr,
+h["_about"] = ("HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, --kernel-include-regex "
+               "<kernel>; tools/profile_round.sh).  The counters are KiB; traffic_bytes = (_fetch_factor * FETCH_SIZE + WRITE_SIZE) * 1024.  _fetch_factor is MEASURED for this "
+               "kernel's access pattern by tools/calib_fetch.hip (scattered 16-byte loads at known distinct 128-byte lines: one request per line, tallied at 64 bytes, also "
+               "when both halves of the line are touched => the L2 fetches whole lines and the counter reports half the bytes, as for streaming reads).  bench.py copies the "
+               "number for its workload into roofline.traffic when workload, read count, GPU count and kernel-source hash (portello_amd/build.py source_hash()) match.  "
+               "Every entry is written by tools/save_profiles.py from the passes' output; none is typed by hand.")
+h["_fetch_factor"] = {"value": fetch_factor, "source": (f"profiles/{rnd}_{ver}_fetch_calibration.json" if calib else "MI355X_MICROARCH.md (streaming reads); not calibrated in this run")}
+h["wgs30x"] = {b["roofline"]["kernel"]: int((fetch_factor * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr, "_fetch_factor": fetch_factor,
                "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
                "_reads": b["config"]["reads_this_rank"], "_source_hash": b["config"]["kernel_source_hash"], "_n_gpus": b["n_gpus"]}
 json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
@@ -76,7 +92,7 @@ if os.path.exists(f"{src}/stress_kernel_stats.csv"):
                 if "," in l:
                     f.write(l)
     sb = json.load(open(f"{src}/stress_bench.json"))
-    h["stress"] = {sb["roofline"]["kernel"]: int((2 * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr,
+    h["stress"] = {sb["roofline"]["kernel"]: int((fetch_factor * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr, "_fetch_factor": fetch_factor,
                    "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"],
                    "_reads": sb["config"]["reads_this_rank"], "_source_hash": sb["config"]["kernel_source_hash"], "_n_gpus": sb["n_gpus"]}
     json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)

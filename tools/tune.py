@@ -62,7 +62,7 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         if i:
             ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.mid_ms); la.append(t.lanes_ms)
     print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(la):.3f} ms ({t.n_lane_items} items)  mid {np.mean(ln):.3f} ms ({t.n_mid_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
-          f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big)+np.mean(la))/1e3:.1f} M items/s", flush=True)
+          f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big)+np.mean(la))/1e3:.1f} M items/s  lane utilisation {t.lane_utilisation:.3f}", flush=True)
     if args.timing:
         ph = (C.c_ulonglong * 12)()
         L.plo_ctx_phase_cycles(eng.handle, ph)
