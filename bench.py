@@ -559,7 +559,7 @@ def main():
     if args.reads:
         over["n_reads"] = args.reads
     cfg = synth.config(args.workload, **over)
-    chunk_reads = args.chunk_reads or (250_000 if cfg.name.startswith("stress") else 8_000_000)
+    chunk_reads = args.chunk_reads or (500_000 if cfg.name.startswith("stress") else 8_000_000)  # (stress: 16.0 M reads/s at 500 k per batch, 14.7 M at 250 k)
     if world == 1 and dist is None and cfg.n_reads > chunk_reads:
         rc = stream_main(args, cfg, dev, dev_index, chunk_reads)
         if rc:

@@ -691,6 +691,14 @@ __global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_
                                                                                                      uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
     lift_lanes_g_kernel<false>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
 }
+// The same kernel at three waves per SIMD (168 VGPRs, 144 B of spills per lane; 3 x 53 KB of LDS windows are exactly a CU's): slower for a lone
+// wave -- 10.0 against 9.5 ms at 100 k stress reads, where every resident wave has one group and the kernel takes as long as its longest item
+// -- and faster once the waves have several groups each and the kernel is bound by issue throughput: 25.7 against 29.3 ms at 500 k reads.
+// Chosen by the number of heavy items (liftover_core).
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lift_lanes_g_w3(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
+                                                                                                     uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
+    lift_lanes_g_kernel<false>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
+}
 __global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_G_WPE, PLO_LANE_G_WPE))) void k_lift_lanes_g_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t lo,
                                                                                                         uint32_t mid, uint32_t hi, uint32_t per, uint32_t *scratch, int stride) {
     lift_lanes_g_kernel<true>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
@@ -1762,8 +1770,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
         if (heavy_lanes) {
             // as many items per wave as it takes to give every resident wave a group (at least 8, at most 64 lanes at work)
-            const int occ = PLO_LANE_G_WPE;  // (4 waves a workgroup, one per SIMD)
             const uint32_t n_heavy = n_items - n_small, n2 = h_cls[2], n3 = n_heavy - n2;
+            // three waves per SIMD once every one of their slots gets a full group (k_lift_lanes_g_w3 above); PLO_LANE_G_W3=0/1 forces
+            bool w3 = !sp && n_heavy >= (uint32_t)c->n_cus * 3u * LANE_G_WAVES * 64u;
+            if (const char *e = getenv("PLO_LANE_G_W3")) w3 = !sp && atoi(e) != 0;
+            const int occ = w3 ? 3 : PLO_LANE_G_WPE;  // (4 waves a workgroup, one per SIMD)
             const uint32_t slots = (uint32_t)(c->n_cus * occ) * LANE_G_WAVES;
             uint32_t per = std::min(64u, std::max(8u, (n_heavy + slots - 1) / slots));
             if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
@@ -1789,6 +1800,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             if (!n_small) wk.slab_offset = 0ull;
             PLO_STAT_RANGE(nblk * LANE_G_WAVES);
             if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+            else if (w3) hipLaunchKernelGGL(k_lift_lanes_g_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
             else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[2], st));

@@ -55,13 +55,13 @@ for s in [(a, b) for a in args.settings.split(",") for b in args.stages.split(",
         os.environ["PLO_TILE_WAVES"] = parts[3] if len(parts) > 3 else "4"
         os.environ["PLO_WINDOW"], os.environ["PLO_BIG_THRESH"], os.environ["PLO_CAP"] = win, thr, cap
     eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
-    ms, big, en, ln, la = [], [], [], [], []
+    ms, big, en, ln, la, hv = [], [], [], [], [], []
     for i in range(args.steps + 1):
         eng.liftover_batch_dev(desc, stages)
         t = eng.timing()
         if i:
-            ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.mid_ms); la.append(t.lanes_ms)
-    print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(la):.3f} ms ({t.n_lane_items} items)  mid {np.mean(ln):.3f} ms ({t.n_mid_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
+            ms.append(t.lift_ms); big.append(t.big_ms); en.append(t.enumerate_ms); ln.append(t.mid_ms); la.append(t.lanes_ms); hv.append(t.heavy_lanes_ms)
+    print(f"tw={os.environ.get('PLO_TILE_WAVES', 'auto')} stages={stages} window={win} thresh={thr} cap={cap}: lanes {np.mean(la):.3f} ms ({t.n_lane_items} items)  heavy lanes {np.mean(hv):.3f} ms ({t.n_heavy_lane_items} items)  mid {np.mean(ln):.3f} ms ({t.n_mid_items} items, {t.n_retry_items} retried)  tiles {np.mean(ms):.3f} ms  big {np.mean(big):.3f} ms ({t.n_big_items} items)  enum {np.mean(en):.3f} ms  "
           f"items {t.n_items}  {t.n_items/(np.mean(ms)+np.mean(ln)+np.mean(big)+np.mean(la))/1e3:.1f} M items/s  lane utilisation {t.lane_utilisation:.3f}", flush=True)
     if args.timing:
         ph = (C.c_ulonglong * 12)()
