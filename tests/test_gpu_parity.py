@@ -286,7 +286,7 @@ def test_full_size_properties_chr20(oracle):
     eng_ix.close()
 
 
-def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, **over):
+def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, threads=8, **over):
     import torch
 
     import fullsize
@@ -305,7 +305,7 @@ def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, **over):
     assert (res2.item_status == res.item_status).all()
     for i in range(0, res.n_items, 97):
         assert np.array_equal(res.item_cigar(i), res2.item_cigar(i))
-    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, n_blocks, block)
+    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, n_blocks, block, threads=threads)
     _dump(f"full_size_{name}.json", {"reads": w.n_reads, "items": int(res.n_items), "items_compared_with_oracle": n_cmp,
                                      "of_them_flipped": n_flip, "contigs_in_sample": n_contigs, "large_items": int(t.n_big_items),
                                      "mid_items": int(getattr(t, "n_mid_items", 0)), "retry_items": int(t.n_retry_items),
@@ -317,9 +317,9 @@ def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, **over):
 
 
 def test_full_size_wgs30x(oracle):
-    """BASELINE configs[2] (the bench workload) at full size: properties of all ~2 M records + oracle parity on 50 blocks of
-    400 reads spread over the whole coordinate-sorted read set"""
-    _full_size("wgs30x", oracle, 50, 400)
+    """BASELINE configs[2] (the bench workload) at full size: properties of all ~2 M records + oracle parity on 250 blocks of
+    1 000 reads spread over the whole coordinate-sorted read set (an eighth of all items, as in the bench's own sample)"""
+    _full_size("wgs30x", oracle, 250, 1000, threads=os.cpu_count() or 8)
 
 
 def test_full_size_stress(oracle):
