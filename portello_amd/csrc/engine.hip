@@ -1751,6 +1751,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                     const uint32_t per_group = std::max<uint32_t>(1u, (uint32_t)c->lane_capw / (uint32_t)std::max(1, c->lane_max_w));
                     const size_t max_groups = (size_t)chunks * (ch / per_group + 2);
                     HIP_TRY(c, c->lane_groups.ensure(max_groups * 8));
+                    if (getenv("PLO_DEBUG_GEOMETRY"))
+                        fprintf(stderr, "[plo] lane groups cut by LDS budget: windows of %u, slices of %d dwords, at most %zu groups\n", ch, c->lane_capw, max_groups);
                 }
                 hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
                                    (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch, (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,

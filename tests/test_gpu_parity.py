@@ -409,6 +409,34 @@ def test_every_item_of_100k_stress_reads_heavy_lane_kernel(oracle):
     index.close()
 
 
+@pytest.mark.parametrize("window", ["256", "512", "2048"])
+def test_lane_groups_cut_by_lds_budget_on_the_gpu(oracle, monkeypatch, capfd, window):
+    """PLO_LANE_BUDGET=1 (off by default): k_chunk_sort sorts wider windows and cuts them into the lane kernel's groups by LDS
+    budget on the device (prefix sums + a binary search per position + the chain of group starts), the persistent waves walk the list -- every
+    item of a 60 k-read workload against the oracle, with the default slice and with one so small that groups hold a dozen items"""
+    import torch
+
+    from portello_amd import devbatch
+
+    monkeypatch.setenv("PLO_LANE_BUDGET", "1")
+    monkeypatch.setenv("PLO_LANE_SORT_WINDOW", window)
+    monkeypatch.setenv("PLO_LANE_GROUP", "64")  # (a batch this small would get groups of 32, which are not cut by budget)
+    monkeypatch.setenv("PLO_DEBUG_GEOMETRY", "1")
+    w = synth.generate(synth.config("chr20", n_reads=60_000, seed=synth.config("chr20").seed + 31), device="cuda")
+    index = api.Index(w.index_data_device())
+    ref = oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, os.cpu_count() or 8).canonical()
+    for capw in ("3072", "768"):
+        monkeypatch.setenv("PLO_LANE_CAPW", capw)
+        eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+        got = devbatch.run_and_download(eng, devbatch.DeviceBatch.from_workload(w))
+        t = eng.timing()
+        assert t.n_lane_items > 0.9 * got.n_items
+        assert got.canonical() == ref, f"window {window} capw {capw}"
+        assert "lane groups cut by LDS budget" in capfd.readouterr().err  # (the path under test was the one that ran)
+        eng.close()
+    index.close()
+
+
 def test_geometry_sweep(oracle):
     """every item of five workloads with different contig block-map densities / strand mixes (hence different per-batch tile
     geometries, retry and large-item traffic) against the oracle (tests/soak.py at a size that finishes in a minute)"""
