@@ -352,8 +352,12 @@ constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SOR
 // items while there are fewer than 64 and their regions fit `cap` dwords) and the groups are appended to the list ({first position, count};
 // *n_groups zeroed by the host).  A window sorted by weight has its long items together; as fixed groups of 64 those need more LDS than a
 // wave's slice and run in several rounds -- which is what made windows larger than 128 slower although they level the lanes better.
-__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *weight, uint32_t n0, uint32_t n1, uint32_t chunk,
-                                                                  const uint32_t *region, uint32_t cap, uint32_t *glist, uint32_t *n_groups) {
+// Sort key: what the group's loops run for -- the merged op count n_m (= / X ops, which the tiling weight counts, are merged away before any
+// loop sees them) plus the block-map entries of the item's window (the liftover loop's extra pieces); in the class with the shift stage n_m
+// counts twice (its rounds and scans follow the indel clusters, half of n_m, and cost twice a liftover iteration).  Off line, windows of 128,
+// against the tiling weight: shift rounds per group 1.67 -> 1.52 x the mean, liftover iterations 1.59 -> 1.49 (forward class) / 1.56.
+__global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *n_m, const uint32_t *w0, const uint32_t *w1, uint32_t n0, uint32_t n1,
+                                                                  uint32_t chunk, const uint32_t *region, uint32_t cap, uint32_t *glist, uint32_t *n_groups) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
     __shared__ uint16_t reg[LANE_SORT_MAX_CHUNK], nxt[LANE_SORT_MAX_CHUNK];
@@ -379,7 +383,8 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
 #pragma unroll
     for (uint32_t j = 0; j < LANE_SORT_PER; ++j) {
         const uint32_t p = lo + j * LANE_SORT_THREADS + threadIdx.x;
-        uint32_t w = p < hi ? weight[g[j]] : 0u;
+        uint32_t w = 0u;
+        if (p < hi) w = (blockIdx.x < c0 ? n_m[g[j]] : 2u * n_m[g[j]]) + (w1[g[j]] - w0[g[j]]);
         k[j] = w < 255u ? w : 255u;
         if (p < hi) atomicAdd(&hist[k[j]], 1u);
     }
@@ -1754,8 +1759,9 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                     if (getenv("PLO_DEBUG_GEOMETRY"))
                         fprintf(stderr, "[plo] lane groups cut by LDS budget: windows of %u, slices of %d dwords, at most %zu groups\n", ch, c->lane_capw, max_groups);
                 }
-                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(),
-                                   (const uint32_t *)c->item_nin.as<uint32_t>(), n0, n1, ch, (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
+                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
+                                   (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch,
+                                   (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
                                    budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev);
             }
             wk.lane_groups = budget ? c->lane_groups.as<uint32_t>() : nullptr;
