@@ -1175,12 +1175,20 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         if (listed) {
             lo = wk.lane_groups[2 * t];
             hi = lo + wk.lane_groups[2 * t + 1];
-        } else if (t < t0) {
-            lo = t * gs;
-            hi = lo + gs < n0 ? lo + gs : n0;
         } else {
-            lo = n0 + (t - t0) * gs;
-            hi = lo + gs < n0 + n1 ? lo + gs : n0 + n1;
+            // the two classes interleaved (group 0 of the first, group 0 of the second, group 1 of the first, ...; the longer class's rest
+            // behind): the groups with the shift stage are the ones whose probes load the memory system, and a kernel that runs all the
+            // others first and all of them last has every wave probing at the same time
+            const uint32_t m = t0 < t1 ? t0 : t1;
+            const bool second = t < 2u * m ? (t & 1u) != 0u : t1 > t0;
+            const uint32_t idx = t < 2u * m ? t >> 1 : t - m;
+            if (!second) {
+                lo = idx * gs;
+                hi = lo + gs < n0 ? lo + gs : n0;
+            } else {
+                lo = n0 + idx * gs;
+                hi = lo + gs < n0 + n1 ? lo + gs : n0 + n1;
+            }
         }
     };
     // round j: wave w takes group j * stride + (w + j) % stride -- the waves rotate through the slots from round to round, so that
