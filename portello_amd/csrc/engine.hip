@@ -72,40 +72,29 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     // Two dependent chains, issued side by side so that the kernel is three memory round trips deep instead of five:
     //   CIGAR offsets -> ops (reference span)   and   contig -> its segment range -> segment intervals (overlap test,
     //   one contig segment per lane of the group)
-    uint32_t c0 = 0, c1 = 0, contig = 0;
+    uint32_t c0 = 0, c1 = 0, contig = 0, rd = 0;
     long long r_start = 0;
-    if (live) {
+    if (live) {  // level 0: the segment's own fields
         c0 = bt.seg_cigar_off[s];
         c1 = bt.seg_cigar_off[s + 1];
         contig = bt.seg_contig[s];
         r_start = (long long)bt.seg_pos[s];
+        rd = bt.seg_read[s];
         if (c1 < c0 || c1 > 0x7fffffffu) {  // (ops are indexed with int: more than 2^31 - 1 of them cannot be addressed)
             bad |= c1 < c0 ? VERR_INDEX : VERR_RANGE;
             c1 = c0;
         }
         if (r_start < 0 || r_start > 0x7ffffff0LL) bad |= VERR_RANGE;
         if (contig >= ix.n_contigs) bad |= VERR_INDEX;
-        if (sub == 0) {
-            const uint32_t rd = bt.seg_read[s];
-            if (rd >= bt.n_reads) {
-                bad |= VERR_INDEX;
-            } else {
-                const unsigned long long len = bt.read_seq_len[rd];
-                // (sparse bases: the header must lie inside the buffer; where it points is checked by every probe)
-                const unsigned long long need = bt.seq_fmt == PLO_SEQ_BAM4          ? (len + 1) / 2
-                                                : bt.seq_fmt == PLO_SEQ_BAM4_SPARSE ? (unsigned long long)sparse_header_bytes((uint32_t)len)
-                                                                                    : len;
-                const unsigned long long off = bt.read_seq_off[rd];
-                if (off > bt.seq_bytes || need > bt.seq_bytes - off) bad |= VERR_INDEX;
-                if (bt.seq_fmt == PLO_SEQ_BAM4_SPARSE && (off & 15ull)) bad |= VERR_INDEX;
-            }
-        }
+        if (rd >= bt.n_reads) bad |= VERR_INDEX;
     }
-    uint32_t g0 = 0, g1 = 0;
-    if (live && contig < ix.n_contigs) {
-        g0 = ix.contig_seg_off[contig];
-        g1 = ix.contig_seg_off[contig + 1];  // g0 == g1: contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367)
-    }
+    // level 1, all of it unconditional (lanes without a valid index read plo_safe_words): the read's length and offset, the contig's segment
+    // range -- and, in the loop below, the ops
+    const bool rd_ok = live && sub == 0 && rd < bt.n_reads, ct_ok = live && contig < ix.n_contigs;
+    const unsigned long long len = *(rd_ok ? bt.read_seq_len + rd : (const uint32_t *)plo_safe_words);
+    const unsigned long long off = *(rd_ok ? bt.read_seq_off + rd : (const uint64_t *)plo_safe_words);
+    const uint32_t *const gp = ct_ok ? ix.contig_seg_off + contig : (const uint32_t *)plo_safe_words;
+    const uint32_t g0 = gp[0], g1 = gp[1];  // g0 == g1: contig never seen in the asm->ref BAM (contig_alignment_scanner/mod.rs:364-367), or no contig
     long long part = 0;
     unsigned long long rpart = 0;  // read bases the CIGAR consumes (M I S H = X): what the length check compares with seq_len
     // Every lane of the group takes eight CONSECUTIVE ops per step (two 16-byte loads; the group's four lanes 128 contiguous bytes), so
@@ -158,6 +147,14 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
         pairs += (uint32_t)__shfl_xor((int)pairs, (int)d, 64);
     }
     if (part > 0x3fffffffLL) bad |= VERR_RANGE;
+    if (rd_ok) {
+        // (sparse bases: the header must lie inside the buffer; where it points is checked by every probe)
+        const unsigned long long need = bt.seq_fmt == PLO_SEQ_BAM4          ? (len + 1) / 2
+                                        : bt.seq_fmt == PLO_SEQ_BAM4_SPARSE ? (unsigned long long)sparse_header_bytes((uint32_t)len)
+                                                                            : len;
+        if (off > bt.seq_bytes || need > bt.seq_bytes - off) bad |= VERR_INDEX;
+        if (bt.seq_fmt == PLO_SEQ_BAM4_SPARSE && (off & 15ull)) bad |= VERR_INDEX;
+    }
     if (bad) atomicOr(err, bad);
     const long long r_end = r_start + part;
     // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end (int_range.rs:56-58)
@@ -177,8 +174,14 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
 __global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off, int *seg_reflen) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
-    if (seg_off[s + 1] == seg_off[s]) return;
-    enumerate_segment(ix, bt, s, &wk, stages, seg_off[s], seg_reflen);
+    // (level 0 of the descriptor loads goes out with the offsets: enumerate.hpp)
+    const uint32_t o0 = seg_off[s], o1 = seg_off[s + 1];
+    const int ref_len = seg_reflen[s];
+    SegInfo si;
+    seg_info_level0(si, bt, wk, stages, s);
+    if (o0 == o1) return;  // (no items -- among them the segments whose contig the index does not know: nothing below is indexed by it)
+    seg_info_level1(si, ix, bt, wk, stages, s);
+    emit_segment_items(ix, wk, stages, s, o0, (long long)ref_len, si);
 }
 
 // Block maps of the contig segments, built on the device at index creation: thread per contig split segment walks its

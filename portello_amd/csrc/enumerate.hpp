@@ -8,6 +8,34 @@
 
 namespace plo {
 
+// 32 readable bytes in global memory: where the lanes without a valid address point their (unconditional) loads.  A load inside a
+// lane-divergent branch is waited for at the end of that branch (the merge needs the value); an unconditional one only where its value
+// is used, so that independent loads are in flight together.
+#ifdef PLO_EMULATOR
+alignas(16) static const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+alignas(16) static __device__ const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+// End of a level of loads: an empty volatile statement that takes the loaded values as operands.  Every load of the level is issued in front
+// of it and waited for there -- once -- instead of being sunk by the compiler to the branch that uses it and waited for one by one.
+#ifdef PLO_EMULATOR
+#define PLO_LEVEL_END(...)
+#else
+#define PLO_LV_(x) "v"(x)
+#define PLO_LV1(a) PLO_LV_(a)
+#define PLO_LV2(a, ...) PLO_LV_(a), PLO_LV1(__VA_ARGS__)
+#define PLO_LV3(a, ...) PLO_LV_(a), PLO_LV2(__VA_ARGS__)
+#define PLO_LV4(a, ...) PLO_LV_(a), PLO_LV3(__VA_ARGS__)
+#define PLO_LV5(a, ...) PLO_LV_(a), PLO_LV4(__VA_ARGS__)
+#define PLO_LV6(a, ...) PLO_LV_(a), PLO_LV5(__VA_ARGS__)
+#define PLO_LV7(a, ...) PLO_LV_(a), PLO_LV6(__VA_ARGS__)
+#define PLO_LV8(a, ...) PLO_LV_(a), PLO_LV7(__VA_ARGS__)
+#define PLO_LV9(a, ...) PLO_LV_(a), PLO_LV8(__VA_ARGS__)
+#define PLO_LV_N(_1, _2, _3, _4, _5, _6, _7, _8, _9, n, ...) PLO_LV##n
+#define PLO_LEVEL_END(...) asm volatile("" ::PLO_LV_N(__VA_ARGS__, 9, 8, 7, 6, 5, 4, 3, 2, 1)(__VA_ARGS__))
+#endif
+
 // get_cigar_ref_offset (lib/rust-vc-utils/src/bam_utils/cigar/mod.rs:174-180)
 PLO_DEV long long segment_ref_len(const DevBatch &bt, uint32_t seg) {
     uint32_t c0 = bt.seg_cigar_off[seg], c1 = bt.seg_cigar_off[seg + 1];
@@ -54,7 +82,7 @@ PLO_DEV int lane_region_dwords(int n, int w0, int w1) { return n + lane_region_g
 // block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
 // Eight-way: seven independent probes per level, so that a map of a few thousand blocks costs four or five memory round trips
 // instead of a dozen dependent ones (the descriptor kernel is a chain of dependent loads per item, nothing else).
-PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
+PLO_DEV void kv_upper_bound_narrow(const KV *kv, int &lo, int &hi, int x) {  // narrows [lo,hi) to at most eight entries around the answer
     // invariant: keys below lo are <= x, keys from hi on are > x
     while (hi - lo > 8) {
         const int step = (hi - lo) >> 3;
@@ -68,13 +96,19 @@ PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first inde
         hi = c < 7 ? lo + (c + 1) * step : hi;
         lo = nlo;
     }
+}
+PLO_DEV int kv_upper_bound_tail(const KV *kv, int lo, int hi, int x) {  // hi - lo <= 8
     int k[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) k[j] = lo + j < hi ? kv[lo + j].key : 0x7fffffff;
+    for (int j = 0; j < 8; ++j) k[j] = (lo + j < hi ? kv + (lo + j) : (const KV *)plo_safe_words)->key;  // (eight loads, one round trip)
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c += (lo + j < hi && k[j] <= x) ? 1 : 0;
+    for (int j = 0; j < 8; ++j) c += ((lo + j < hi) & (k[j] <= x)) ? 1 : 0;
     return lo + c;
+}
+PLO_DEV int kv_upper_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key > x, else hi
+    kv_upper_bound_narrow(kv, lo, hi, x);
+    return kv_upper_bound_tail(kv, lo, hi, x);
 }
 PLO_DEV int kv_lower_bound(const KV *kv, int lo, int hi, int x) {  // first index in [lo,hi) with key >= x, else hi
     while (lo < hi) {
@@ -93,10 +127,10 @@ PLO_DEV int kv_lower_bound_near(const KV *kv, int lo, int hi, int x) {
     {   // the next eight entries at once: nearly always enough (a read crosses a few blocks)
         int k[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) k[j] = lo + j < hi ? kv[lo + j].key : 0x7fffffff;
+        for (int j = 0; j < 8; ++j) k[j] = (lo + j < hi ? kv + (lo + j) : (const KV *)plo_safe_words)->key;
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c += (lo + j < hi && k[j] < x) ? 1 : 0;
+        for (int j = 0; j < 8; ++j) c += ((lo + j < hi) & (k[j] < x)) ? 1 : 0;
         if (c < 8 || lo + 8 >= hi) return lo + c;
         lo += 8;
     }
@@ -173,67 +207,149 @@ PLO_DEV int item_weight(int n_in, int w0, int w1, int kv1) {
 }
 enum { LEVEL_TILE = 0, LEVEL_RETRY = 1, LEVEL_LAST = 2, LEVEL_MID = 3 };
 
+// The descriptor code is a chain of dependent loads per item and nothing else, so it is written level by level: every load of a level
+// is issued before the first use of any of them, and every store comes after the last load (stores and loads may alias for all the
+// compiler knows, and the memory counter is in order: a load behind a store waits for the store).
+
+// What an item needs through its read segment: the segment's own fields (level 0), then its read's and its contig's (level 1)
+struct SegInfo {
+    uint32_t contig, read, in_off, n_in, n_m, read_len, g0, g1, seq_len;
+    int contig_len;
+    long long pos;
+    uint64_t seq_off, revseq;
+    bool seg_fwd, read_rev;
+};
+PLO_DEV void seg_info_level0(SegInfo &s, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t seg) {
+    s.contig = bt.seg_contig[seg];
+    s.read = bt.seg_read[seg];
+    s.in_off = bt.seg_cigar_off[seg];
+    s.n_in = bt.seg_cigar_off[seg + 1];
+    s.pos = (long long)bt.seg_pos[seg];
+    s.n_m = wk.seg_nm ? wk.seg_nm[seg] : 0u;
+    s.read_len = wk.seg_readlen ? wk.seg_readlen[seg] : 0u;
+    const uint32_t sf = (stages & PLO_STAGE_STRAND) ? (uint32_t)bt.seg_is_fwd[seg] : 0u;
+    PLO_LEVEL_END(s.contig, s.read, s.in_off, s.n_in, s.pos, s.n_m, s.read_len, sf);
+    s.seg_fwd = sf != 0u;
+    s.n_in -= s.in_off;
+}
+PLO_DEV void seg_info_level1(SegInfo &s, const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t seg) {
+    s.g0 = ix.contig_seg_off[s.contig];
+    s.g1 = ix.contig_seg_off[s.contig + 1];
+    s.contig_len = ix.contig_len[s.contig];
+    s.revseq = ix.contig_revseq ? (uint64_t)(uintptr_t)ix.contig_revseq[s.contig] : 0ull;
+    s.seq_len = bt.read_seq_len[s.read];
+    s.seq_off = bt.read_seq_off[s.read];
+    const uint32_t rr = (stages & PLO_STAGE_STRAND) ? (uint32_t)bt.read_is_reverse[s.read] : 0u;
+    PLO_LEVEL_END(s.g0, s.g1, s.contig_len, s.revseq, s.seq_len, s.seq_off, rr);
+    s.read_rev = rr != 0u;
+    if (!wk.seg_nm) s.n_m = segment_n_merged(bt, seg);
+    if (!wk.seg_readlen) s.read_len = segment_read_len_sat(bt, seg);
+}
+// ... and through its contig split segment (level 2: one index, seven arrays)
+struct CsegInfo {
+    int start, end;
+    uint32_t kv0, kv1, chrom;
+    uint8_t is_fwd, mapq;
+};
+PLO_DEV CsegInfo cseg_info(const DevIndex &ix, uint32_t gseg) {
+    CsegInfo c;
+    c.start = ix.cs_start[gseg];
+    c.end = ix.cs_end[gseg];
+    c.kv0 = ix.cs_kv_off[gseg];
+    c.kv1 = ix.cs_kv_off[gseg + 1];
+    c.chrom = ix.cs_chrom[gseg];
+    const uint32_t f = ix.cs_is_fwd[gseg], q = ix.cs_mapq[gseg];
+    PLO_LEVEL_END(c.start, c.end, c.kv0, c.kv1, c.chrom, f, q);
+    c.is_fwd = (uint8_t)f;
+    c.mapq = (uint8_t)q;
+    return c;
+}
+
 // Resolves everything the tile kernel needs to know about item i = (read segment seg, contig segment cseg):
 // the caller glue of get_liftover_alignment_for_read_and_contig_segment (src/read_alignment_scanner.rs:146-176) --
 // need_flipped (:153-157), rev_pos (:164-166) -- plus the window of the block map the item can touch.
-PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t i, uint32_t seg,
-                             uint32_t cseg, long long ref_len) {
-    uint32_t contig = bt.seg_contig[seg];
-    uint32_t gseg = ix.contig_seg_off[contig] + cseg;
-    uint32_t read = bt.seg_read[seg];
-    uint32_t in_off = bt.seg_cigar_off[seg];
-    uint32_t n_in = bt.seg_cigar_off[seg + 1] - in_off;
-    bool contig_fwd = ix.cs_is_fwd[gseg] != 0;
+PLO_DEV void build_item_desc(const DevIndex &ix, const DevWork &wk, uint32_t stages, uint32_t i, uint32_t seg, uint32_t cseg, long long ref_len,
+                             const SegInfo &s, const CsegInfo &c) {
+    const bool contig_fwd = c.is_fwd != 0;
     bool flip = false, rev = false;
     if (stages & PLO_STAGE_STRAND) {
-        bool changes = (bt.read_is_reverse[read] != 0) == (bt.seg_is_fwd[seg] != 0);
+        const bool changes = s.read_rev == s.seg_fwd;
         flip = (!contig_fwd) != changes;
         rev = !contig_fwd;
     }
-    long long pos = (long long)bt.seg_pos[seg];
-    long long pos1 = rev ? (long long)ix.contig_len[contig] - (pos + ref_len) : pos;
-    int kv0 = (int)ix.cs_kv_off[gseg], kv1 = (int)ix.cs_kv_off[gseg + 1];
+    const long long pos1 = rev ? (long long)s.contig_len - (s.pos + ref_len) : s.pos;
+    const int kv0 = (int)c.kv0, kv1 = (int)c.kv1;
     // every contig position the item can touch lies in [pos1, pos1 + ref_len]
-    long long lo = pos1 < -0x7fffffffLL ? -0x7fffffffLL : pos1;
-    long long hi = pos1 + ref_len > 0x7fffffffLL ? 0x7fffffffLL : pos1 + ref_len;
-    int ub = kv_upper_bound(ix.kv, kv0, kv1, (int)lo);
-    int w0 = ub - 1 > kv0 ? ub - 1 : kv0;
-    int w1 = kv_lower_bound_near(ix.kv, w0, kv1, (int)hi);
+    const long long lo = pos1 < -0x7fffffffLL ? -0x7fffffffLL : pos1;
+    const long long hi = pos1 + ref_len > 0x7fffffffLL ? 0x7fffffffLL : pos1 + ref_len;
+    int slo = kv0, shi = kv1;
+    kv_upper_bound_narrow(ix.kv, slo, shi, (int)lo);
+    // (the chromosome's two fields ride with the last level of the search)
+    const uint64_t chrom_ref = (uint64_t)(uintptr_t)ix.chrom_seq[c.chrom];
+    const int chrom_ref_len = ix.chrom_len[c.chrom];
+    const int ub = kv_upper_bound_tail(ix.kv, slo, shi, (int)lo);
+    PLO_LEVEL_END(chrom_ref, chrom_ref_len, ub);
+    const int w0 = ub - 1 > kv0 ? ub - 1 : kv0;
+    const int w1 = kv_lower_bound_near(ix.kv, w0, kv1, (int)hi);
+    const bool do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
+    const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);  // (the lane kernel's LOAD merges match runs for these stages)
+    const int region = lane_region_dwords((int)(merges ? s.n_m : s.n_in), w0, w1);
+    // ---- stores ----
     wk.item_seg[i] = seg;
     wk.item_cseg[i] = cseg;
-    wk.item_nin[i] = (uint32_t)item_weight((int)n_in, w0, w1, kv1);  // tiling weight
-    const bool do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
-    const uint32_t n_m = wk.seg_nm ? wk.seg_nm[seg] : segment_n_merged(bt, seg);
-    const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);  // (the lane kernel's LOAD merges match runs for these stages)
-    const int region = lane_region_dwords((int)(merges ? n_m : n_in), w0, w1);
+    wk.item_nin[i] = (uint32_t)item_weight((int)s.n_in, w0, w1, kv1);  // tiling weight
     wk.item_cls[i] = (do_shift ? 1u : 0u) | ((wk.lane_max_w < 0 || region > wk.lane_max_w) ? 2u : 0u);
     if (wk.item_region) wk.item_region[i] = (uint32_t)region;
-    wk.d.n_m[i] = n_m;
-    wk.d.in_off[i] = in_off;
-    wk.d.n_in[i] = n_in;
+    wk.d.n_m[i] = s.n_m;
+    wk.d.in_off[i] = s.in_off;
+    wk.d.n_in[i] = s.n_in;
     wk.d.pos1[i] = (int)pos1;
     wk.d.w0[i] = (uint32_t)w0;
     wk.d.w1[i] = (uint32_t)w1;
     wk.d.kv0[i] = (uint32_t)kv0;
     wk.d.kv1[i] = (uint32_t)kv1;
     wk.d.flags[i] = (rev ? (uint32_t)ITF_REV : 0u) | (flip ? (uint32_t)ITF_FLIP : 0u) | (contig_fwd ? (uint32_t)ITF_CONTIG_FWD : 0u);
-    wk.d.contig[i] = contig;
-    wk.d.seq_len[i] = bt.read_seq_len[read];
-    wk.d.seq_off[i] = bt.read_seq_off[read];
-    wk.d.shift_ref[i] = (uint64_t)(uintptr_t)(ix.contig_revseq ? ix.contig_revseq[contig] : nullptr);
-    wk.d.shift_ref_len[i] = ix.contig_len[contig];
-    uint32_t chrom = ix.cs_chrom[gseg];
-    wk.d.chrom_ref[i] = (uint64_t)(uintptr_t)ix.chrom_seq[chrom];
-    wk.d.chrom_ref_len[i] = ix.chrom_len[chrom];
+    wk.d.contig[i] = s.contig;
+    wk.d.seq_len[i] = s.seq_len;
+    wk.d.seq_off[i] = s.seq_off;
+    wk.d.shift_ref[i] = s.revseq;
+    wk.d.shift_ref_len[i] = s.contig_len;
+    wk.d.chrom_ref[i] = chrom_ref;
+    wk.d.chrom_ref_len[i] = chrom_ref_len;
     // The length check of src/read_alignment_scanner.rs:204-229 compares seq_len with the read bases the LIFTED CIGAR consumes.
     // Neither left_shift_indels nor liftover_read_alignment changes that number: the shift re-emits the same match / insertion
     // bases; the liftover turns every read-consuming piece into M, I or S of the same length (:102-123), copies I / S / H ops
     // (:157-160), and its edge clean-up turns insertions into clips of the same length.  So the check is made on the input CIGAR.
-    wk.d.read_len[i] = wk.seg_readlen ? wk.seg_readlen[seg] : segment_read_len_sat(bt, seg);
+    wk.d.read_len[i] = s.read_len;
     // outputs that do not depend on the CIGAR pipeline
     wk.flip[i] = (uint8_t)flip;
-    wk.mapq[i] = ix.cs_mapq[gseg];
-    wk.chrom[i] = ix.cs_chrom[gseg];
+    wk.mapq[i] = c.mapq;
+    wk.chrom[i] = c.chrom;
+}
+// (an item of an explicit list: the three levels one after the other)
+PLO_DEV void build_item_desc(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t i, uint32_t seg,
+                             uint32_t cseg, long long ref_len) {
+    SegInfo s;
+    seg_info_level0(s, bt, wk, stages, seg);
+    seg_info_level1(s, ix, bt, wk, stages, seg);
+    build_item_desc(ix, wk, stages, i, seg, cseg, ref_len, s, cseg_info(ix, s.g0 + cseg));
+}
+
+// The items of one read segment, in contig-segment order, resolved at out_off (`s`: both levels loaded; the batch has been validated
+// and the segment has items).  Returns their number.
+PLO_DEV uint32_t emit_segment_items(const DevIndex &ix, const DevWork &wk, uint32_t stages, uint32_t seg, uint32_t out_off, long long ref_len,
+                                    const SegInfo &s) {
+    const long long r_start = s.pos, r_end = r_start + ref_len;
+    uint32_t n = 0;
+    for (uint32_t g = s.g0; g < s.g1; ++g) {
+        const CsegInfo c = cseg_info(ix, g);
+        // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end
+        if ((r_end >= (long long)c.start) & (r_start < (long long)c.end)) {
+            build_item_desc(ix, wk, stages, out_off + n, seg, g - s.g0, ref_len, s, c);
+            ++n;
+        }
+    }
+    return n;
 }
 
 // Counts (and, when wk != nullptr, resolves at out_off) the items of one read segment, in contig-segment order.
@@ -251,16 +367,18 @@ PLO_DEV uint32_t enumerate_segment(const DevIndex &ix, const DevBatch &bt, uint3
         ref_len = segment_ref_len(bt, seg);
         if (ref_len_cache) ref_len_cache[seg] = (int)ref_len;
     }
+    if (wk) {
+        SegInfo s;
+        seg_info_level0(s, bt, *wk, stages, seg);
+        seg_info_level1(s, ix, bt, *wk, stages, seg);
+        return emit_segment_items(ix, *wk, stages, seg, out_off, ref_len, s);
+    }
     long long r_start = (long long)bt.seg_pos[seg];
     long long r_end = r_start + ref_len;
     uint32_t n = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
+    for (uint32_t g = g0; g < g1; ++g)
         // segment_range.intersect_range(&read_range): other.end >= self.start && other.start < self.end
-        if (r_end >= (long long)ix.cs_start[g] && r_start < (long long)ix.cs_end[g]) {
-            if (wk) build_item_desc(ix, bt, *wk, stages, out_off + n, seg, g - g0, ref_len);
-            ++n;
-        }
-    }
+        if (r_end >= (long long)ix.cs_start[g] && r_start < (long long)ix.cs_end[g]) ++n;
     return n;
 }
 

@@ -34,12 +34,7 @@
 
 namespace plo {
 
-// 32 readable bytes in global memory: where the lanes without a usable probe window point their (unconditional) loads
-#ifdef PLO_EMULATOR
-static const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#else
-static __device__ const uint32_t plo_safe_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
+// (plo_safe_words, enumerate.hpp: where the lanes without a usable probe window point their unconditional loads)
 
 
 // -------------------------------------------------------------------------------------------------------------------
