@@ -274,26 +274,32 @@ __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_c
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, uint32_t nb, uint32_t *totals) {
     __shared__ unsigned wt[4];
-    for (uint32_t c = 0; c < 3; ++c) {
-        uint32_t *p = partial + c * nb;
-        unsigned carry = 0;
-        for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
-            const uint32_t i = b0 + threadIdx.x;
-            const unsigned v = i < nb ? p[i] : 0;
-            unsigned tot;
-            const unsigned inc = block_scan_incl(v, wt, tot);
-            if (i < nb) p[i] = carry + inc - v;
-            carry += tot;
-        }
-        if (threadIdx.x == 0) totals[c] = carry;
-    }
-    // heaviest item and the sum of the weights
+    // one pass over the blocks, SCAN_THREADS at a time: the six rows of a step are loaded together (one round trip per step, not one per
+    // row and step), the three class rows scanned, the other three reduced
+    unsigned carry[3] = {0, 0, 0};
     unsigned mx = 0;
     unsigned long long sum = 0;
-    for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS) {
-        mx = partial[3 * nb + i] > mx ? partial[3 * nb + i] : mx;
-        sum += (unsigned long long)partial[4 * nb + i] + ((unsigned long long)partial[5 * nb + i] << 16);
+    for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        const uint32_t i = b0 + threadIdx.x;
+        const bool ok = i < nb;
+        const uint32_t j = ok ? i : 0u;  // (nb > 0: the kernel is launched for batches with items)
+        unsigned v[6];
+#pragma unroll
+        for (uint32_t c = 0; c < 6; ++c) v[c] = partial[c * nb + j];
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+            const unsigned x = ok ? v[c] : 0u;
+            unsigned tot;
+            const unsigned inc = block_scan_incl(x, wt, tot);
+            if (ok) partial[c * nb + i] = carry[c] + inc - x;
+            carry[c] += tot;
+        }
+        if (ok) {
+            mx = v[3] > mx ? v[3] : mx;
+            sum += (unsigned long long)v[4] + ((unsigned long long)v[5] << 16);
+        }
     }
+    // heaviest item and the sum of the weights
     __shared__ unsigned long long ssum;
     __shared__ unsigned smax;
     if (threadIdx.x == 0) {
@@ -301,10 +307,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, ui
         smax = 0;
     }
     __syncthreads();
-    atomicMax(&smax, mx);
-    atomicAdd(&ssum, sum);
+    mx = (unsigned)wv::reduce_max((int)(mx & 0x7fffffffu));  // (weights are below 2^31: checked sums of CIGAR ops and block-map entries)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMax(&smax, mx);
+        atomicAdd(&ssum, sum);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
+        totals[0] = carry[0];
+        totals[1] = carry[1];
+        totals[2] = carry[2];
         totals[3] = smax;
         totals[4] = (uint32_t)(ssum & 0xffffffffull);
         totals[5] = (uint32_t)(ssum >> 32);
@@ -826,7 +840,11 @@ __global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint3
         }
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) atomicAdd(&acc[k], a[k]);
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) a[k] += (unsigned long long)__shfl_xor((long long)a[k], d, 64);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&acc[k], a[k]);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&counters[CNT_ALGO_BYTES], acc[0]);
