@@ -241,22 +241,35 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *wave_t
 constexpr uint32_t CLS_THREADS = 256, CLS_PER = 8, CLS_BLOCK = CLS_THREADS * CLS_PER;
 // partial: [6][nb] per block: items of class 0 / 1 / 2, heaviest item, sum of the weights (exact, 64 bits as two words: the batch-size
 // guard and the output sizing rest on it); totals (k_cls_scan): [0..2] class counts, [3] heaviest item, [4..5] 64-bit sum of the weights
+// the CLS_PER = 8 consecutive values of a thread: two 16-byte loads (the arrays come from hipMalloc and base is a multiple of 8), element by element
+// with `fill` behind the end only in the array's last block
+__device__ __forceinline__ void load8(const uint32_t *a, uint32_t base, uint32_t n, uint32_t fill, uint32_t (&v)[8]) {
+    if (base + 8u <= n) {
+        const uint4 x = *(const uint4 *)(a + base), y = *(const uint4 *)(a + base + 4);
+        v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w, v[4] = y.x, v[5] = y.y, v[6] = y.z, v[7] = y.w;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = base + k < n ? a[base + k] : fill;
+    }
+}
 __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial) {
     __shared__ uint32_t acc[6];
     if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
     uint32_t c0 = 0, c1 = 0, c2 = 0, mw = 0, sl = 0, sh = 0;  // sl / sh: sums of the weights' low / high 16 bits (a block's fit 32 bits each)
+    uint32_t cv[CLS_PER], wv_[CLS_PER];
+    load8(item_cls, base, n, 3u, cv);
+    load8(item_w, base, n, 0u, wv_);
+#pragma unroll
     for (uint32_t k = 0; k < CLS_PER; ++k) {
-        if (base + k < n) {
-            const uint32_t c = item_cls[base + k], w = item_w[base + k];
-            c0 += c == 0;
-            c1 += c == 1;
-            c2 += c == 2;
-            mw = w > mw ? w : mw;
-            sl += w & 0xffffu;
-            sh += w >> 16;
-        }
+        const uint32_t c = cv[k], w = wv_[k];  // (behind the end: class 3 counted nowhere, weight 0)
+        c0 += c == 0;
+        c1 += c == 1;
+        c2 += c == 2;
+        mw = w > mw ? w : mw;
+        sl += w & 0xffffu;
+        sh += w >> 16;
     }
     // (counts of a wave fit 16 bits: 64 threads x 8 items)
     const int p01 = wv::reduce_add((int)(c0 | (c1 << 16))), p2 = wv::reduce_add((int)c2), pm = wv::reduce_max((int)(mw & 0x7fffffffu));
@@ -328,10 +341,15 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
                                                           uint32_t n, uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w) {
     __shared__ unsigned wt[4];
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
-    uint32_t cls[CLS_PER];
+    // every load in front of the scans and of the stores (a load behind a store waits for the store: the memory counter is in order)
+    uint32_t cls[CLS_PER], wgt[CLS_PER];
+    load8(item_cls, base, n, 3u, cls);
+    load8(item_nin, base, n, 0u, wgt);
+    const uint32_t p0 = partial[0 * nb + blockIdx.x], p1 = partial[1 * nb + blockIdx.x], p2 = partial[2 * nb + blockIdx.x];
+    const uint32_t n0 = totals[0], n1 = totals[1], n2 = totals[2];
     uint32_t c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
     for (uint32_t k = 0; k < CLS_PER; ++k) {
-        cls[k] = base + k < n ? item_cls[base + k] : 3u;
         c0 += cls[k] == 0;
         c1 += cls[k] == 1;
         c2 += cls[k] == 2;
@@ -339,10 +357,10 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
     unsigned tot;
     const unsigned i01 = block_scan_incl(c0 | (c1 << 16), wt, tot);  // (a block holds 2 048 items: each count fits 16 bits)
     const unsigned i2 = block_scan_incl(c2, wt, tot);
-    uint32_t r0 = partial[0 * nb + blockIdx.x] + (i01 & 0xffffu) - c0;
-    uint32_t r1 = partial[1 * nb + blockIdx.x] + (i01 >> 16) - c1;
-    uint32_t r2 = partial[2 * nb + blockIdx.x] + i2 - c2;
-    const uint32_t n0 = totals[0], n1 = totals[1], n2 = totals[2];
+    uint32_t r0 = p0 + (i01 & 0xffffu) - c0;
+    uint32_t r1 = p1 + (i01 >> 16) - c1;
+    uint32_t r2 = p2 + i2 - c2;
+#pragma unroll
     for (uint32_t k = 0; k < CLS_PER; ++k) {
         const uint32_t i = base + k;
         if (i >= n) break;
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
         perm[j] = i;
         // only the large items are tiled; items no geometry can hold (heavier than huge_w) take no room in the weight stream: they
         // ride along in their neighbours' tiles, 64 per pass, and are handed to the large-item kernel there
-        const uint32_t w = item_nin[i];
+        const uint32_t w = wgt[k];
         nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
         r0 += c == 0;
         r1 += c == 1;
@@ -478,6 +496,70 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
     }
 }
 
+// The same sort for the default geometry -- windows of at most 128 positions, fixed groups: one WAVE per window (two items per lane, four bins
+// per lane), four windows per workgroup, no workgroup barrier and 4 KB of LDS (k_chunk_sort: a workgroup and 25 KB per window).
+__global__ __launch_bounds__(256) void k_chunk_sort_w(uint32_t *perm, const uint32_t *n_m, const uint32_t *w0, const uint32_t *w1, uint32_t n0, uint32_t n1,
+                                                      uint32_t chunk) {
+    __shared__ uint32_t hist_all[4][256];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *const hist = hist_all[wave];
+    const uint32_t c0 = (n0 + chunk - 1) / chunk, c1 = (n1 + chunk - 1) / chunk;
+    const uint32_t win = blockIdx.x * 4u + wave;
+    if (win >= c0 + c1) return;
+    uint32_t lo, hi;
+    if (win < c0) {  // windows do not straddle the two lane classes
+        lo = win * chunk;
+        hi = lo + chunk < n0 ? lo + chunk : n0;
+    } else {
+        lo = n0 + (win - c0) * chunk;
+        hi = lo + chunk < n0 + n1 ? lo + chunk : n0 + n1;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) hist[lane + 64u * q] = 0;
+    uint32_t g[2], k[2];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t p = lo + j * 64u + lane;
+        g[j] = p < hi ? perm[p] : 0u;
+    }
+    uint32_t a[2], b0[2], b1[2];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {  // (six gathers in flight)
+        a[j] = n_m[g[j]];
+        b0[j] = w0[g[j]];
+        b1[j] = w1[g[j]];
+    }
+    wv::sync();
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t p = lo + j * 64u + lane;
+        const uint32_t w = (win < c0 ? a[j] : 2u * a[j]) + (b1[j] - b0[j]);
+        k[j] = w < 255u ? w : 255u;
+        if (p < hi) atomicAdd(&hist[k[j]], 1u);
+    }
+    wv::sync();
+    {   // exclusive prefix of the 256 bins: lane t owns bins 4 t .. 4 t + 3
+        uint32_t h[4], tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            h[q] = hist[4u * lane + q];
+            tot += h[q];
+        }
+        uint32_t base = (uint32_t)wv::scan_add((int)tot) - tot;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            hist[4u * lane + q] = base;
+            base += h[q];
+        }
+    }
+    wv::sync();
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t p = lo + j * 64u + lane;
+        if (p < hi) perm[lo + atomicAdd(&hist[k[j]], 1u)] = g[j];
+    }
+}
+
 // thread per tile: first class-order position (>= n_small) whose exclusive op prefix reaches the tile's window
 __global__ void k_tile_bounds(const uint32_t *op_prefix, uint32_t n_items, uint32_t n_tiles, int window, uint32_t n_small, uint32_t *tile_lo) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -547,9 +629,12 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *in, uint32_t n,
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const uint32_t *in, uint32_t n, uint32_t *partial) {
     __shared__ unsigned wt[4];
     uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    static_assert(SCAN_PER_THREAD == 8, "load8");
+    uint32_t v[SCAN_PER_THREAD];
+    load8(in, base, n, 0u, v);
     unsigned s = 0;
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (base + k < n) s += in[base + k];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) s += v[k];
     unsigned tot;
     block_scan_incl(s, wt, tot);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -573,18 +658,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in,
                                                              uint32_t *out) {
     __shared__ unsigned wt[4];
     uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    unsigned v[SCAN_PER_THREAD];
+    uint32_t v[SCAN_PER_THREAD];
+    load8(in, base, n, 0u, v);
+    const unsigned before = partial[blockIdx.x];
     unsigned s = 0;
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
-        s += v[k];
-    }
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) s += v[k];
     unsigned tot;
     unsigned inc = block_scan_incl(s, wt, tot);
-    unsigned run = partial[blockIdx.x] + inc - s;
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
+    unsigned run = before + inc - s;
+    if (base + SCAN_PER_THREAD <= n) {  // (two 16-byte stores; out comes from hipMalloc and base is a multiple of 8)
+        uint4 x, y;
+        x.x = run, x.y = x.x + v[0], x.z = x.y + v[1], x.w = x.z + v[2];
+        y.x = x.w + v[3], y.y = y.x + v[4], y.z = y.y + v[5], y.w = y.z + v[6];
+        *(uint4 *)(out + base) = x;
+        *(uint4 *)(out + base + 4) = y;
+    } else {
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+            if (base + k < n) out[base + k] = run;
+            run += v[k];
+        }
     }
 }
 
@@ -1432,6 +1525,10 @@ plo_status plo_ctx_download(plo_ctx *c, void *host_dst, const void *dev_src, siz
 static plo_status scan_u32(plo_ctx *c, const uint32_t *in, uint32_t n, uint32_t *out /* n+1 */) {
     uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb == 0) nb = 1;
+    if ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) {  // (the kernels move eight values per thread as two 16-byte accesses)
+        c->err = "scan_u32: unaligned buffer";
+        return PLO_ERR_INVALID_ARG;
+    }
     HIP_TRY(c, c->scan_partial.ensure((size_t)nb * 4));
     uint32_t *partial = c->scan_partial.as<uint32_t>();
     hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(SCAN_THREADS), 0, c->stream, in, n, partial);
@@ -1780,10 +1877,14 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                     if (getenv("PLO_DEBUG_GEOMETRY"))
                         fprintf(stderr, "[plo] lane groups cut by LDS budget: windows of %u, slices of %d dwords, at most %zu groups\n", ch, c->lane_capw, max_groups);
                 }
-                hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
-                                   (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch,
-                                   (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
-                                   budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev);
+                if (!budget && ch <= 128u)
+                    hipLaunchKernelGGL(k_chunk_sort_w, dim3((chunks + 3u) / 4u), dim3(256), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
+                                       (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch);
+                else
+                    hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
+                                       (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch,
+                                       (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
+                                       budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev);
             }
             wk.lane_groups = budget ? c->lane_groups.as<uint32_t>() : nullptr;
             wk.lane_n_groups = c->misc.as<uint32_t>() + 32;
