@@ -518,6 +518,16 @@ extern "C" void emu_sa_free(uint32_t *off, uint8_t *text) {
     free(text);
 }
 
+// the block-map searches of the descriptor code (enumerate.hpp) on one sorted key array: kv_upper_bound, kv_lower_bound,
+// kv_lower_bound_near -- for the unit test against numpy.searchsorted
+extern "C" void emu_kv_search(const int *keys, int n, int lo, int hi, int x, int near_from, int *out /*[3]*/) {
+    std::vector<plo::KV> kv((size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) kv[(size_t)i] = plo::KV{keys[i], 0};
+    out[0] = plo::kv_upper_bound(kv.data(), lo, hi, x);
+    out[1] = plo::kv_lower_bound(kv.data(), lo, hi, x);
+    out[2] = plo::kv_lower_bound_near(kv.data(), near_from, hi, x);
+}
+
 // the device's DEFLATE decoder (inflate.hpp) executed on the host: serially, and by the 64 lanes of an emulated wave
 extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *written) {
     plo::InfWork ws;

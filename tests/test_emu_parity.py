@@ -242,3 +242,34 @@ def test_lane_path_heavy_items_longer_than_their_region(oracle, monkeypatch):
     assert rc == 0 and cnt[7] > 0  # items handed on
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1), res)
 
+
+
+def test_block_map_searches_against_searchsorted():
+    """kv_upper_bound (eight-way, unconditional last level), kv_lower_bound and kv_lower_bound_near (enumerate.hpp) on random sorted key
+    arrays: empty ranges, ranges inside a larger array, probes below / above / equal to keys"""
+    import ctypes as C
+
+    import emu_lib
+    L = emu_lib.lib()
+    L.emu_kv_search.restype = None
+    L.emu_kv_search.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(7)
+    out = (C.c_int * 3)()
+    for n in [0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 200, 1000, 5000]:
+        keys = np.unique(rng.integers(0, max(4, 6 * n), size=n).astype(np.int32)) if n else np.zeros(0, np.int32)
+        n = len(keys)
+        kp = np.ascontiguousarray(keys if n else np.zeros(1, np.int32)).ctypes.data_as(C.POINTER(C.c_int))
+        for _ in range(60):
+            lo = int(rng.integers(0, n + 1))
+            hi = int(rng.integers(lo, n + 1))
+            pool = [int(rng.integers(-3, max(4, 6 * n) + 3))]
+            if hi > lo:
+                k = int(keys[int(rng.integers(lo, hi))])
+                pool += [k, k - 1, k + 1]
+            for x in pool:
+                near = int(rng.integers(lo, hi + 1))
+                L.emu_kv_search(kp, n, lo, hi, x, near, out)
+                sub = keys[lo:hi]
+                assert out[0] == lo + int(np.searchsorted(sub, x, side="right")), (n, lo, hi, x)
+                assert out[1] == lo + int(np.searchsorted(sub, x, side="left")), (n, lo, hi, x)
+                assert out[2] == near + int(np.searchsorted(keys[near:hi], x, side="left")), (n, lo, hi, x, near)
