@@ -7,7 +7,11 @@ One *step* = one pass of the hot path (plo_liftover_batch_dev: item enumeration,
 liftover, length check, simplify) over one batch of synthetic reads that is already resident in HBM when the timed
 region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU), default `--scaling strong` = BASELINE.json configs[3]: ONE
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK) bench.py is one rank of it;
+WITHOUT one, `python bench.py --gpus N` starts the N ranks itself as a child `python -m torch.distributed.run` (launch_plan) and
+relays rank 0's line and the exit code; a WORLD_SIZE that disagrees with --gpus is an error.  `--dist-backend gloo` runs the same
+shard -> lift -> gather -> verify with host-tensor payloads (one-GPU boxes, where RCCL refuses two ranks on a device).
+Default `--scaling strong` = BASELINE.json configs[3]: ONE
 read set (same seed on every rank) is cut into the reference's own windows (<= 20 Mb of a contig,
 src/read_alignment_scanner.rs:508), the windows are dealt to the ranks balanced by their input CIGAR ops
 (portello_amd/shard.py), every rank lifts its windows with no data-path collective, and the compact result records are
@@ -471,6 +475,50 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
 
 
 
+def launch_plan(n_gpus: int, argv, port: int = 0, base_env=None):
+    """The N-rank launch of `python bench.py --gpus N ...` when no launcher started it (WORLD_SIZE unset): the command line and the
+    environment of ONE child process -- `python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1 -- exactly the
+    command the driver uses for N > 1.  The reference starts its own workers the same way (a rayon pool of --threads workers inside
+    scan_and_remap_reads, src/read_alignment_scanner.rs:606-660, one reader per worker, src/worker_thread_data.rs:21-30).  A child
+    process, never os.exec*: this process may already have loaded the HIP runtime."""
+    import socket
+
+    if port <= 0:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ if base_env is None else base_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)  # (torch.distributed.run sets them per rank)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["PLO_BENCH_LAUNCHED"] = "1"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, int(n_gpus)))))
+    return cmd, env
+
+
+def launch_ranks(n_gpus: int, argv) -> int:
+    """runs the plan as a child process; rank 0's JSON line is the child's stdout, relayed as it is; returns the child's exit code"""
+    import subprocess
+
+    cmd, env = launch_plan(n_gpus, argv)
+    log(f"[bench] --gpus {n_gpus} without a launcher: starting {n_gpus} ranks: {' '.join(cmd)}")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in js:
+            log(ln)
+    if js:
+        print(js[-1], flush=True)  # ONE JSON line: rank 0's
+    elif p.returncode == 0:
+        log("[bench] the ranks printed no result line")
+        return 5
+    return p.returncode
+
+
 def finalize(result) -> int:
     """A result whose records differ from the checker's is not a measurement: `parity_sample_ok` false, a failed `end_to_end`
     verification or a gathered record set that differs from the single-GPU one => "parity_failed": true, "value": null (the number
@@ -530,17 +578,27 @@ def main():
                          "arrangement INTEGRATION.md recommends) and report the rate as the supplementary object `overlap` (N = 1 only; "
                          "0/1 = skip: traced runs -- tools/profile_round.sh -- skip it, its launches would enter a rocprofv3 kernel summary "
                          "with their longer, overlapped durations)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default=os.environ.get("PLO_BENCH_DIST_BACKEND", "nccl"),
+                    help="N > 1: nccl = RCCL over xGMI (device tensors, the production path); gloo = the same shard -> lift -> gather -> "
+                         "verify run with the rank payloads passing through host tensors -- for boxes with ONE GPU, where RCCL refuses two "
+                         "ranks on a device (PLO_BENCH_SHARE_GPU=1 lets the ranks share it)")
     args = ap.parse_args()
 
+    # N > 1 without a launcher: start the N ranks ourselves (before anything touches the GPU), relay rank 0's line and the exit code
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    if world != args.gpus:
+        log(f"error: --gpus {args.gpus} but WORLD_SIZE {world}: the launcher's world size and --gpus must agree "
+            f"(unset WORLD_SIZE to let bench.py start the ranks itself)")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     n_dev = torch.cuda.device_count()
     # (several ranks on one GPU only happen in the single-GPU exercise of the distributed path, PLO_BENCH_SHARE_GPU=1)
-    dev_index = local_rank if not os.environ.get("PLO_BENCH_SHARE_GPU") else local_rank % max(1, n_dev)
+    share_gpu = bool(os.environ.get("PLO_BENCH_SHARE_GPU")) or (args.dist_backend == "gloo" and world > n_dev)
+    dev_index = local_rank if not share_gpu else local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -552,7 +610,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+    # where the collectives' tensors live: the GPU for RCCL; host memory for gloo (payloads are copied down on the engine's stream)
+    host_comm = dist is not None and args.dist_backend == "gloo"
+    comm_dev = torch.device("cpu") if host_comm else dev
     strong = args.scaling == "strong"
 
     over = {"seed": synth.config(args.workload).seed + (0 if strong else 1000 * rank)}
@@ -610,7 +674,11 @@ def main():
         if dist is not None and gather:
             engs[k].compact_output_dev(out)  # no slab gaps over xGMI; completes on the engine's stream, not at return
             with gather_lock, torch.cuda.stream(streams[k]):  # the exchange is ordered behind the engine's kernels
-                last_gather[0] = plo_gather.gather_results(out, dev, dist, rank, world)
+                if host_comm:
+                    mine = {k_: v.cpu() for k_, v in plo_gather.tensors_from_out(out, dev).items()}
+                    last_gather[0] = plo_gather.gather_payloads(mine, dist, rank, world)
+                else:
+                    last_gather[0] = plo_gather.gather_results(out, dev, dist, rank, world)
         last_out[k] = out
         return out
 
@@ -661,7 +729,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -717,7 +785,9 @@ def main():
                        "tile_geometry": {"slice_elements": int(tm.tile_cap), "window": int(tm.tile_window)},
                        "parallelism": (f"one read set, 20 Mb windows dealt to {world} ranks by input ops" if strong else f"{world} independent read sets"),
                        "host_workers_per_gpu": n_workers, "kernel_source_hash": src_hash,
-                       "gather": gather_desc},
+                       "gather": gather_desc, "dist_backend": (args.dist_backend if dist is not None else None),
+                       "launched_by": ("bench.py (child torch.distributed.run)" if os.environ.get("PLO_BENCH_LAUNCHED") else
+                                       ("external launcher" if world > 1 else "single process"))},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
@@ -735,7 +805,7 @@ def main():
         total_reads = float(my_reads)
         result = make_result(dt, "none")
     else:
-        nr = torch.tensor([my_reads], dtype=torch.float64, device=dev)
+        nr = torch.tensor([my_reads], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(nr, op=dist.ReduceOp.SUM)
         total_reads = float(nr.item())
         # First the same K steps without the record gather (no collective on the data path): a complete measurement that rank 0 can
@@ -793,13 +863,13 @@ def main():
                 print(json.dumps(failed_line(gather_error[0] or "the synchronous record gather failed")), flush=True)
             os._exit(3)
         if dt_sync is not None:
-            result = make_result(dt_sync, "rccl send/recv to rank 0 after every step")
+            result = make_result(dt_sync, ("gloo send/recv of host copies" if host_comm else "rccl send/recv") + " to rank 0 after every step")
             pending_print[0] = result
         # (b) the gather of batch i overlapped with the compute of batch i+1: two contexts alternate, so that the exchange reads one
         # context's buffers while the other computes.  Both the posting and the wait happen under the owning engine's stream: RCCL
         # starts the sends behind the compaction kernel, and the engine's next kernels start behind the sends that read its buffers.
         dt_async = None
-        if n_workers == 1 and dt_sync is not None:
+        if n_workers == 1 and dt_sync is not None and not host_comm:
             def async_run():
                 s2 = torch.cuda.Stream(device=dev)
                 a_streams = [streams[0], s2]
@@ -921,13 +991,14 @@ def main():
             torch.cuda.synchronize()
             if strong and not args.no_verify:
                 if rank == 0:
-                    seg_maps = [plo_gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)) for r in range(world)]
+                    seg_maps = [plo_gather.local_to_global_segments(w, shard.rank_read_ranges(wins, deal, r)).to(comm_dev) for r in range(world)]
                     got_all = plo_gather.combine(last_gather[0], seg_maps)
                     got_all = {k_: v.clone() for k_, v in got_all.items()}
                     whole_db = devbatch.DeviceBatch.from_workload(w)
                     whole_out = eng.liftover_batch_dev(whole_db.desc())
+                    eng.compact_output_dev(whole_out)
                     eng.sync()
-                    whole = plo_gather.tensors_from_out(whole_out, dev)
+                    whole = {k_: v.to(comm_dev) for k_, v in plo_gather.tensors_from_out(whole_out, dev).items()}
                     same = plo_gather.same_records(got_all, whole)
                     verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
                               "reads": int(w.n_reads)}

@@ -737,7 +737,8 @@ static plo_status records_build(plo_bam_window *w, const plo_batch_out *lift, co
                      (fin->item_seq_off[i] <= fin->rev_seq_bytes && sb <= fin->rev_seq_bytes - fin->item_seq_off[i] &&
                       fin->item_qual_off[i] <= fin->rev_qual_bytes && qb <= fin->rev_qual_bytes - fin->item_qual_off[i]);
                 // a record has flipped bases exactly when the lift says it needs them (a stale array would give silently wrong bases)
-                ok = ok && ((fin->item_seq_off[i] != PLO_NO_FLIP) == (lift->item_need_flipped[i] != 0));
+                // (a read without bases has nothing to flip: the finishing kernel leaves PLO_NO_FLIP there whatever the lift says)
+                ok = ok && (rec.l_seq() == 0 || (fin->item_seq_off[i] != PLO_NO_FLIP) == (lift->item_need_flipped[i] != 0));
                 if (ok && sa) ok = sa->item_sa_off[i] <= sa->item_sa_off[i + 1] && sa->item_sa_off[i + 1] <= sa->sa_bytes;
             }
             if (!ok) {

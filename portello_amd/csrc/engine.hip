@@ -392,7 +392,7 @@ constexpr uint32_t LANE_SORT_MAX_CHUNK = 2048, LANE_SORT_THREADS = 256, LANE_SOR
 // counts twice (its rounds and scans follow the indel clusters, half of n_m, and cost twice a liftover iteration).  Off line, windows of 128,
 // against the tiling weight: shift rounds per group 1.67 -> 1.52 x the mean, liftover iterations 1.59 -> 1.49 (forward class) / 1.56.
 __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm, const uint32_t *n_m, const uint32_t *w0, const uint32_t *w1, uint32_t n0, uint32_t n1,
-                                                                  uint32_t chunk, const uint32_t *region, uint32_t cap, uint32_t *glist, uint32_t *n_groups) {
+                                                                  uint32_t chunk, const uint32_t *region, uint32_t cap, uint32_t *glist, uint32_t *n_groups, uint32_t glist_cap) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
     __shared__ uint16_t reg[LANE_SORT_MAX_CHUNK], nxt[LANE_SORT_MAX_CHUNK];
@@ -490,7 +490,10 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
         g_base = atomicAdd(n_groups, ng);
     }
     __syncthreads();
+    // (the host sizes the list for the most groups the windows can have, a group being cut at 64 items or at the slice's capacity; a
+    // group beyond it would be a sizing bug -- it is not written, and the batch's count then exceeds the capacity, which the host checks)
     for (uint32_t q = threadIdx.x; q < g_cnt; q += LANE_SORT_THREADS) {
+        if (g_base + q >= glist_cap) continue;
         glist[2 * (g_base + q)] = lo + starts[q];
         glist[2 * (g_base + q) + 1] = starts[q + 1] - starts[q];
     }
@@ -1212,6 +1215,7 @@ struct plo_ctx {
     // groups cut by LDS budget inside larger sort windows (k_chunk_sort, lane_groups_cut): on for batches whose groups are of 64
     bool lane_budget = false;  // (measured, MI355X, wgs30x 2 M reads: 1.42 ms with windows of 512 against 1.29 ms with fixed groups in windows of 128 -- DESIGN.md section 6)
     int lane_budget_window = 512;
+    uint32_t lane_groups_cap = 0;  // groups the list of the budget-cut groups has room for (set with the list, attempt 0 of a batch)
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
     // batches with at least that many heavy items; < 0 (default) = by lane_heavy_ratio, see the routing in liftover_core (0: never).
     // Stress workload, heavy items -> k_lift_mid / k_lift_lanes_g: 20 k 2.8 / 7.9 ms, 60 k 8.0 / 9.6 ms, 80 k 10.5 / 9.6 ms,
@@ -1865,14 +1869,17 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             const uint32_t n0 = h_cls[0], n1 = h_cls[1];
             // groups cut by LDS budget (wider sort windows without the extra rounds of over-full groups) when the groups are of 64
             const bool budget = c->lane_sort && wk.item_region && lane_gs == 64u;
+            uint32_t lane_groups_cap_now = 0;
             if (attempt == 0 && c->lane_sort) {
                 const uint32_t ch = (uint32_t)(budget ? c->lane_budget_window : c->lane_sort_window);
                 const uint32_t chunks = (n0 + ch - 1) / ch + (n1 + ch - 1) / ch;
                 uint32_t *n_groups_dev = c->misc.as<uint32_t>() + 32;  // (misc was cleared before the class kernels)
                 if (budget) {
                     // most groups a window can have: every group holds at least cap / (largest region) items
-                    const uint32_t per_group = std::max<uint32_t>(1u, (uint32_t)c->lane_capw / (uint32_t)std::max(1, c->lane_max_w));
+                    // (k_chunk_sort cuts a group at 64 items as well as at the slice's capacity)
+                    const uint32_t per_group = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (uint32_t)c->lane_capw / (uint32_t)std::max(1, c->lane_max_w)));
                     const size_t max_groups = (size_t)chunks * (ch / per_group + 2);
+                    lane_groups_cap_now = (uint32_t)std::min<size_t>(max_groups, 0xffffffffu);
                     HIP_TRY(c, c->lane_groups.ensure(max_groups * 8));
                     if (getenv("PLO_DEBUG_GEOMETRY"))
                         fprintf(stderr, "[plo] lane groups cut by LDS budget: windows of %u, slices of %d dwords, at most %zu groups\n", ch, c->lane_capw, max_groups);
@@ -1884,10 +1891,12 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                     hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
                                        (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch,
                                        (const uint32_t *)c->item_region.as<uint32_t>(), (uint32_t)c->lane_capw,
-                                       budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev);
+                                       budget ? c->lane_groups.as<uint32_t>() : (uint32_t *)nullptr, n_groups_dev, lane_groups_cap_now);
             }
             wk.lane_groups = budget ? c->lane_groups.as<uint32_t>() : nullptr;
             wk.lane_n_groups = c->misc.as<uint32_t>() + 32;
+            if (attempt == 0) c->lane_groups_cap = lane_groups_cap_now;
+            wk.lane_groups_cap = c->lane_groups_cap;
             const size_t lds = lane_lds;
             const uint32_t gs = lane_gs, nblk = lane_nblk;
             wk.slab_pre = 1u;  // first slab by wave id
@@ -2120,7 +2129,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         HIP_TRY(c, c->o_cigar.ensure((size_t)(hc[CNT_CIGAR] + wk.slab_offset + 4096 + (size_t)std::min<uint32_t>(n_tiles + 1024, (uint32_t)c->n_cus * 16) * SLAB_OPS) * 4));
     }
     if (hc[CNT_ERROR]) {
-        c->err = "an item exceeded the large-item scratch capacity (raise PLO_BIG_CAP)";
+        c->err = "an item exceeded the large-item scratch capacity (raise PLO_BIG_CAP), or the lane kernel's group list its capacity";
         return PLO_ERR_INTERNAL;
     }
     c->timing.n_items = n_items;

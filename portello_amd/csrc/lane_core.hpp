@@ -503,7 +503,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     const int W = n_ld + gap + LANE_SLACK;  // dwords
 
     // ---- block-map entries of the group -> LDS (loads now; the stores follow the LOAD pass, whose round trip covers this one) ----
-    int kvs_base = 0;
+    int kvs_base = 0, kvs_cnt = 0;
     bool kv_lds = false, kvs_store = false;
     KV kvs_e0 = {0, 0}, kvs_e1 = {0, 0};
     if (kvs != nullptr && (stages & PLO_STAGE_LIFTOVER)) {
@@ -513,6 +513,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         const int top = wv::reduce_max(has ? need_hi : 0);
         const int cnt = wv::imax(0, wv::imin(top - kvs_base, LANE_KVS));
         kv_lds = has & (need_hi <= kvs_base + cnt);
+        kvs_cnt = cnt;
         if (lane < cnt) kvs_e0 = ix.kv[kvs_base + lane];
         if (lane + 64 < cnt) kvs_e1 = ix.kv[kvs_base + lane + 64];
         kvs_store = true;
@@ -874,7 +875,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             // entry `idx` of the block map for the lanes `on`: from the staged copy, or (items outside it) from global memory
             auto kv_fetch = [&](bool on, int idx, int &key, int &val) {
                 if (kvs != nullptr) {
-                    const bool l = on & kv_lds & ((unsigned)(idx - kvs_base) < (unsigned)LANE_KVS);
+                    // (only what was staged: the cursor's look-ahead may ask for the entry one past the item's own range)
+                    const bool l = on & kv_lds & ((unsigned)(idx - kvs_base) < (unsigned)kvs_cnt);
                     const uint32_t *q = kvs + 2 * (l ? idx - kvs_base : 0);
                     const int lk = (int)q[0], lv = (int)q[1];
                     key = l ? lk : key;
@@ -1165,7 +1167,11 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
     // groups: cut by LDS budget (k_chunk_sort's list, wk.lane_groups) or fixed: `gs` items each from the start of either class
     const bool listed = wk.lane_groups != nullptr;
     const uint32_t t0 = (n0 + gs - 1u) / gs, t1 = (n1 + gs - 1u) / gs;
-    const uint32_t n_groups = listed ? wv::bcast_first(*wk.lane_n_groups) : t0 + t1;
+    uint32_t n_groups = listed ? wv::bcast_first(*wk.lane_n_groups) : t0 + t1;
+    if (listed && n_groups > wk.lane_groups_cap) {  // (k_chunk_sort did not write the groups beyond the list's capacity)
+        if (first == 0u && lane == 0u) wv::atomic_add_global(&wk.counters[CNT_ERROR], 1ull);
+        n_groups = wk.lane_groups_cap;
+    }
     auto group = [&](uint32_t t, uint32_t &lo, uint32_t &hi) {
         if (listed) {
             lo = wk.lane_groups[2 * t];

@@ -119,6 +119,7 @@ struct DevWork {
     uint32_t *item_region;
     const uint32_t *lane_groups;    // [2 * n]: lo, count
     const uint32_t *lane_n_groups;  // [1]
+    uint32_t lane_groups_cap;       // groups `lane_groups` has room for (more would be a sizing bug: reported through CNT_ERROR)
 };
 
 }  // namespace plo

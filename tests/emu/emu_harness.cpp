@@ -240,6 +240,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             }
             wk.lane_groups = glist.data();
             wk.lane_n_groups = &n_glist;
+            wk.lane_groups_cap = n_glist;
         }
         if (n_small) {  // k_lift_lanes: persistent waves over the groups of the two lane classes
             std::vector<uint32_t> llds((size_t)lane_capw + LANE_KVS_DWORDS + 16, 0xdeadbeefu);

@@ -55,6 +55,42 @@ def test_timing_getter_respects_struct_size(lib_path):
     assert L.plo_ctx_timing(None, C.byref(t)) == abi.PLO_ERR_INVALID_ARG
 
 
+@pytest.mark.gpu
+def test_timing_struct_size_contract_on_a_real_context(lib_path):
+    """API version 4 on a live context (the NULL-context test above never reaches the size check): struct_size 0 is refused; a caller
+    with a SMALLER (older) struct gets a truncated copy -- not one byte beyond it is written -- and the size that was filled in"""
+    from portello_amd import synth
+
+    w = synth.generate(synth.config("tiny", n_reads=50, seed=3))
+    index = api.Index(w.index_data(), 0)
+    eng = api.Engine(index)
+    eng.liftover_batch(w.batch_data())
+    L = eng.lib
+
+    class Guarded(C.Structure):  # a plo_timing followed by a canary
+        _fields_ = [("t", abi.PloTiming), ("canary", C.c_uint8 * 64)]
+
+    g = Guarded()
+    C.memset(C.byref(g), 0xA5, C.sizeof(g))
+    g.t.struct_size = 0
+    assert L.plo_ctx_timing(eng.handle, C.byref(g.t)) == abi.PLO_ERR_INVALID_ARG
+    assert bytes(g.canary) == b"\xa5" * 64
+    # an older caller: the struct ends after n_in_ops (40 bytes)
+    small = abi.PloTiming.n_in_ops.offset + 8
+    C.memset(C.byref(g), 0xA5, C.sizeof(g))
+    g.t.struct_size = small
+    assert L.plo_ctx_timing(eng.handle, C.byref(g.t)) == abi.PLO_OK
+    raw = bytes((C.c_uint8 * C.sizeof(g)).from_buffer(g))
+    assert g.t.struct_size == small and g.t.n_in_ops > 0
+    assert raw[small:] == b"\xa5" * (C.sizeof(g) - small)  # nothing past the caller's struct was touched
+    # the full struct
+    g.t.struct_size = C.sizeof(abi.PloTiming)
+    assert L.plo_ctx_timing(eng.handle, C.byref(g.t)) == abi.PLO_OK
+    assert g.t.struct_size == C.sizeof(abi.PloTiming) and g.t.n_items > 0 and bytes(g.canary) == b"\xa5" * 64
+    eng.close()
+    index.close()
+
+
 def test_ctypes_struct_layout_matches_header():
     # sizes implied by the header on LP64
     assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8

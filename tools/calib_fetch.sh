@@ -7,10 +7,15 @@ out=${1:-gpurun_out/fetch_calibration.json}
 [ -x tools/calib_fetch ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/calib_fetch tools/calib_fetch.hip || exit 1
 tools/calib_fetch > /tmp/calib_plain.jsonl || exit 1
 rx="k_stream|k_scatter16|k_scatter_2h|k_probe20"
+rm -rf /tmp/calib_ok && mkdir -p /tmp/calib_ok  # the directories of THIS run's passes that succeeded (stale CSVs of earlier runs are not read)
 for grp in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   d=/tmp/calib_$(echo $grp | tr ' ' '_')
   rm -rf $d
-  timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "$rx" --output-format csv -d $d -- tools/calib_fetch > /dev/null 2> $d.err || echo "pass '$grp' failed (see $d.err)" >&2
+  if timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "$rx" --output-format csv -d $d -- tools/calib_fetch > /dev/null 2> $d.err; then
+    ln -s $d /tmp/calib_ok/$(basename $d)
+  else
+    echo "pass '$grp' failed (see $d.err): its counters are left out" >&2
+  fi
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, collections, sys
@@ -21,7 +26,8 @@ best = {}
 for r in plain:
     best[r["kernel"]] = min(best.get(r["kernel"], 1e9), r["ms"])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("/tmp/calib_*/**/*counter_collection.csv", recursive=True):
+import os
+for f in [f_ for d in sorted(glob.glob("/tmp/calib_ok/*")) for f_ in glob.glob(os.path.realpath(d) + "/**/*counter_collection.csv", recursive=True)]:
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {"_what": "tools/calib_fetch.hip under rocprofv3 --pmc (tools/calib_fetch.sh): counters per dispatch (mean of 3) and per touched 128-byte line",

@@ -56,7 +56,11 @@ h["_about"] = ("HBM traffic per launch of the dominant kernel from rocprofv3 PMC
                "when both halves of the line are touched => the L2 fetches whole lines and the counter reports half the bytes, as for streaming reads).  bench.py copies the "
                "number for its workload into roofline.traffic when workload, read count, GPU count and kernel-source hash (portello_amd/build.py source_hash()) match.  "
                "Every entry is written by tools/save_profiles.py from the passes' output; none is typed by hand.")
-h["_fetch_factor"] = {"value": fetch_factor, "source": (f"profiles/{rnd}_{ver}_fetch_calibration.json" if calib else "MI355X_MICROARCH.md (streaming reads); not calibrated in this run")}
+# (the calibration file is the source only when its FETCH_SIZE pass succeeded, i.e. it carries a conclusion; else the factor is the guide's, and says so)
+calibrated = bool(calib) and "_conclusion" in calib
+h["_fetch_factor"] = {"value": fetch_factor, "calibrated": calibrated,
+                      "source": (f"profiles/{rnd}_{ver}_fetch_calibration.json" if calibrated else
+                                 "MI355X_MICROARCH.md (streaming reads); NOT calibrated in this run" + (": the calibration's FETCH_SIZE pass failed" if calib else ""))}
 h["wgs30x"] = {b["roofline"]["kernel"]: int((fetch_factor * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr, "_fetch_factor": fetch_factor,
                "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
                "_reads": b["config"]["reads_this_rank"], "_source_hash": b["config"]["kernel_source_hash"], "_n_gpus": b["n_gpus"]}
