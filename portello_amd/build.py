@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libportello_liftover.so")
 SOURCES = ["engine.hip", "bam_host.cpp", "phase1.cpp"]
 LIBS = ["-lz", "-ldl"]
-HEADERS = ["plo_wave.hpp", "lift_core.hpp", "lane_core.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp", "bam_internal.hpp"]
+HEADERS = ["plo_wave.hpp", "lift_core.hpp", "lane_core.hpp", "lane_stream.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp", "bam_internal.hpp"]
 
 
 def hipcc() -> str:

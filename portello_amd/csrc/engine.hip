@@ -43,6 +43,7 @@
 #include "inflate.hpp"
 #include "lift_core.hpp"
 #include "lane_core.hpp"
+#include "lane_stream.hpp"
 
 using namespace plo;
 
@@ -822,6 +823,31 @@ __global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_
     lift_lanes_g_kernel<true>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
 }
 
+// HEAVY items, streamed (lane_stream.hpp): the same stage code, the stages chained through four LDS rings per lane instead of running one
+// after the other over regions in global memory; a lane takes the wave's next item when it has finished one.  Taken by batches that
+// run all stages; two waves per SIMD with rings of 16 ops, three (`_w3`) with 16 / 8 / 8 / 16.
+template <bool SP, int NI, int N1, int N2, int N3>
+PLO_DEV void lift_stream_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t lo, uint32_t mid, uint32_t hi) {
+    __shared__ uint32_t rings[LANE_G_WAVES][stream_lds_dwords(NI, N1, N2, N3)];
+    const uint32_t k = threadIdx.x >> 6;
+    // XCD-aware placement as in lift_lanes_kernel: neighbouring shares of the class order -- reads over the same stretch of a contig -- share an L2
+    const uint32_t nb = gridDim.x, per = nb >> 3, b = blockIdx.x;
+    const uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
+    const uint32_t wave = tb * LANE_G_WAVES + k, n_waves = nb * LANE_G_WAVES;
+    WaveCtx ctx;
+    lane_stream_persistent<SP, NI, N1, N2, N3>(ix, bt, wk, wave, n_waves, lo, mid, hi, rings[k], ctx);
+    wave_ctx_flush(wk, ctx, wave);
+}
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_stream(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
+    lift_stream_kernel<false, 16, 16, 16, 16>(ix, bt, wk, lo, mid, hi);
+}
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lift_stream_w3(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
+    lift_stream_kernel<false, 16, 8, 8, 16>(ix, bt, wk, lo, mid, hi);
+}
+__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_stream_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
+    lift_stream_kernel<true, 16, 16, 16, 16>(ix, bt, wk, lo, mid, hi);
+}
+
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
 // items per wave with a larger LDS slice (retry_cap)
 constexpr uint32_t RETRY_PER = 1;
@@ -1215,6 +1241,7 @@ struct plo_ctx {
     // groups cut by LDS budget inside larger sort windows (k_chunk_sort, lane_groups_cut): on for batches whose groups are of 64
     bool lane_budget = false;  // (measured, MI355X, wgs30x 2 M reads: 1.42 ms with windows of 512 against 1.29 ms with fixed groups in windows of 128 -- DESIGN.md section 6)
     int lane_budget_window = 512;
+    bool lane_stream = true;       // heavy items of all-stage batches through the streaming kernel (lane_stream.hpp)
     uint32_t lane_groups_cap = 0;  // groups the list of the budget-cut groups has room for (set with the list, attempt 0 of a batch)
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
     // batches with at least that many heavy items; < 0 (default) = by lane_heavy_ratio, see the routing in liftover_core (0: never).
@@ -1919,28 +1946,47 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
             const uint32_t groups = (n2 + per - 1) / per + (n3 + per - 1) / per;
             uint32_t nblk = std::min<uint32_t>((groups + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ));
-            // Regions start on 128-byte lines and hold the heaviest item of the batch (64: room for the liftover's gap, lane_region_gap)
-            // -- unless that one is an outlier: the regions of all resident lanes together are kept within 8 GB, an item too long for
-            // its region then is handed to the retry list (wave-cooperative code, whatever its size) like any other that outgrows it.
-            int stride = (int)((max_nin + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
-            {
-                const unsigned long long fit = (8ull << 30) / (4ull * per * LANE_G_WAVES * std::max(1u, nblk));
-                const int cap_stride = (int)std::max<unsigned long long>(1024ull, std::min<unsigned long long>(fit, 0x7fffffe0ull) & ~31ull);
-                stride = std::min(stride, cap_stride);
-                if (const char *e = getenv("PLO_LANE_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;
+            // all stages: the streaming kernel (lane_stream.hpp; PLO_LANE_STREAM=0: the kernel over global regions below, which also
+            // takes the stage subsets) -- no scratch, every wave an equal contiguous share of either class
+            bool stream = (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL && c->lane_stream;
+            if (const char *e = getenv("PLO_LANE_STREAM")) stream = stream && atoi(e) != 0;
+            if (stream) {
+                const uint32_t n_waves = (n_heavy + per - 1) / per;
+                nblk = std::max<uint32_t>(1u, std::min<uint32_t>((n_waves + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ)));
+                if (nblk >= 8u) nblk &= ~7u;  // (the XCD mapping wants a multiple of 8)
+                if (getenv("PLO_DEBUG_GEOMETRY"))
+                    fprintf(stderr, "[plo] heavy items through the streaming lane kernel: %u items, %u workgroups of %d waves (%d per SIMD), ~%u items per wave\n", n_heavy, nblk,
+                            LANE_G_WAVES, occ, n_heavy / (nblk * LANE_G_WAVES));
+                wk.slab_pre = 0u;
+                if (!n_small) wk.slab_offset = 0ull;
+                PLO_STAT_RANGE(nblk * LANE_G_WAVES);
+                if (sp) hipLaunchKernelGGL(k_lift_stream_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
+                else if (w3) hipLaunchKernelGGL(k_lift_stream_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
+                else hipLaunchKernelGGL(k_lift_stream, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
+            } else {
+                // Regions start on 128-byte lines and hold the heaviest item of the batch (64: room for the liftover's gap, lane_region_gap)
+                // -- unless that one is an outlier: the regions of all resident lanes together are kept within 8 GB, an item too long for
+                // its region then is handed to the retry list (wave-cooperative code, whatever its size) like any other that outgrows it.
+                int stride = (int)((max_nin + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
+                {
+                    const unsigned long long fit = (8ull << 30) / (4ull * per * LANE_G_WAVES * std::max(1u, nblk));
+                    const int cap_stride = (int)std::max<unsigned long long>(1024ull, std::min<unsigned long long>(fit, 0x7fffffe0ull) & ~31ull);
+                    stride = std::min(stride, cap_stride);
+                    if (const char *e = getenv("PLO_LANE_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;
+                }
+                const unsigned long long per_wave = (unsigned long long)per * (unsigned long long)stride * 4ull;
+                nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_G_WAVES)));
+                HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_G_WAVES * nblk)));
+                if (getenv("PLO_DEBUG_GEOMETRY"))
+                    fprintf(stderr, "[plo] heavy items through the lane-per-item code: %u items, %u per wave, %u workgroups, regions of %d dwords, %.1f MB scratch\n", n_heavy, per,
+                            nblk, stride, per_wave * LANE_G_WAVES * nblk / 1e6);
+                wk.slab_pre = 0u;  // (a group's output is a slab of its own; the light items' waves own the first slabs, if any)
+                if (!n_small) wk.slab_offset = 0ull;
+                PLO_STAT_RANGE(nblk * LANE_G_WAVES);
+                if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+                else if (w3) hipLaunchKernelGGL(k_lift_lanes_g_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
+                else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
             }
-            const unsigned long long per_wave = (unsigned long long)per * (unsigned long long)stride * 4ull;
-            nblk = (uint32_t)std::max<unsigned long long>(1ull, std::min<unsigned long long>(nblk, (16ull << 30) / (per_wave * LANE_G_WAVES)));
-            HIP_TRY(c, c->lane_scratch.ensure((size_t)(per_wave * LANE_G_WAVES * nblk)));
-            if (getenv("PLO_DEBUG_GEOMETRY"))
-                fprintf(stderr, "[plo] heavy items through the lane-per-item code: %u items, %u per wave, %u workgroups, regions of %d dwords, %.1f MB scratch\n", n_heavy, per,
-                        nblk, stride, per_wave * LANE_G_WAVES * nblk / 1e6);
-            wk.slab_pre = 0u;  // (a group's output is a slab of its own; the light items' waves own the first slabs, if any)
-            if (!n_small) wk.slab_offset = 0ull;
-            PLO_STAT_RANGE(nblk * LANE_G_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
-            else if (w3) hipLaunchKernelGGL(k_lift_lanes_g_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
-            else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev[2], st));
         } else if (n_items > n_small) {

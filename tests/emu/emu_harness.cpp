@@ -12,6 +12,7 @@
 #include "../../portello_amd/csrc/inflate.hpp"
 #include "../../portello_amd/csrc/lift_core.hpp"
 #include "../../portello_amd/csrc/lane_core.hpp"
+#include "../../portello_amd/csrc/lane_stream.hpp"
 
 using namespace plo;
 
@@ -26,7 +27,9 @@ struct Out {
 
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
                                   int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, int lane_max_w, int lane_capw,
-                                  int lane_heavy_per, int lane_budget, plo_batch_out *out, unsigned long long *counters_out) {
+                                  int lane_heavy_per, int lane_budget, int lane_stream, plo_batch_out *out, unsigned long long *counters_out) {
+    // lane_stream (with lane_heavy_per > 0, all stages): the heavy classes through the streaming kernel (lane_stream.hpp) -- 1: the GPU's
+    // rings, 2: the three-waves-per-SIMD rings, 3: the smallest rings the code allows (unreleased tails outgrow them: retry list)
     // lane_max_w >= 0: items up to that weight run through the lane-per-item code (lane_core.hpp) with an LDS slice of lane_capw
     // dwords per wave; what it cannot hold goes to the retry list like on the GPU
     // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
@@ -205,7 +208,29 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             int stride = (int)((max_w + LANE_SLACK + 64u + LANE_REGION_PAD + 31u) & ~31u);
             if (const char *e = getenv("PLO_EMU_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;  // (regions too small for the longer items: retry list)
             std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS + LANE_KVS_DWORDS, 0xdeadbeefu);
-            for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
+            const bool stream = lane_stream > 0 && (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL;
+            std::vector<uint32_t> slds((size_t)stream_lds_dwords(16, 16, 16, 16) + 16, 0xdeadbeefu);
+            for (uint32_t wv_id = 0; wv_id < n_waves && stream; ++wv_id) {
+                wv::EmuWave w;
+                w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
+                const uint32_t lo_ = n_small, mid_ = n_small + r2[n_items], hi_ = n_items;
+                w.run([&]() {
+                    WaveCtx ctx;
+                    if (lane_stream == 1) {
+                        if (sp) lane_stream_persistent<true, 16, 16, 16, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                        else lane_stream_persistent<false, 16, 16, 16, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                    } else if (lane_stream == 2) {
+                        if (sp) lane_stream_persistent<true, 16, 8, 8, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                        else lane_stream_persistent<false, 16, 8, 8, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                    } else {
+                        if (sp) lane_stream_persistent<true, 16, 8, 4, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                        else lane_stream_persistent<false, 16, 8, 4, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
+                    }
+                    wave_ctx_flush(wk, ctx, 0);
+                });
+                sum_stats();
+            }
+            for (uint32_t wv_id = 0; wv_id < n_waves && !stream; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
                 w.run([&]() {

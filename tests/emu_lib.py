@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False, sanitize=False):
     srcs = [os.path.join(_HERE, "emu", "emu_harness.cpp"), os.path.join(_HERE, "emu", "plo_wave.hpp")] + [
-        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "lane_core.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
+        os.path.join(ROOT, "portello_amd", "csrc", f) for f in ("lift_core.hpp", "lane_core.hpp", "lane_stream.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "emu"),
@@ -34,7 +34,7 @@ def lib():
         L = C.CDLL(_LIB)
         L.emu_liftover_batch.restype = C.c_int
         L.emu_liftover_batch.argtypes = [C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.c_uint32, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.PloBatchOut), C.POINTER(C.c_ulonglong)]
+                                         C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.PloBatchOut), C.POINTER(C.c_ulonglong)]
         L.emu_finish_batch.restype = C.c_int
         L.emu_finish_batch.argtypes = [C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn), C.POINTER(abi.PloBatchOut), C.c_int,
                                        C.POINTER(abi.PloFinishOut)]
@@ -44,12 +44,12 @@ def lib():
 
 
 def liftover_batch(index: abi.IndexData, batch: abi.BatchData, stages=abi.STAGES_ALL, cap=768, window=256, big_thresh=256,
-                   big_cap=1 << 16, order_seed=0, mid_waves=0, mid_cap=2048, lane_max_w=-1, lane_capw=3072, lane_heavy_per=0, lane_budget=0):
+                   big_cap=1 << 16, order_seed=0, mid_waves=0, mid_cap=2048, lane_max_w=-1, lane_capw=3072, lane_heavy_per=0, lane_budget=0, lane_stream=0):
     d = index.to_desc()
     b = batch.to_desc()
     out = abi.PloBatchOut()
     counters = (C.c_ulonglong * 24)()
-    rc = lib().emu_liftover_batch(C.byref(d), C.byref(b), stages, cap, window, big_thresh, big_cap, order_seed, mid_waves, mid_cap, lane_max_w, lane_capw, lane_heavy_per, lane_budget, C.byref(out), counters)
+    rc = lib().emu_liftover_batch(C.byref(d), C.byref(b), stages, cap, window, big_thresh, big_cap, order_seed, mid_waves, mid_cap, lane_max_w, lane_capw, lane_heavy_per, lane_budget, lane_stream, C.byref(out), counters)
     res = abi.result_from_out(out)
     lib().emu_free_last()
     return rc, res, list(counters)
