@@ -741,7 +741,8 @@ def main():
         dominant = max(kms, key=kms.get)
         dom_ms = kms[dominant]
         # the name rocprofv3 lists it under: the tile kernel of batches without heavy items has its slice capacity compiled in
-        dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
+        dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>",
+                    "k_lift_lanes_g": {2: "k_lift_lanes_g_w3", 3: "k_lift_stream"}.get(int(tm.heavy_kernel), "k_lift_lanes_g")}.get(dominant, dominant)
         # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
         # attribute them to the dominant kernel in proportion to its share of the lift time
         share = dom_ms / max(1e-9, sum(kms.values()))

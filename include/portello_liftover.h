@@ -230,6 +230,9 @@ typedef struct plo_timing {
     uint32_t n_heavy_lane_items;
     float lane_utilisation;      /* lane-per-item kernels: lanes at work / (64 x loop trips), summed over the liftover loop and the
                                     shift stage's event rounds of all waves (0 when no such kernel ran)                      */
+    uint32_t heavy_kernel;       /* which kernel `heavy_lanes_ms` is the time of: 0 none, 1 k_lift_lanes_g, 2 k_lift_lanes_g_w3,
+                                    3 k_lift_stream (teams of waves, stages chained through LDS rings)                       */
+    uint32_t host_syncs;         /* host round trips of the call (stream synchronisations that returned counts to the host)  */
 } plo_timing;
 
 plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **out);

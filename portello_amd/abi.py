@@ -140,6 +140,8 @@ class PloTiming(C.Structure):
         ("heavy_lanes_ms", C.c_float),
         ("n_heavy_lane_items", C.c_uint32),
         ("lane_utilisation", C.c_float),
+        ("heavy_kernel", C.c_uint32),
+        ("host_syncs", C.c_uint32),
     ]
 
 

@@ -20,7 +20,7 @@ from . import abi
 from . import cigar as cg
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libportello_liftover.so")
+LIB_PATH = os.environ.get("PLO_LIB") or os.path.join(_HERE, "libportello_liftover.so")  # (PLO_LIB: timing-experiment builds, tools/)
 
 Backend = Callable[[abi.IndexData, abi.BatchData, int], abi.BatchResult]
 

@@ -823,29 +823,28 @@ __global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_
     lift_lanes_g_kernel<true>(ix, bt, wk, stages, lo, mid, hi, per, scratch, stride);
 }
 
-// HEAVY items, streamed (lane_stream.hpp): the same stage code, the stages chained through four LDS rings per lane instead of running one
-// after the other over regions in global memory; a lane takes the wave's next item when it has finished one.  Taken by batches that
-// run all stages; two waves per SIMD with rings of 16 ops, three (`_w3`) with 16 / 8 / 8 / 16.
+// HEAVY items, streamed (lane_stream.hpp): the same stage code as a PIPELINE OF WAVES -- a workgroup is a team of three waves (left shift,
+// liftover, simplify; two for the forward class) working on the same 64 item slots, the ops flowing from wave to wave through rings in
+// LDS; a lane of the head wave takes the team's next item when it has finished one.  Taken by batches that run all stages.
+// Teams [0, t0): the forward class, [t0, t0 + t1): the reverse class; more teams than the chip holds are started as others retire.
+#ifndef PLO_PIPE_WPE
+#define PLO_PIPE_WPE 4
+#endif
 template <bool SP, int NI, int N1, int N2, int N3>
-PLO_DEV void lift_stream_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t lo, uint32_t mid, uint32_t hi) {
-    __shared__ uint32_t rings[LANE_G_WAVES][stream_lds_dwords(NI, N1, N2, N3)];
-    const uint32_t k = threadIdx.x >> 6;
-    // XCD-aware placement as in lift_lanes_kernel: neighbouring shares of the class order -- reads over the same stretch of a contig -- share an L2
-    const uint32_t nb = gridDim.x, per = nb >> 3, b = blockIdx.x;
-    const uint32_t tb = (per > 0 && (nb & 7u) == 0) ? (b & 7u) * per + (b >> 3) : b;
-    const uint32_t wave = tb * LANE_G_WAVES + k, n_waves = nb * LANE_G_WAVES;
+PLO_DEV void lift_stream_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t lo, uint32_t mid, uint32_t hi, uint32_t t0, uint32_t t1) {
+    __shared__ uint32_t rings[stream_lds_dwords(NI, N1, N2, N3)];
+    uint32_t b = 0, e = 0;
+    bool has_shift = false;
+    pipe_team_span(blockIdx.x, t0, t1, lo, mid, hi, b, e, has_shift);
     WaveCtx ctx;
-    lane_stream_persistent<SP, NI, N1, N2, N3>(ix, bt, wk, wave, n_waves, lo, mid, hi, rings[k], ctx);
-    wave_ctx_flush(wk, ctx, wave);
+    pipe_team<SP, NI, N1, N2, N3>(ix, bt, wk, b, e, has_shift, rings, ctx);
+    wave_ctx_flush(wk, ctx, blockIdx.x * PIPE_WAVES + (uint32_t)wv::wave_id());
 }
-__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_stream(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
-    lift_stream_kernel<false, 16, 16, 16, 16>(ix, bt, wk, lo, mid, hi);
+__global__ __launch_bounds__(PIPE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_PIPE_WPE, PLO_PIPE_WPE))) void k_lift_stream(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi, uint32_t t0, uint32_t t1) {
+    lift_stream_kernel<false, 16, 16, 16, 32>(ix, bt, wk, lo, mid, hi, t0, t1);
 }
-__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lift_stream_w3(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
-    lift_stream_kernel<false, 16, 8, 8, 16>(ix, bt, wk, lo, mid, hi);
-}
-__global__ __launch_bounds__(LANE_G_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_stream_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi) {
-    lift_stream_kernel<true, 16, 16, 16, 16>(ix, bt, wk, lo, mid, hi);
+__global__ __launch_bounds__(PIPE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_PIPE_WPE, PLO_PIPE_WPE))) void k_lift_stream_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t lo, uint32_t mid, uint32_t hi, uint32_t t0, uint32_t t1) {
+    lift_stream_kernel<true, 16, 16, 16, 32>(ix, bt, wk, lo, mid, hi, t0, t1);
 }
 
 // Items of tiles (or of the lane kernel) whose intermediates overflowed the shared capacity: the tile code again, RETRY_PER
@@ -1249,6 +1248,7 @@ struct plo_ctx {
     // 100 k 13.1 / 9.9 ms, 250 k 32.5 / 16-20 ms.
     int lane_heavy_min = -1;
     int lane_heavy_ratio = 50000;
+    int lane_stream_ratio = 30000;  // the same for the streaming kernel (PLO_LANE_STREAM_RATIO)
     // workgroup-per-item kernel for the items a shared tile cannot hold (k_lift_mid): waves per workgroup (8 or 16; 0 = off,
     // such items then run one wave each from global scratch) and the largest LDS capacity in elements
     int mid_waves = 16;
@@ -1494,6 +1494,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     if (const char *e = getenv("PLO_LANE_BUDGET")) c->lane_budget = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
     if (const char *e = getenv("PLO_LANE_HEAVY_RATIO")) c->lane_heavy_ratio = std::max(0, atoi(e));
+    if (const char *e = getenv("PLO_LANE_STREAM_RATIO")) c->lane_stream_ratio = std::max(1, atoi(e));
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1601,6 +1602,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;  // the `_sp` kernels: probes look granules up
     hipStream_t st = c->stream;
     memset(&c->timing, 0, sizeof(c->timing));
+    uint32_t n_syncs = 0;  // host round trips of the call
     c->ev_big = false;
     c->ev_mid = false;
 
@@ -1633,7 +1635,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         uint32_t *h = c->h_counters.as<uint32_t>();
         HIP_TRY(c, hipMemcpyAsync(h, c->seg_off.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(h + 1, c->verr.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, hipStreamSynchronize(st)); ++n_syncs;
         if (h[1]) return verr_status(h[1]);
         n_items = in->item_seg ? in->n_items : h[0];
     }
@@ -1734,7 +1736,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                c->wave_stats.as<unsigned long long>(), stat_used, c->counters.as<unsigned long long>());            \
         stat_used = 0;                                                                                                               \
         HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));                                         \
-        HIP_TRY(c, hipStreamSynchronize(st));                                                                                        \
+        HIP_TRY(c, hipStreamSynchronize(st)); ++n_syncs;                                                                                        \
     } while (0)
     wk.big_list = c->big_list.as<uint32_t>();
     if (c->lane_sort && c->lane_budget && c->lane_max_w >= 0) {
@@ -1774,7 +1776,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                (const uint32_t *)c->misc.as<uint32_t>(), n_items, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
                                c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu);
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipEventSynchronize(c->ev_cls));  // (the copies are done; k_permute2 may still be running)
+            HIP_TRY(c, hipEventSynchronize(c->ev_cls)); ++n_syncs;  // (the copies are done; k_permute2 may still be running)
         }
         if (m_[6]) return verr_status(m_[6]);
         h_cls[0] = m_[0];
@@ -1795,11 +1797,27 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     // longest item's by lane_heavy_ratio -- 50 000, the measured crossing on the stress profile (67 k reads of 2 000 ops, longest
     // 2 800 + 240 block-map allowance).  PLO_LANE_HEAVY_MIN: an item count instead (0: always).
     const uint32_t n_heavy_all = n_items - n_small;
+    // The streaming kernel (a team of waves per 64 item slots, lane_stream.hpp; all stages only) has a third of the lane kernel's latency per
+    // item -- its stages run side by side -- at about the same instructions per op: measured on the stress profile it is the fastest of the
+    // three from ~40 k heavy items (50 k reads: 5.9 ms against 6.65 ms workgroup-per-item and 8.6 ms k_lift_lanes_g) to ~200 k (100 k reads:
+    // 9.1 against 9.5 ms; 500 k: 30.6 against 25.9 ms k_lift_lanes_g_w3, whose waves each hold several groups by then).  So: the
+    // batch's ops against its longest item's by lane_stream_ratio (30 000) for the lower bound, the three-waves-per-SIMD rule of
+    // k_lift_lanes_g_w3 for the upper.  PLO_LANE_STREAM=0 / 1: never / whenever the lane path is taken.
+    bool stream_ok = (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL && c->lane_stream && n_items < (1u << 28);
+    bool stream_forced = false;
+    if (const char *e = getenv("PLO_LANE_STREAM")) {
+        stream_ok = stream_ok && atoi(e) != 0;
+        stream_forced = stream_ok;
+    }
+    const bool stream_size = n_heavy_all >= 8192u && n_heavy_all < (uint32_t)c->n_cus * 3u * LANE_G_WAVES * 64u &&
+                             all_ops >= (unsigned long long)c->lane_stream_ratio * std::min<unsigned long long>(max_nin, 16384ull);
     const bool heavy_lanes =
         n_heavy_all > 0 && c->lane_max_w >= 0 &&
         (c->lane_heavy_min >= 0 ? n_heavy_all >= (uint32_t)c->lane_heavy_min
-                                : (c->lane_heavy_ratio > 0 && n_heavy_all >= 8192u &&
-                                   all_ops >= (unsigned long long)c->lane_heavy_ratio * std::min<unsigned long long>(max_nin, 16384ull)));
+                                : ((stream_ok && stream_size) ||
+                                   (c->lane_heavy_ratio > 0 && n_heavy_all >= 8192u &&
+                                    all_ops >= (unsigned long long)c->lane_heavy_ratio * std::min<unsigned long long>(max_nin, 16384ull))));
+    const bool heavy_stream = heavy_lanes && stream_ok && (stream_forced || stream_size || c->lane_heavy_min >= 0);
     if (n_items > n_small && !heavy_lanes) {
         plo_status s = scan_u32(c, c->nin_p.as<uint32_t>(), n_items, c->op_prefix.as<uint32_t>());
         if (s != PLO_OK) return s;
@@ -1812,7 +1830,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         // one copy: [0] max weight, [2..3] weight sum, [4] tiled weight, [8..] weight histogram
         uint32_t *m_ = c->h_counters.as<uint32_t>() + 64;
         HIP_TRY(c, hipMemcpyAsync(m_, c->whist.p, (WHIST_AT + WHIST_BINS) * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
+        HIP_TRY(c, hipStreamSynchronize(st)); ++n_syncs;
         uint32_t *h = c->h_counters.as<uint32_t>();
         for (int k = 0; k < WHIST_BINS; ++k) h[8 + k] = m_[WHIST_AT + k];
         total_ops = m_[4];  // weight of the tiled items
@@ -1883,7 +1901,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         c->seq_pending = false;
     }
     unsigned long long *hc = c->h_counters.as<unsigned long long>();
-    uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0, n_miss = 0;
+    uint32_t n_big = 0, n_retry = 0, n_mid = 0, n_huge = 0, n_miss = 0, heavy_kernel = 0;
     float miss_ms = 0.f;
     for (int attempt = 0;; ++attempt) {
         wk.out_cigar = c->o_cigar.as<uint32_t>();
@@ -1948,21 +1966,31 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             uint32_t nblk = std::min<uint32_t>((groups + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ));
             // all stages: the streaming kernel (lane_stream.hpp; PLO_LANE_STREAM=0: the kernel over global regions below, which also
             // takes the stage subsets) -- no scratch, every wave an equal contiguous share of either class
-            bool stream = (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL && c->lane_stream;
-            if (const char *e = getenv("PLO_LANE_STREAM")) stream = stream && atoi(e) != 0;
+            const bool stream = heavy_stream;
             if (stream) {
-                const uint32_t n_waves = (n_heavy + per - 1) / per;
-                nblk = std::max<uint32_t>(1u, std::min<uint32_t>((n_waves + LANE_G_WAVES - 1) / LANE_G_WAVES, (uint32_t)(c->n_cus * occ)));
-                if (nblk >= 8u) nblk &= ~7u;  // (the XCD mapping wants a multiple of 8)
+                // Items per team: 64, one per lane -- more teams than the chip holds are started as others retire, which levels the load
+                // better than lanes taking a second item does (measured, stress profile: 64 / 128 / 256 items per team 9.9 / 11.4 / 20.8 ms
+                // at 100 k reads, 30.6 / 32.6 / 41 ms at 500 k: a team is as slow as its last lane, and with 80 items on 64 lanes the second
+                // half of its run has a quarter of the lanes at work).  A batch too small to give every CU four teams of 64 is spread over
+                // as many teams with fewer lanes each (at least 8).
+                const uint32_t full = 64u * (uint32_t)c->n_cus * 4u;
+                uint32_t per_team = n_heavy >= full ? 64u : std::min(64u, std::max(8u, (n_heavy + (uint32_t)c->n_cus * 4u - 1) / ((uint32_t)c->n_cus * 4u)));
+                int tocc = 0;
+                if (getenv("PLO_DEBUG_GEOMETRY") && hipOccupancyMaxActiveBlocksPerMultiprocessor(&tocc, sp ? (const void *)k_lift_stream_sp : (const void *)k_lift_stream, PIPE_WAVES * 64, 0) != hipSuccess) tocc = 0;
+                if (const char *e = getenv("PLO_LANE_HEAVY_PER")) per_team = std::min(4096u, std::max(1u, (uint32_t)atoi(e)));
+                // (every wave of the launch has a statistics slot)
+                while (((unsigned long long)(n2 + per_team - 1) / per_team + (n3 + per_team - 1) / per_team) * PIPE_WAVES + stat_used > STAT_SLOTS) per_team *= 2;
+                const uint32_t t0 = (n2 + per_team - 1) / per_team, t1 = (n3 + per_team - 1) / per_team;
+                nblk = t0 + t1;
                 if (getenv("PLO_DEBUG_GEOMETRY"))
-                    fprintf(stderr, "[plo] heavy items through the streaming lane kernel: %u items, %u workgroups of %d waves (%d per SIMD), ~%u items per wave\n", n_heavy, nblk,
-                            LANE_G_WAVES, occ, n_heavy / (nblk * LANE_G_WAVES));
+                    fprintf(stderr, "[plo] heavy items through the streaming lane kernel: %u + %u items, %u + %u teams of %d waves (%d teams per CU), %u items per team\n", n2, n3,
+                            t0, t1, PIPE_WAVES, tocc, per_team);
                 wk.slab_pre = 0u;
                 if (!n_small) wk.slab_offset = 0ull;
-                PLO_STAT_RANGE(nblk * LANE_G_WAVES);
-                if (sp) hipLaunchKernelGGL(k_lift_stream_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
-                else if (w3) hipLaunchKernelGGL(k_lift_stream_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
-                else hipLaunchKernelGGL(k_lift_stream, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items);
+                PLO_STAT_RANGE(nblk * PIPE_WAVES);
+                heavy_kernel = 3u;
+                if (sp) hipLaunchKernelGGL(k_lift_stream_sp, dim3(nblk), dim3(PIPE_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items, t0, t1);
+                else hipLaunchKernelGGL(k_lift_stream, dim3(nblk), dim3(PIPE_WAVES * 64), 0, st, ix, bt, wk, n_small, n_small + n2, n_items, t0, t1);
             } else {
                 // Regions start on 128-byte lines and hold the heaviest item of the batch (64: room for the liftover's gap, lane_region_gap)
                 // -- unless that one is an outlier: the regions of all resident lanes together are kept within 8 GB, an item too long for
@@ -1983,6 +2011,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 wk.slab_pre = 0u;  // (a group's output is a slab of its own; the light items' waves own the first slabs, if any)
                 if (!n_small) wk.slab_offset = 0ull;
                 PLO_STAT_RANGE(nblk * LANE_G_WAVES);
+                heavy_kernel = w3 ? 2u : 1u;
                 if (sp) hipLaunchKernelGGL(k_lift_lanes_g_sp, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
                 else if (w3) hipLaunchKernelGGL(k_lift_lanes_g_w3, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
                 else hipLaunchKernelGGL(k_lift_lanes_g, dim3(nblk), dim3(LANE_G_WAVES * 64), 0, st, ix, bt, wk, stages, n_small, n_small + n2, n_items, per, c->lane_scratch.as<uint32_t>(), stride);
@@ -2115,7 +2144,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                bt, wk, d_read, d_len);
             uint32_t *h_read = c->h_miss.as<uint32_t>(), *h_len = h_read + n_miss;
             HIP_TRY(c, hipMemcpyAsync(h_read, d_read, (size_t)n_miss * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
+            HIP_TRY(c, hipStreamSynchronize(st)); ++n_syncs;
             std::vector<uint32_t> order(n_miss);
             for (uint32_t k = 0; k < n_miss; ++k) order[k] = k;
             std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_read[a] < h_read[b]; });
@@ -2187,6 +2216,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.miss_ms = miss_ms;
     c->timing.n_lane_items = n_small;
     c->timing.n_heavy_lane_items = heavy_lanes ? n_items - n_small : 0u;
+    c->timing.heavy_kernel = heavy_kernel;
+    c->timing.host_syncs = n_syncs;
     c->timing.n_retry_items = n_retry;
     if (c->adaptive && c->cap == TILE_CAP_SMALL && n_retry > n_items / 200) c->small_window_tight = true;
     c->timing.n_in_ops = hc[CNT_IN_OPS];

@@ -28,8 +28,8 @@ struct Out {
 extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in *in, uint32_t stages, int cap, int window,
                                   int big_thresh, int big_cap, unsigned order_seed, int mid_waves, int mid_cap, int lane_max_w, int lane_capw,
                                   int lane_heavy_per, int lane_budget, int lane_stream, plo_batch_out *out, unsigned long long *counters_out) {
-    // lane_stream (with lane_heavy_per > 0, all stages): the heavy classes through the streaming kernel (lane_stream.hpp) -- 1: the GPU's
-    // rings, 2: the three-waves-per-SIMD rings, 3: the smallest rings the code allows (unreleased tails outgrow them: retry list)
+    // lane_stream (with lane_heavy_per > 0, all stages): the heavy classes through the streaming kernel (lane_stream.hpp) -- teams of three waves, 1: the GPU's
+    // rings, 2: the smallest Q2 the code allows (unreleased tails outgrow it: retry list)
     // lane_max_w >= 0: items up to that weight run through the lane-per-item code (lane_core.hpp) with an LDS slice of lane_capw
     // dwords per wave; what it cannot hold goes to the retry list like on the GPU
     // mid_waves: 0 = items beyond big_thresh run one wave each (LEVEL_LAST); 2..16 = they first go through the workgroup-per-item
@@ -209,26 +209,39 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             if (const char *e = getenv("PLO_EMU_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;  // (regions too small for the longer items: retry list)
             std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS + LANE_KVS_DWORDS, 0xdeadbeefu);
             const bool stream = lane_stream > 0 && (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL;
-            std::vector<uint32_t> slds((size_t)stream_lds_dwords(16, 16, 16, 16) + 16, 0xdeadbeefu);
-            for (uint32_t wv_id = 0; wv_id < n_waves && stream; ++wv_id) {
-                wv::EmuWave w;
-                w.order_seed = order_seed ? order_seed + 61 + wv_id : 0;
+            std::vector<uint32_t> slds((size_t)stream_lds_dwords(16, 16, 16, 32) + 16, 0xdeadbeefu);
+            if (stream) {
+                // teams of three waves (lane_stream.hpp): `lane_heavy_per` items per team, the forward class first
                 const uint32_t lo_ = n_small, mid_ = n_small + r2[n_items], hi_ = n_items;
-                w.run([&]() {
-                    WaveCtx ctx;
-                    if (lane_stream == 1) {
-                        if (sp) lane_stream_persistent<true, 16, 16, 16, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                        else lane_stream_persistent<false, 16, 16, 16, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                    } else if (lane_stream == 2) {
-                        if (sp) lane_stream_persistent<true, 16, 8, 8, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                        else lane_stream_persistent<false, 16, 8, 8, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                    } else {
-                        if (sp) lane_stream_persistent<true, 16, 8, 4, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                        else lane_stream_persistent<false, 16, 8, 4, 16>(ix, bt, wk, wv_id, n_waves, lo_, mid_, hi_, slds.data(), ctx);
-                    }
-                    wave_ctx_flush(wk, ctx, 0);
-                });
-                sum_stats();
+                const uint32_t per_ = (uint32_t)lane_heavy_per;
+                const uint32_t t0 = (mid_ - lo_ + per_ - 1) / per_, t1 = (hi_ - mid_ + per_ - 1) / per_;
+                for (uint32_t team = 0; team < t0 + t1; ++team) {
+                    wv::EmuWave w;
+                    w.nw = PIPE_WAVES;
+                    w.order_seed = order_seed ? order_seed + 61 + team : 0;
+                    std::fill(slds.begin(), slds.end(), 0xdeadbeefu);
+                    w.run([&]() {
+                        WaveCtx ctx;
+                        uint32_t b_, e_;
+                        bool hs;
+                        pipe_team_span(team, t0, t1, lo_, mid_, hi_, b_, e_, hs);
+                        if (lane_stream == 1) {
+                            if (sp) pipe_team<true, 16, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            else pipe_team<false, 16, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                        } else {
+                            if (sp) pipe_team<true, 16, 16, 8, 16>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            else pipe_team<false, 16, 16, 8, 16>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                        }
+                        // the waves of the emulated workgroup share the one statistics slot: one wave at a time
+                        for (int ww = 0; ww < PIPE_WAVES; ++ww) {
+                            if (ww == wv::wave_id()) {
+                                wave_ctx_flush(wk, ctx, 0);
+                                if (wv::lane() == 0) sum_stats();
+                            }
+                            wv::block_sync();
+                        }
+                    });
+                }
             }
             for (uint32_t wv_id = 0; wv_id < n_waves && !stream; ++wv_id) {
                 wv::EmuWave w;

@@ -94,8 +94,8 @@ def test_timing_struct_size_contract_on_a_real_context(lib_path):
 def test_ctypes_struct_layout_matches_header():
     # sizes implied by the header on LP64
     assert C.sizeof(abi.PloBatchOut) == 8 + 10 * 8 + 8
-    # struct_size + 4 floats + 2 u32 | 3 u64 | 4 + 2 + 2 + 2 + 2 + 1 four-byte fields (+ tail padding to 8)
-    assert C.sizeof(abi.PloTiming) == 8 * 4 + 3 * 8 + 14 * 4
+    # struct_size + 4 floats + 2 u32 | 3 u64 | 4 + 2 + 2 + 2 + 2 + 1 + 2 four-byte fields (+ tail padding to 8)
+    assert C.sizeof(abi.PloTiming) == 8 * 4 + 3 * 8 + 16 * 4
     assert abi.PloTiming.struct_size.offset == 0 and abi.PloTiming.n_in_ops.offset == 32
     assert C.sizeof(abi.PloBatchIn) == 8 + 4 * 8 + 8 + 8 + 6 * 8 + 8 + 2 * 8 + 2 * 8
     assert C.sizeof(abi.PloIndexDesc) == 8 + 2 * 8 + 8 + 8 * 8 + 8 + 3 * 8 + 8

@@ -273,3 +273,28 @@ def test_block_map_searches_against_searchsorted():
                 assert out[0] == lo + int(np.searchsorted(sub, x, side="right")), (n, lo, hi, x)
                 assert out[1] == lo + int(np.searchsorted(sub, x, side="left")), (n, lo, hi, x)
                 assert out[2] == near + int(np.searchsorted(keys[near:hi], x, side="left")), (n, lo, hi, x, near)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_streaming_kernel_indel_dense_items(oracle, case):
+    """lane_stream.hpp under the emulator (teams of three waves with random drift between them): indel-dense reads of ~3 kb -- hundreds of
+    ops per item, so that every ring wraps many times, headers and end markers of successive items share a ring, lanes take second and
+    third items while their neighbours are mid-way -- on clean and on indel-rich contigs (block-map crossings, gap deletions, items
+    that do not lift), forward and reverse classes; rings as on the GPU and with the smallest Q2 (retry list)"""
+    R = synth.EditRates
+    rr, cr, sp = [
+        (R(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.5, min_gap=1), None, 0.1),
+        (R(mismatch=5e-3, ins=2.5e-2, dele=2.5e-2, hpol_frac=0.9, min_gap=1), R(mismatch=1e-3, ins=2e-3, dele=2e-3, hpol_frac=0.3, big_indel_prob=0.01), 0.3),
+        (R(mismatch=2e-2, ins=5e-2, dele=5e-2, hpol_frac=0.7, min_gap=1), R(mismatch=1e-3, ins=1e-2, dele=1e-2, hpol_frac=0.3, big_indel_prob=0.05), 0.3),
+    ][case]
+    over = dict(n_reads=200, seed=40 + case, split_read_frac=sp, read_len_mean=3000, read_len_sd=1200, read_rates=rr)
+    if cr is not None:
+        over["contig_rates"] = cr
+    w = synth.generate(synth.config("tiny", **over))
+    ix, b = w.index_data(), w.batch_data()
+    ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1).canonical()
+    for mode, per, oseed in ((1, 64, 0), (1, 150, 99), (2, 64, 5)):
+        rc, got, cnt = emu_lib.liftover_batch(ix, b, lane_max_w=12, lane_capw=1024, lane_heavy_per=per, lane_stream=mode, order_seed=oseed)
+        assert rc == 0 and cnt[23] == 0  # (every item is heavy: all of them took the streaming kernel)
+        assert got.canonical() == ref, f"rings {mode}, {per} items per team, order seed {oseed}"
+        assert cnt[7] <= (0 if mode == 1 and case < 2 else got.n_items // 10)  # items handed to the retry list

@@ -41,6 +41,14 @@ def test_fuzz_emulated_device_algorithm(oracle, seed):
                                                   lane_capw=1024, lane_heavy_per=(64, 5)[seed % 2])
             assert rc == 0 and cnt[23] < got.n_items
             _diff(ref, got, b, f"heavy lane path: seed {seed} alpha {alpha} stages {stages}")
+            if stages == abi.STAGES_ALL:
+                # ... and through the streaming kernel (lane_stream.hpp): teams of three emulated waves, the stages chained through LDS rings
+                # (2: with the smallest Q2 the code allows -- unreleased tails outgrow it and the items take the retry list), waves drifting
+                for mode, oseed in ((1, 0), (2, 0), (1, 7 + seed)):
+                    rc, got, cnt = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096, lane_max_w=12,
+                                                          lane_capw=1024, lane_heavy_per=(64, 5)[seed % 2], lane_stream=mode, order_seed=oseed)
+                    assert rc == 0 and cnt[23] < got.n_items
+                    _diff(ref, got, b, f"streaming kernel (rings {mode}, order seed {oseed}): seed {seed} alpha {alpha}")
 
 
 @pytest.mark.gpu
@@ -58,7 +66,7 @@ def test_fuzz_hip(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["g", "g_w3", "stream", "stream_w3"])
+@pytest.mark.parametrize("variant", ["g", "g_w3", "stream"])
 @pytest.mark.parametrize("per", ["64", "5"])
 def test_fuzz_hip_heavy_lane_kernel(oracle, monkeypatch, per, variant):
     """VERDICT r3 (weak #1), r4 (next #6): the 40 adversarial seeds x 7 stage sets through EVERY instantiation of the heavy-item lane kernel

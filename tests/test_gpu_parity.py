@@ -398,7 +398,8 @@ def test_every_item_of_100k_stress_reads_heavy_lane_kernel(oracle, monkeypatch):
             monkeypatch.setenv(k, v)  # (read by every batch call)
         gots[name] = devbatch.run_and_download(eng, db)
         t = eng.timing()
-        assert t.n_heavy_lane_items > 0.9 * gots[name].n_items and t.n_mid_items == 0, name
+        # (the streaming kernel hands the few items whose unreleased tail outgrows a ring to the wave-cooperative code)
+        assert t.n_heavy_lane_items > 0.9 * gots[name].n_items and t.n_mid_items <= (0 if name.startswith("g") else gots[name].n_items // 200), name
     ix = w.index_data()
     n_cmp = 0
     n_items = gots["g"].n_items
