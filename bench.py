@@ -750,6 +750,7 @@ def main():
         # HBM traffic from the PMC counters (profiles/hbm_traffic.json, refreshed by tools/save_profiles.py): reported only when the
         # entry was collected on this workload, this read count and these very kernel sources -- else null
         traffic = None
+        issue = None  # wave-instructions per launch of the dominant kernel (same keyed profile): what the SIMDs must issue at the least
         src_hash = plo_build.source_hash()
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
@@ -757,6 +758,7 @@ def main():
                 ent = json.load(open(prof)).get(cfg.name, {})
                 if ent.get("_reads") == int(my_reads) and ent.get("_source_hash") == src_hash and ent.get("_n_gpus", 1) == world:
                     traffic = ent.get(dom_name, ent.get(dominant))
+                    issue = ent.get("_insts")
             except Exception:
                 traffic = None
 
@@ -766,6 +768,21 @@ def main():
         enum_bytes = 4 * int(tm.n_in_ops) + 25 * int(db.n_segs) + 13 * int(db.n_reads) + 100 * int(tm.n_items)
         enum_obj = {"ms": enum_ms, "algorithmic_bytes": enum_bytes, "achieved": enum_bytes / (enum_ms * 1e-3) / 1e9 if enum_ms > 0 else 0.0,
                     "unit": "GB/s", "frac": (enum_bytes / (enum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if enum_ms > 0 else 0.0}
+        # The issue floor beside the HBM fraction, so that the line itself says which resource binds: a wave-instruction occupies its SIMD's
+        # issue slot for four cycles (wave64 on 16 lanes); `issue_floor_ms` counts the vector instructions only (what VERDICT r4 asked for),
+        # `issue_floor_all_ms` every instruction class -- measured on this engine's kernels, scalar instructions do not hide behind the vector
+        # ones of the few waves a SIMD holds: all three lane kernels run at 65-92 % of THAT floor
+        n_simds = 4 * int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        clock_hz = 2.4e9  # MI355X engine clock (MI355X_MICROARCH.md)
+        issue_obj = {"issue_floor_ms": None, "frac_of_issue_floor": None}
+        if issue and issue.get("valu") and dom_ms > 0:
+            fl = issue["valu"] * 4.0 / (n_simds * clock_hz) * 1e3
+            allc = sum(issue.get(k_, 0.0) for k_ in ("valu", "salu", "lds", "vmem_rd", "vmem_wr", "branch"))
+            issue_obj = {"issue_floor_ms": fl, "frac_of_issue_floor": fl / dom_ms, "issue_floor_all_ms": allc * 4.0 / (n_simds * clock_hz) * 1e3,
+                         "frac_of_issue_floor_all": allc * 4.0 / (n_simds * clock_hz) * 1e3 / dom_ms,
+                         "wave_instructions_per_launch": {k_: issue[k_] for k_ in ("valu", "salu", "lds", "vmem_rd", "vmem_wr", "branch") if k_ in issue},
+                         "wave_instructions_per_item": allc / max(1, int(tm.n_items)), "simds": n_simds, "clock_ghz": clock_hz / 1e9,
+                         "binding_resource": "instruction issue" if fl / dom_ms > achieved / HBM_PEAK_GBS else "hbm"}
         result = {
             "metric": "lifted HiFi reads/sec (whole node)",
             "value": total_reads * args.steps / dt_,
@@ -794,7 +811,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(tm.algo_bytes * share), "kernel_ms": dom_ms,
                          "enumerate_ms": float(np.mean(times["enum"])), "enumerate_pass": enum_obj, "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"],
                          "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_lanes_ms": kms["k_lift_lanes_g"],
-                         "lane_utilisation": float(tm.lane_utilisation)},  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
+                         "lane_utilisation": float(tm.lane_utilisation),  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
+                         "host_syncs_per_call": int(tm.host_syncs), **issue_obj},
         }
         return result
 

@@ -652,3 +652,48 @@ def test_device_entry_point_checks_its_batch():
     assert int(eng.liftover_batch_dev(good.desc()).n_items) > 0
     eng.close()
     index.close()
+
+
+def test_one_process_two_indexes(oracle):
+    """ONE process drives several `plo_index` objects -- one per device, a worker thread per context, no
+    collective, results by D2H (the reference picks its per-worker state the same way: src/worker_thread_data.rs:8-30,
+    src/read_alignment_scanner.rs:516-517).  Two indexes (devices 0 and 1 when the box has two, else ordinal 0 twice), two threads, each
+    lifts its half of a read set while the other runs; both halves equal the oracle, and each context can still be driven from the other
+    thread afterwards (the entry points set the calling thread's device themselves)."""
+    import threading
+
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    devs = [0, 1 % max(1, n_dev)]
+    w = synth.generate(synth.config("tiny", n_reads=600, seed=23, split_read_frac=0.15))
+    ix = w.index_data()
+    half = w.n_reads // 2
+    parts = [w.batch_data(0, half), w.batch_data(half, w.n_reads)]
+    indexes = [api.Index(ix, d) for d in devs]
+    engines = [api.Engine(indexes[k]) for k in range(2)]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(3):  # (several calls each: the two contexts' kernels and host syncs interleave)
+                got[k] = engines[k].liftover_batch(parts[k])
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        ref = oracle.liftover_batch(ix, parts[k], abi.STAGES_ALL, 1)
+        assert got[k].canonical() == ref.canonical(), f"index {k} on device {devs[k]}"
+    # a thread may drive contexts of different devices in turn
+    assert engines[1].liftover_batch(parts[1]).canonical() == got[1].canonical()
+    assert engines[0].liftover_batch(parts[0]).canonical() == got[0].canonical()
+    for e in engines:
+        e.close()
+    for i in indexes:
+        i.close()

@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ver = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 src = f"gpurun_out/{ver}"
 pre = f"profiles/{rnd}_{ver}_wgs30x"
 rows = list(csv.reader(open(f"{src}/kernel_stats.csv")))
@@ -28,6 +28,17 @@ shutil.copy(f"{src}/bench_under_rocprof.json", f"{pre}_bench_under_rocprof.json"
 
 def rd(p):
     return {l.split(",")[0]: float(l.split(",")[1]) for l in open(p) if "," in l}
+
+
+def insts(*paths):
+    """wave-instructions per launch of the dominant kernel by class (the SQ passes): bench.py derives roofline.issue_floor_ms from them"""
+    d = {}
+    for p in paths:
+        if os.path.exists(p):
+            d.update(rd(p))
+    keys = {"valu": "SQ_INSTS_VALU", "salu": "SQ_INSTS_SALU", "lds": "SQ_INSTS_LDS", "vmem_rd": "SQ_INSTS_VMEM_RD", "vmem_wr": "SQ_INSTS_VMEM_WR",
+            "branch": "SQ_INSTS_BRANCH", "wave_cycles": "SQ_WAVE_CYCLES", "wait_any": "SQ_WAIT_ANY"}
+    return {k: d[v] for k, v in keys.items() if v in d}
 
 
 fe, wr = rd(f"{src}/pmc_fetch.csv")["FETCH_SIZE"], rd(f"{src}/pmc_write.csv")["WRITE_SIZE"]
@@ -63,7 +74,8 @@ h["_fetch_factor"] = {"value": fetch_factor, "calibrated": calibrated,
                                  "MI355X_MICROARCH.md (streaming reads); NOT calibrated in this run" + (": the calibration's FETCH_SIZE pass failed" if calib else ""))}
 h["wgs30x"] = {b["roofline"]["kernel"]: int((fetch_factor * fe + wr) * 1024), "_fetch_size_kib": fe, "_write_size_kib": wr, "_fetch_factor": fetch_factor,
                "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"],
-               "_reads": b["config"]["reads_this_rank"], "_source_hash": b["config"]["kernel_source_hash"], "_n_gpus": b["n_gpus"]}
+               "_reads": b["config"]["reads_this_rank"], "_source_hash": b["config"]["kernel_source_hash"], "_n_gpus": b["n_gpus"],
+               "_insts": insts(f"{src}/pmc_sq1.csv", f"{src}/pmc_sq2.csv")}
 json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
 print(h["wgs30x"])
 print(json.dumps(b["roofline"]))
@@ -98,7 +110,8 @@ if os.path.exists(f"{src}/stress_kernel_stats.csv"):
     sb = json.load(open(f"{src}/stress_bench.json"))
     h["stress"] = {sb["roofline"]["kernel"]: int((fetch_factor * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr, "_fetch_factor": fetch_factor,
                    "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"],
-                   "_reads": sb["config"]["reads_this_rank"], "_source_hash": sb["config"]["kernel_source_hash"], "_n_gpus": sb["n_gpus"]}
+                   "_reads": sb["config"]["reads_this_rank"], "_source_hash": sb["config"]["kernel_source_hash"], "_n_gpus": sb["n_gpus"],
+                   "_insts": insts(f"{src}/stress_pmc_sq1.csv", f"{src}/stress_pmc_sq2.csv")}
     json.dump(h, open("profiles/hbm_traffic.json", "w"), indent=1)
     print(h["stress"])
     print(json.dumps(sb["roofline"]))
