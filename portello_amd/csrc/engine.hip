@@ -185,16 +185,17 @@ __global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stage
     emit_segment_items(ix, wk, stages, s, o0, (long long)ref_len, si);
 }
 
-// Block maps of the contig segments, built on the device at index creation: thread per contig split segment walks its
-// contig->reference CIGAR (build_segment_map, enumerate.hpp); count pass, host prefix sum (a few thousand segments),
-// emit pass.
-__global__ void k_map_build(const uint32_t *seg_cigar, const uint32_t *seg_cigar_off, const int64_t *seg_pos, uint32_t n_segments,
-                            const uint32_t *kv_off, KV *kv, int *counts) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_segments) return;
-    uint32_t c0 = seg_cigar_off[g], c1 = seg_cigar_off[g + 1];
-    int cnt = build_segment_map(seg_cigar + c0, c1 - c0, (long long)seg_pos[g], kv ? kv + kv_off[g] : nullptr);
-    if (counts) counts[g] = cnt;
+// Block maps of the contig segments, built on the device at index creation: ONE WAVE per contig split segment walks its contig->reference
+// CIGAR 64 ops at a time (build_segment_map_wave, enumerate.hpp: prefix sums for the positions, a max-scan for the start of every match
+// run, a prefix sum of 1 or 2 entries per flush); count pass, host prefix sum (a few thousand segments), emit pass.  (Round 4: one THREAD
+// per segment, 1 806 threads walking ~50 k ops each -- 37.8 ms per pass on wgs30x.)
+__global__ __launch_bounds__(64) void k_map_build(const uint32_t *seg_cigar, const uint32_t *seg_cigar_off, const int64_t *seg_pos, uint32_t n_segments,
+                                                  const uint32_t *kv_off, KV *kv, int *counts) {
+    for (uint32_t g = blockIdx.x; g < n_segments; g += gridDim.x) {
+        const uint32_t c0 = seg_cigar_off[g], c1 = seg_cigar_off[g + 1];
+        const int cnt = build_segment_map_wave(seg_cigar + c0, c1 - c0, (long long)seg_pos[g], kv ? kv + kv_off[g] : nullptr);
+        if (counts && threadIdx.x == 0) counts[g] = cnt;
+    }
 }
 
 // explicit item list: thread per item
@@ -756,12 +757,16 @@ constexpr int LANE_WAVES = 4;
 #ifndef PLO_LANE_WPE_MIN
 #define PLO_LANE_WPE_MIN PLO_LANE_WPE
 #endif
+#ifndef PLO_LANE_FWD_WPE
+#define PLO_LANE_FWD_WPE 3  // k_lift_lanes_fwd (no shift stage)
+#endif
 #ifndef PLO_LANE_G_WPE
 #define PLO_LANE_G_WPE 2  // k_lift_lanes_g: the windows' bookkeeping on top of 168 registers would spill; 12 KB of LDS per wave anyway
 #endif
 constexpr int LANE_G_WAVES = 4;
-template <bool SP>
-PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw) {
+template <bool SP, bool NOSHIFT = false>
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw, uint32_t base = 0,
+                               uint32_t slab_wave0 = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
@@ -771,11 +776,22 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
     const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
     WaveCtx ctx;
     if (wk.slab_pre) {
-        ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
+        ctx.slab_base = (unsigned long long)(wave + slab_wave0) * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx);
+    lane_tiles_persistent<SP, NOSHIFT>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx, base);
     wave_ctx_flush(wk, ctx, wave);
+}
+// The two light classes as two launches (PLO_LANE_SPLIT=1, an experiment of round 5): the forward class through an instantiation compiled
+// without the shift stage (k_lift_lanes_fwd), the other class through k_lift_lanes from its first position (`base`, `slab_wave0`: its waves'
+// pre-owned output slabs lie behind the first launch's)
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_FWD_WPE, PLO_LANE_FWD_WPE))) void k_lift_lanes_fwd(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                   uint32_t gs, int capw) {
+    lift_lanes_kernel<false, true>(ix, bt, wk, stages, n0, 0u, gs, capw);
+}
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_rev(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t base,
+                                                                                                   uint32_t n1, uint32_t gs, int capw, uint32_t slab_wave0) {
+    lift_lanes_kernel<false, false>(ix, bt, wk, stages, 0u, n1, gs, capw, base, slab_wave0);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
                                                                                                    uint32_t n1, uint32_t gs, int capw) {
@@ -1329,7 +1345,7 @@ plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **
             drop_tmp();
             return fail(PLO_ERR_HIP);
         }
-        if (ns) hipLaunchKernelGGL(k_map_build, dim3((ns + 63) / 64), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, (const uint32_t *)nullptr,
+        if (ns) hipLaunchKernelGGL(k_map_build, dim3(std::min<uint32_t>(ns, 65535u * 16u)), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, (const uint32_t *)nullptr,
                                    (KV *)nullptr, (int *)d_cnt);
         if (hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
             drop_tmp();
@@ -1355,7 +1371,7 @@ plo_status plo_index_create(const plo_index_desc *desc, int device, plo_index **
         }
         ix->owned.push_back(kvp);
         d.kv = (const KV *)kvp;
-        if (ns) hipLaunchKernelGGL(k_map_build, dim3((ns + 63) / 64), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, d.cs_kv_off, (KV *)kvp,
+        if (ns) hipLaunchKernelGGL(k_map_build, dim3(std::min<uint32_t>(ns, 65535u * 16u)), dim3(64), 0, 0, d_cg, d_cgoff, d_pos, ns, d.cs_kv_off, (KV *)kvp,
                                    (int *)nullptr);
         hipError_t e = hipDeviceSynchronize();
         drop_tmp();
@@ -1948,7 +1964,15 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
             if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
-            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
+            else if (getenv("PLO_LANE_SPLIT") && !wk.lane_groups && n0 && n1) {
+                // (experiment: the classes as two launches, the forward one without the shift stage's code; both over the whole grid)
+                hipLaunchKernelGGL(k_lift_lanes_fwd, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, gs, c->lane_capw);
+                DevWork wk2 = wk;
+                wk2.slab_pre = 0u;  // (the second launch reserves its slabs)
+                wk2.stat_base = stat_used;
+                stat_used += nblk * LANE_WAVES;
+                hipLaunchKernelGGL(k_lift_lanes_rev, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk2, stages, n0, n1, gs, c->lane_capw, 0u);
+            } else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));

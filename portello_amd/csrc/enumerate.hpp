@@ -76,7 +76,13 @@ PLO_DEV uint32_t segment_n_merged(const DevBatch &bt, uint32_t seg) {
 // span (entries w0+1 .. w1-1, and w0 itself when no block holds the item's start) and one jump deletion per block entered that
 // way -- and a little slack for the shift stage.
 constexpr int LANE_SLACK = 2;
-PLO_DEV int lane_region_gap(int w0, int w1) { return 2 * (w1 > w0 ? w1 - w0 : 0); }
+#ifndef PLO_LANE_GAP_HALVES
+#define PLO_LANE_GAP_HALVES 4  // the allowance per block-map key of the item's span, in halves of an op (4: the bound, two ops per key)
+#endif
+#ifndef PLO_LANE_GAP_CONST
+#define PLO_LANE_GAP_CONST 0
+#endif
+PLO_DEV int lane_region_gap(int w0, int w1) { return (PLO_LANE_GAP_HALVES * (w1 > w0 ? w1 - w0 : 0) + 1) / 2 + PLO_LANE_GAP_CONST; }
 PLO_DEV int lane_region_dwords(int n, int w0, int w1) { return n + lane_region_gap(w0, w1) + LANE_SLACK; }
 
 // block-map searches (ReadToRefTreeMap::get_ref_range, read_to_ref_map.rs:74-85)
@@ -196,6 +202,84 @@ PLO_HD int build_segment_map(const uint32_t *cigar, uint32_t n, long long ref_po
         if ((0x18D >> t) & 1) ref_pos += len;   // M D N = X
     }
     return bad ? -1 : cnt;
+}
+
+// The same block map built by ONE WAVE (index creation, k_map_build): 64 ops per step, lane i takes op base + i.  The sequential state of
+// build_segment_map becomes scans: the read / reference positions in front of every op are prefix sums (64-bit, as two 16-bit halves per
+// op); the match run that a non-match op flushes starts behind the nearest non-match op before it (a max-scan over lane indices; carried
+// over the step's border as the positions at which the open run starts); a flush appends {k0 -> Some(v0)}, {k1 -> None} -- or, when the
+// previous flush's k1 equals k0 (nothing of the read was consumed between the two: deletions), overwrites that None and appends one
+// entry -- so the entries' places are a prefix sum of 1 or 2 per flush.  Wave-uniform call; returns what build_segment_map returns.
+PLO_DEV long long wave_scan_add64(long long x) {  // inclusive; 0 <= x < 2^28 per lane (CIGAR op lengths)
+    const long long lo = (long long)wv::scan_add((int)(x & 0xffff)), hi = (long long)wv::scan_add((int)(x >> 16));
+    return (hi << 16) + lo;
+}
+PLO_DEV long long wave_bcast64(long long v, int src) { return wv::shfl(v, src); }
+PLO_DEV int build_segment_map_wave(const uint32_t *cigar, uint32_t n, long long ref_pos0, KV *out) {
+    const int lane = wv::lane();
+    long long read_base = 0, ref_base = ref_pos0;          // positions in front of the step's first op (wave-uniform)
+    long long run_read = 0, run_ref = ref_pos0;            // ... at which the open match run starts (behind the last non-match op so far)
+    long long last_key = -1;                               // k1 of the last flush (-1: none yet)
+    int cnt = 0;
+    bool bad = false;
+    for (uint32_t base = 0; base <= n; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool have = i <= n;                          // (op n: the trailing pseudo soft clip of length 0 that performs the final flush, :134)
+        const uint32_t c = i < n ? cigar[i] : 4u;
+        const int t = (int)(c & 15u);
+        const long long len = have ? (long long)(c >> 4) : 0;
+        bad = bad | (have & (t > 8));
+        const bool is_m = (t == OP_M) | (t == OP_EQ) | (t == OP_X);
+        const long long rl = ((0x1B3 >> t) & 1) ? len : 0, fl = ((0x18D >> t) & 1) ? len : 0;  // M I S H = X | M D N = X
+        const long long r_inc = wave_scan_add64(rl), f_inc = wave_scan_add64(fl);
+        const long long r_before = read_base + r_inc - rl, f_before = ref_base + f_inc - fl;
+        // the nearest non-match op in front of this one, inside the step
+        const int nm = (have & !is_m) ? lane : -1;
+        const int nm_inc = wv::scan_max(nm);
+        const int prev_nm = wv::shfl_up1(nm_inc, -1);      // (exclusive)
+        // positions behind that op = in front of op prev_nm + 1: the run's start
+        const long long r_after = r_before + rl, f_after = f_before + fl;
+        const long long rs_l = wave_bcast64(r_after, prev_nm < 0 ? 0 : prev_nm), fs_l = wave_bcast64(f_after, prev_nm < 0 ? 0 : prev_nm);
+        const long long rs = prev_nm < 0 ? run_read : rs_l, fs = prev_nm < 0 ? run_ref : fs_l;
+        const long long match_len = r_before - rs;         // (match ops consume read and reference alike)
+        const bool flush = have & !is_m & (match_len > 0);  // update_map (:105-113)
+        const bool range_bad = flush & ((r_before > 0x7ffffff0LL) | (f_before > 0x7ffffff0LL) | (fs < 0));
+        bad = bad | range_bad;
+        const bool ev = flush & !range_bad;
+        const long long k0 = rs, v0 = fs, k1 = r_before;
+        // the previous flush: inside the step, or the carried one
+        const int fl_lane = ev ? lane : -1;
+        const int fl_inc = wv::scan_max(fl_lane);
+        const int prev_fl = wv::shfl_up1(fl_inc, -1);
+        const long long pk_l = wave_bcast64(k1, prev_fl < 0 ? 0 : prev_fl);
+        const long long prev_key = prev_fl < 0 ? last_key : pk_l;
+        const bool merge = ev & (prev_key >= 0) & (prev_key == k0);
+        const int add = ev ? (merge ? 1 : 2) : 0;
+        const int inc = wv::scan_add(add);
+        const int at = cnt + inc - add;                    // first entry of this flush
+        if (out && ev) {
+            if (!merge) {
+                out[at].key = (int)k0;
+                out[at].val = (int)v0;
+            }
+            out[at + add - 1].key = (int)k1;
+            out[at + add - 1].val = NONE32;
+        }
+        wv::sync();  // (the None of a flush is written before the next flush of the step replaces it)
+        if (out && merge) out[at - 1].val = (int)v0;
+        // carry
+        const int last_nm = wv::bcast_last(nm_inc), last_fl = wv::bcast_last(fl_inc);
+        const long long tr = wave_bcast64(r_after, 63), tf = wave_bcast64(f_after, 63);
+        const long long nr = wave_bcast64(r_after, last_nm < 0 ? 0 : last_nm), nf = wave_bcast64(f_after, last_nm < 0 ? 0 : last_nm);
+        run_read = last_nm < 0 ? run_read : nr;
+        run_ref = last_nm < 0 ? run_ref : nf;
+        const long long lk = wave_bcast64(k1, last_fl < 0 ? 0 : last_fl);
+        last_key = last_fl < 0 ? last_key : lk;
+        read_base = tr;
+        ref_base = tf;
+        cnt += wv::bcast_last(inc);
+    }
+    return wv::ballot(bad) != 0ull ? -1 : cnt;
 }
 
 // Upper bound of the elements an item needs in any stage: pieces <= ops + blocks, raw lifted ops <= pieces + one jump

@@ -447,7 +447,9 @@ PLO_DEV void win_flush(LaneWin &w, bool on, int end) {
 // an L2 round trip in every iteration of every group.  Items whose window lies outside the staged range keep the global loads.
 constexpr int LANE_KVS = 128;                  // staged entries per wave
 constexpr int LANE_KVS_DWORDS = 2 * LANE_KVS;  // behind the wave's slice (lds + capw) / windows (lds + 64 * LANE_WIN_DWORDS)
-template <bool SP, bool WIN = false>
+// NOSHIFT: an instantiation for groups of the class without the shift stage (forward-mapped contig segments), compiled without that
+// stage's code and state -- lanes that would need it are handed to the retry list (the class order keeps them away).
+template <bool SP, bool WIN = false, bool NOSHIFT = false>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
                        uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre,
                        uint32_t *greg = nullptr, uint32_t *kvs = nullptr) {
@@ -495,6 +497,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         const bool contig_fwd = (fl & ITF_CONTIG_FWD) != 0;
         do_shift = (stages & PLO_STAGE_LSHIFT) && (!(stages & PLO_STAGE_STRAND) || !contig_fwd);
     }
+    const bool need_shift = do_shift;
+    if constexpr (NOSHIFT) do_shift = false;
     // The item's region (enumerate.hpp lane_region_dwords): its ops as LOAD stores them -- match runs merged when the next stage
     // merges them anyway -- behind a gap for what the liftover may add.
     const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);
@@ -522,7 +526,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
     {
-        const bool defer = has && W > (WIN ? fixed_stride - LANE_REGION_PAD : capw);
+        const bool defer = has && (W > (WIN ? fixed_stride - LANE_REGION_PAD : capw) || (NOSHIFT && need_shift));
         const unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int slot = 0;
@@ -727,7 +731,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         // The emission of a cluster (M I D, :132-147) needs its homology; the probe is sent when the cluster ends and the cluster
         // stays `pend`ing -- match bases that follow collect in `msince` -- until the lane's next event: its probe's HBM round trip
         // runs under the scan in between.
-        if (wv::ballot(shift_on) != 0ull) {
+        if constexpr (!NOSHIFT) if (wv::ballot(shift_on) != 0ull) {
             const uint8_t *const sref = (const uint8_t *)(uintptr_t)shift_ref;
             LaneOut o;
             wr_open(o, gap);
@@ -1160,9 +1164,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.  k_chunk_sort's windows of 128 items
 // are what survived of it.  Also measured and dropped: the groups dealt out by atomic queues, one per XCD, instead of the fixed
 // slots below -- 1.30 ms either way on wgs30x, the waves' loads are even enough, and a small batch pays for the atomics.)
-template <bool SP>
+// `base`: class-order position of the first item (0; a launch over one class only starts at that class)
+template <bool SP, bool NOSHIFT = false>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
-                                   uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx) {
+                                   uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx, uint32_t base = 0) {
     const uint32_t lane = (uint32_t)wv::lane();
     // groups: cut by LDS budget (k_chunk_sort's list, wk.lane_groups) or fixed: `gs` items each from the start of either class
     const bool listed = wk.lane_groups != nullptr;
@@ -1190,6 +1195,8 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
                 lo = n0 + idx * gs;
                 hi = lo + gs < n0 + n1 ? lo + gs : n0 + n1;
             }
+            lo += base;
+            hi += base;
         }
     };
     // round j: wave w takes group j * stride + (w + j) % stride -- the waves rotate through the slots from round to round, so that
@@ -1212,7 +1219,7 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
         if (tn < n_groups) g_next = lo1 + lane < hi1 ? wk.perm[lo1 + lane] : 0u;
         if (tnn < n_groups) group(tnn, lo2, hi2);
         if (t < n_groups) {
-            lane_tile<SP>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
+            lane_tile<SP, false, NOSHIFT>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
             wv::sync();
         }
     }

@@ -515,6 +515,19 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
 // the device comp_base (lift_core.hpp), for an exhaustive comparison with the oracle
 extern "C" int emu_comp_base(int b) { return plo::comp_base(b); }
 
+// build_segment_map_wave (k_map_build's wave per contig segment) under the emulator, and the sequential build_segment_map beside it
+extern "C" int emu_map_build(const uint32_t *cigar, uint32_t n, long long ref_pos, int wave, plo::KV *out, unsigned order_seed) {
+    if (!wave) return plo::build_segment_map(cigar, n, ref_pos, out);
+    int cnt = 0;
+    wv::EmuWave w;
+    w.order_seed = order_seed;
+    w.run([&]() {
+        int c = plo::build_segment_map_wave(cigar, n, ref_pos, out);
+        if (wv::lane() == 0) cnt = c;
+    });
+    return cnt;
+}
+
 
 // SA tag segments: finish_core.hpp's sa_item_len / sa_item_emit executed on the host.  `lift` and the finish arrays are host
 // copies; text/off are malloc'ed and released by emu_sa_free.

@@ -298,3 +298,49 @@ def test_streaming_kernel_indel_dense_items(oracle, case):
         assert rc == 0 and cnt[23] == 0  # (every item is heavy: all of them took the streaming kernel)
         assert got.canonical() == ref, f"rings {mode}, {per} items per team, order seed {oseed}"
         assert cnt[7] <= (0 if mode == 1 and case < 2 else got.n_items // 10)  # items handed to the retry list
+
+
+def test_block_map_built_by_a_wave_equals_the_sequential_builder():
+    """k_map_build's wave per contig segment (build_segment_map_wave, enumerate.hpp: scans over 64 ops per step) against the sequential
+    build_segment_map -- the restatement of get_read_segment_to_ref_pos_tree_map (lib/rust-vc-utils/src/bam_utils/read_to_ref_map.rs:101-137)
+    that tests/test_gpu_parity.py pins to the oracle's builder: random contig->reference CIGARs with every op code, zero-length ops,
+    deletions right behind a block (the overwritten None, :111-119), runs that straddle the 64-op steps, empty and all-match CIGARs,
+    invalid op codes and positions beyond the 31-bit range (both must refuse)."""
+    import ctypes as C
+
+    L = emu_lib.lib()
+
+    class KV(C.Structure):
+        _fields_ = [("key", C.c_int), ("val", C.c_int)]
+
+    L.emu_map_build.restype = C.c_int
+    L.emu_map_build.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_longlong, C.c_int, C.POINTER(KV), C.c_uint]
+    rng = np.random.default_rng(77)
+
+    def both(cig, pos, seed=0):
+        a = np.ascontiguousarray(cig, dtype=np.uint32)
+        p = a.ctypes.data_as(C.POINTER(C.c_uint32))
+        res = []
+        for wave in (0, 1):
+            out = (KV * (2 * len(a) + 4))()
+            n = L.emu_map_build(p, len(a), pos, wave, out, seed)
+            res.append((n, [(out[i].key, out[i].val) for i in range(max(0, n))]))
+        return res
+
+    cases = [([], 5), ([(100 << 4) | 0], 7), ([(10 << 4) | 4, (50 << 4) | 7, (3 << 4) | 2, (20 << 4) | 8, (5 << 4) | 1, (9 << 4) | 0], 1000),
+             ([(5 << 4) | 0, (0 << 4) | 2, (5 << 4) | 0], 3), ([(5 << 4) | 0, (4 << 4) | 2, (0 << 4) | 1, (5 << 4) | 7], 3),
+             ([(7 << 4) | 9], 1), ([(0x7ffffff << 4) | 0] * 20 + [(1 << 4) | 2], 0), ([(5 << 4) | 2, (6 << 4) | 0], -3)]
+    for n_ops in (1, 2, 63, 64, 65, 127, 128, 129, 500, 3000):
+        for _ in range(6):
+            mode = rng.integers(0, 3)
+            types = rng.choice([0, 7, 8, 1, 2, 3, 4, 5, 6] if mode == 0 else ([7, 8, 2] if mode == 1 else [0, 2, 1]), size=n_ops,
+                               p=None if mode else [.3, .2, .1, .1, .1, .05, .05, .05, .05])
+            lens = rng.integers(0, 4 if mode == 2 else 60, size=n_ops)
+            cases.append((list((lens.astype(np.uint64) << 4 | types.astype(np.uint64)).astype(np.uint32)), int(rng.integers(0, 10_000))))
+    n_merge = 0
+    for k, (cig, pos) in enumerate(cases):
+        seq, wave = both(cig, pos, seed=(k * 13 if k % 3 == 0 else 0))
+        assert seq == wave, f"case {k}: {cig[:20]} at {pos}"
+        keys = [e[0] for e in seq[1]]
+        n_merge += sum(1 for a, b in zip(seq[1], seq[1][1:]) if a[1] != -(2 ** 31) and b[1] != -(2 ** 31))
+    assert n_merge > 20  # (deletions right behind a block: consecutive Some entries -- the merged form -- were exercised)

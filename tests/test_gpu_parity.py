@@ -138,10 +138,14 @@ def test_synthetic_indel_dense_large_item_kernels(oracle, monkeypatch, mid):
     eng_ix.close()
 
 
+@pytest.mark.parametrize("variant", list(HEAVY_VARIANTS))
 @pytest.mark.parametrize("per", ["64", "7"])
-def test_synthetic_indel_dense_heavy_items_lane_per_item(oracle, monkeypatch, per):
-    """heavy items through the lane-per-item code (k_lift_lanes_g): regions in wave-private global scratch behind per-lane LDS
-    windows; every stage subset that changes what the windows carry"""
+def test_synthetic_indel_dense_heavy_items_lane_per_item(oracle, monkeypatch, per, variant):
+    """heavy items through the lane-per-item code, every instantiation (k_lift_lanes_g: regions in wave-private global scratch behind
+    per-lane LDS windows, two and three waves per SIMD; k_lift_stream: teams of waves, the all-stages set only); every stage subset that
+    changes what the windows carry"""
+    for k, v in HEAVY_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
     monkeypatch.setenv("PLO_LANE_HEAVY_PER", per)
     monkeypatch.setenv("PLO_LANE_MAX_W", "150")
@@ -161,6 +165,7 @@ def test_synthetic_indel_dense_heavy_items_lane_per_item(oracle, monkeypatch, pe
 def test_heavy_items_longer_than_their_region_are_handed_on(oracle, monkeypatch):
     """k_lift_lanes_g with regions smaller than the longer items of the batch (what the engine does when an outlier would make the
     regions of all resident lanes exceed 8 GB): those items go to the retry list and through the wave-cooperative kernels"""
+    monkeypatch.setenv("PLO_LANE_STREAM", "0")  # (the streaming kernel has no regions)
     monkeypatch.setenv("PLO_LANE_HEAVY_MIN", "0")
     monkeypatch.setenv("PLO_LANE_HEAVY_STRIDE", "640")
     monkeypatch.setenv("PLO_LANE_MAX_W", "150")
