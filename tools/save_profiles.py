@@ -103,10 +103,19 @@ if os.path.exists(f"{src}/stress_kernel_stats.csv"):
         f.write(f"# rocprofv3 --pmc <counters> --kernel-include-regex {sk} --output-format csv -- python3 bench.py --workload stress --reads 100000 --steps 3 --warmup 1 --e2e-reads 0 --no-cpu-baseline\n")
         f.write(f"# one pass per counter group; value = mean over the launches of {sk}; FETCH_SIZE / WRITE_SIZE in KiB\n")
         f.write("counter,mean_per_launch,launches\n")
-        for p in ["stress_pmc_fetch", "stress_pmc_write", "stress_pmc_sq1"]:
-            for l in open(f"{src}/{p}.csv"):
-                if "," in l:
-                    f.write(l)
+        for p in ["stress_pmc_fetch", "stress_pmc_write", "stress_pmc_sq1", "stress_pmc_sq2"]:
+            if os.path.exists(f"{src}/{p}.csv"):
+                for l in open(f"{src}/{p}.csv"):
+                    if "," in l:
+                        f.write(l)
+        if os.path.exists(f"{src}/stress_g_pmc_fetch.csv"):
+            f.write("# the same workload through k_lift_lanes_g (PLO_LANE_STREAM=0): FETCH_SIZE / WRITE_SIZE per launch\n")
+            for p in ["stress_g_pmc_fetch", "stress_g_pmc_write"]:
+                for l in open(f"{src}/{p}.csv"):
+                    if "," in l:
+                        f.write("k_lift_lanes_g:" + l)
+    if os.path.exists(f"{src}/stress_g_bench.json"):
+        shutil.copy(f"{src}/stress_g_bench.json", f"{pre}_bench_lanes_g.json")
     sb = json.load(open(f"{src}/stress_bench.json"))
     h["stress"] = {sb["roofline"]["kernel"]: int((fetch_factor * sfe + swr) * 1024), "_fetch_size_kib": sfe, "_write_size_kib": swr, "_fetch_factor": fetch_factor,
                    "_source": os.path.basename(f"{pre}_pmc_summary.csv"), "_algorithmic_bytes": sb["roofline"]["algorithmic_bytes_per_launch"],
