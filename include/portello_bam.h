@@ -50,6 +50,13 @@ plo_status plo_bam_open(const char *path, int n_threads, plo_bam_reader **out);
 /* the same with the choice of plo_bam_set_device_inflate made before the first block is read: device >= 0 that GPU, -1 the host,
    -2 as plo_bam_open (host unless the environment says PLO_BGZF_DEVICE=1) */
 plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_bam_reader **out);
+/* one PART of the file for one rank / worker (several GPUs: INTEGRATION.md section 6): the compressed file is cut at size x part /
+   n_parts; the part owns the records whose first byte lies in a BGZF block that starts inside its stretch (it reads on past the
+   stretch's end to finish the last one), found without an index: the first block by its header chain, the first record as the
+   offset from which eight records in a row parse.  The parts' record sets are disjoint and their union is the file's.  `device` as
+   in plo_bam_open_device.  Replaces the per-worker IndexedReader fetch of src/worker_thread_data.rs:21-30,
+   src/read_alignment_scanner.rs:382. */
+plo_status plo_bam_open_range(const char *path, int n_threads, int device, uint32_t part, uint32_t n_parts, plo_bam_reader **out);
 void plo_bam_close(plo_bam_reader *r);
 /* header text and the @SQ list as stored in the BAM header (ChromList::from_bam_header, chrom_list.rs:27-37).
    The pointers stay valid until plo_bam_close. */
@@ -77,6 +84,8 @@ void plo_bam_window_free(plo_bam_window *w);
 uint32_t plo_bam_window_n_records(const plo_bam_window *w);
 /* 1: the reader reached the end of the file while collecting this window (nothing follows it), 0: more windows follow */
 int plo_bam_window_eof(const plo_bam_window *w);
+/* primary record i of the window as it stands in the BAM stream: block_size word + block_size bytes (valid until plo_bam_window_free) */
+plo_status plo_bam_window_record(const plo_bam_window *w, uint32_t i, const uint8_t **bytes, uint32_t *n_bytes);
 /* unmapped records of the window's stretch of the file as BAM record bytes (block_size prefixed), ready for
    plo_bam_write to the "unassembled" output */
 void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records);

@@ -54,6 +54,10 @@ def lib():
         L.plo_bam_window_batch_sparse_strand.argtypes = [vp, C.c_uint32, C.POINTER(abi.PloIndexDesc), C.POINTER(abi.PloBatchIn), C.POINTER(abi.PloFinishIn)]
         L.plo_bam_open_device.restype = C.c_int
         L.plo_bam_open_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        L.plo_bam_window_record.restype = C.c_int
+        L.plo_bam_window_record.argtypes = [vp, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32)]
+        L.plo_bam_open_range.restype = C.c_int
+        L.plo_bam_open_range.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.plo_bam_set_device_inflate.restype = None
         L.plo_bam_set_device_inflate.argtypes = [vp, C.c_int]
         L.plo_bam_window_batch_sparse.restype = C.c_int
@@ -125,6 +129,12 @@ class Window:
     def eof(self) -> bool:
         """the reader reached the end of the file while collecting this window: nothing follows it"""
         return bool(lib().plo_bam_window_eof(self.handle))
+
+    def record_bytes(self, i: int) -> bytes:
+        """primary record i as it stands in the BAM stream (block_size word included)"""
+        p, n = C.POINTER(C.c_uint8)(), C.c_uint32()
+        _check(lib().plo_bam_window_record(self.handle, i, C.byref(p), C.byref(n)), "plo_bam_window_record")
+        return C.string_at(p, n.value)
 
     def unmapped_bytes(self) -> Tuple[bytes, int]:
         p, n, k = C.POINTER(C.c_uint8)(), C.c_uint64(), C.c_uint32()
@@ -207,12 +217,17 @@ class Window:
 
 
 class BamReader:
-    def __init__(self, path: str, n_threads: int = 4, device_inflate: Optional[int] = None):
+    def __init__(self, path: str, n_threads: int = 4, device_inflate: Optional[int] = None, part: Optional[int] = None, n_parts: int = 1):
         """device_inflate: HIP device index = BGZF blocks are inflated on that GPU (plo_bam_set_device_inflate), -1 / False = on the
-        host; None = the environment (PLO_BGZF_DEVICE) decides, host inflate by default"""
+        host; None = the environment (PLO_BGZF_DEVICE) decides, host inflate by default.
+        part / n_parts: this reader's share of the file (plo_bam_open_range: a split by compressed offset, no index needed) -- one rank's
+        or worker's records when several GPUs lift one BAM"""
         h = C.c_void_p()
         dev = -2 if device_inflate is None else (-1 if device_inflate is False else int(device_inflate))
-        _check(lib().plo_bam_open_device(path.encode(), n_threads, dev, C.byref(h)), f"plo_bam_open({path})")
+        if part is None:
+            _check(lib().plo_bam_open_device(path.encode(), n_threads, dev, C.byref(h)), f"plo_bam_open({path})")
+        else:
+            _check(lib().plo_bam_open_range(path.encode(), n_threads, dev, int(part), int(n_parts), C.byref(h)), f"plo_bam_open_range({path}, {part}/{n_parts})")
         self.handle = h
         text, lt, n = C.c_char_p(), C.c_uint32(), C.c_uint32()
         names, lens = C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint32)()

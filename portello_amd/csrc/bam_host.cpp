@@ -95,6 +95,114 @@ plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_
     return PLO_OK;
 }
 
+// One PART of a BAM file for one rank / worker (the reference gives every worker an IndexedReader and fetches its region,
+// src/worker_thread_data.rs:21-30, src/read_alignment_scanner.rs:382; here the split needs no index): the compressed file is cut at
+// size x part / n_parts, a part owns the records whose first byte lies in a BGZF block that STARTS inside its stretch, and reads on
+// past its end to finish the last of them.  A part behind the first finds its first block (BgzfIn::seek_block) and then its first
+// record: the offset in the inflated stream from which a chain of records parses -- sane block_size, reference ids inside the header's
+// list, a NUL-terminated printable name, CIGAR op codes, fixed fields + name + CIGAR + bases + qualities within block_size -- eight
+// times in a row (or to the end of the data).
+static bool plausible_record(const uint8_t *p, size_t left, uint32_t n_ref, size_t *len) {
+    if (left < 4 + 32) return false;
+    const uint32_t bs = rd32(p);
+    if (bs < 32 + 2 || bs > (1u << 28) || 4 + (size_t)bs > left) return false;
+    Rec rec{p + 4, bs};
+    const int32_t tid = rec.tid(), mtid = (int32_t)rd32(p + 4 + 20);
+    if (tid < -1 || tid >= (int32_t)n_ref || mtid < -1 || mtid >= (int32_t)n_ref) return false;
+    if ((int32_t)rd32(p + 4 + 4) < -1 || (int32_t)rd32(p + 4 + 24) < -1) return false;
+    const uint32_t l_name = rec.l_qname();
+    if (l_name < 2 || !rec.layout_ok()) return false;
+    const uint8_t *name = p + 4 + 32;
+    if (name[l_name - 1] != 0) return false;
+    for (uint32_t i = 0; i + 1 < l_name; ++i)
+        if (name[i] < 33 || name[i] > 126) return false;
+    const uint32_t n_cig = rec.n_cigar();
+    const uint8_t *cg = name + l_name;
+    for (uint32_t i = 0; i < n_cig; ++i)
+        if ((rd32(cg + 4 * i) & 15u) > 8u) return false;
+    *len = 4 + (size_t)bs;
+    return true;
+}
+
+plo_status plo_bam_open_range(const char *path, int n_threads, int device, uint32_t part, uint32_t n_parts, plo_bam_reader **out) {
+    if (!out || !n_parts || part >= n_parts) return PLO_ERR_INVALID_ARG;
+    plo_status st = plo_bam_open_device(path, n_threads, device, out);
+    if (st != PLO_OK) return st;
+    plo_bam_reader *r = *out;
+    BgzfIn &in = r->in;
+    auto bail = [&](plo_status s) {
+        plo_bam_close(r);
+        *out = nullptr;
+        return s;
+    };
+    const size_t lo = (size_t)((unsigned __int128)in.size * part / n_parts), hi = (size_t)((unsigned __int128)in.size * (part + 1) / n_parts);
+    // Every BGZF block has one owner: the part whose stretch [lo, hi) holds the block's first byte.  The records start in the block that
+    // holds the first byte behind the header; parts in front of that block's owner have nothing, the owner starts there, the parts behind
+    // it look for their first block and their first record.
+    in.ranged = true;
+    in.range_end = part + 1 == n_parts ? (size_t)-1 : hi;
+    size_t hdr_bytes = 12 + r->text.size();
+    for (size_t i = 0; i < r->names.size(); ++i) hdr_bytes += 8 + r->names[i].size() + 1;
+    size_t c = 0, u = 0;  // walk the blocks from the file's start until the inflated offset passes the header
+    while (c < in.size) {
+        const uint32_t bsz = BgzfIn::bgzf_block_at(in.map + c, in.size - c);
+        if (!bsz) return bail(fail(PLO_ERR_IO, "not a BGZF block"));
+        const uint32_t ulen = rd32(in.map + c + bsz - 4);
+        if (u + ulen > hdr_bytes) break;
+        u += ulen;
+        c += bsz;
+    }
+    const size_t first_rec_block = c, skip = hdr_bytes - u;
+    if (first_rec_block >= in.size || hi <= first_rec_block) {  // no records at all, or this part lies in front of them
+        in.restart_at(in.size);
+        return PLO_OK;
+    }
+    if (lo <= first_rec_block) {  // the owner of the first records' block
+        in.restart_at(first_rec_block);
+        if ((st = in.fill(skip + 4)) != PLO_OK) return bail(st);
+        in.bpos += std::min(skip, in.avail());
+        return PLO_OK;
+    }
+    const size_t blk = in.seek_block(lo);
+    in.restart_at(blk);
+    if (blk >= in.size || blk >= hi) {  // no block starts inside this part's stretch
+        in.restart_at(in.size);
+        return PLO_OK;
+    }
+    // the first record: a chain of eight plausible records (or plausible records to the end of what there is)
+    const uint32_t n_ref = (uint32_t)r->names.size();
+    size_t have = 0;
+    for (size_t want = (size_t)4 << 20;; want *= 4) {
+        if ((st = in.fill(want)) != PLO_OK) return bail(st);
+        have = in.avail();
+        const uint8_t *b = in.buf.data() + in.bpos;
+        for (size_t p = 0; p + 36 <= have; ++p) {
+            size_t q = p, len = 0;
+            int ok = 0;
+            bool ran_out = false;
+            while (ok < 8) {
+                if (q == have && in.eof) break;
+                if (!plausible_record(b + q, have - q, n_ref, &len)) {
+                    ran_out = q + 36 > have || (q + 4 <= have && 4 + (size_t)rd32(b + q) > have - q && rd32(b + q) <= (1u << 28) && rd32(b + q) >= 34);
+                    break;
+                }
+                q += len;
+                ++ok;
+            }
+            if (ok == 8 || (ok > 0 && q == have && in.eof)) {
+                // records that start in a block of the NEXT part's stretch are not this part's: read_window checks every record
+                in.bpos += p;
+                return PLO_OK;
+            }
+            if (ran_out && !in.eof && ok > 0) break;  // a chain cut by the end of the buffered data: buffer more
+        }
+        if (in.eof || want > ((size_t)1 << 32)) break;
+    }
+    // no record boundary in the rest of the file: the stretch holds the tail of one record only
+    in.restart_at(in.size);
+    return PLO_OK;
+}
+
 void plo_bam_close(plo_bam_reader *r) {
     if (!r) return;
     r->in.close();
@@ -147,6 +255,10 @@ plo_status plo_bam_read_window(plo_bam_reader *r, uint32_t max_records, plo_bam_
         }
         if (r->in.avail() < at + 4) {
             st = fail(PLO_ERR_IO, "truncated BAM record");
+            break;
+        }
+        if (r->in.ranged && r->in.block_file_off(at) >= r->in.range_end) {  // the record starts in the next part's stretch
+            w->eof = true;
             break;
         }
         uint32_t bs = rd32(r->in.buf.data() + r->in.bpos + at);
@@ -206,6 +318,13 @@ void plo_bam_set_device_inflate(plo_bam_reader *r, int device) {
 void plo_bam_window_free(plo_bam_window *w) { delete w; }
 uint32_t plo_bam_window_n_records(const plo_bam_window *w) { return w ? w->n_records() : 0; }
 int plo_bam_window_eof(const plo_bam_window *w) { return (w && w->eof) ? 1 : 0; }
+plo_status plo_bam_window_record(const plo_bam_window *w, uint32_t i, const uint8_t **bytes, uint32_t *n_bytes) {
+    if (!w || !bytes || !n_bytes || i >= w->n_records()) return PLO_ERR_INVALID_ARG;
+    const uint8_t *p = w->raw.data() + w->rec_at[i];
+    *bytes = p;
+    *n_bytes = 4 + rd32(p);
+    return PLO_OK;
+}
 void plo_bam_window_unmapped(const plo_bam_window *w, const uint8_t **bytes, uint64_t *n_bytes, uint32_t *n_records) {
     if (bytes) *bytes = w ? w->unmapped.data() : nullptr;
     if (n_bytes) *n_bytes = w ? w->unmapped.size() : 0;

@@ -240,6 +240,62 @@ struct BgzfIn {
     int dev_id = 0;  // HIP device of the device inflate
     int device = -1;  // -1 undecided (environment), -2 undecided (requested), 0 host inflate, 1 blocks are inflated on the GPU
     static constexpr size_t CHUNK = 256u << 20;
+    // A PART of the file (plo_bam_open_range): records whose first byte lies in a BGZF block that starts in [range_lo, range_end) of the
+    // compressed file.  `blkmap`: where in `buf` every block of the current contents starts and where that block starts in the file.
+    size_t range_end = (size_t)-1;
+    bool ranged = false;
+    std::vector<std::pair<size_t, size_t>> blkmap;  // (offset in buf, offset of the block in the file), ascending
+    // file offset of the BGZF block that holds byte `at` of the unconsumed stream (ranged readers only)
+    size_t block_file_off(size_t at) const {
+        const size_t u = bpos + at;
+        size_t lo = 0, hi = blkmap.size();
+        while (lo + 1 < hi) {
+            const size_t m = (lo + hi) / 2;
+            if (blkmap[m].first <= u) lo = m;
+            else hi = m;
+        }
+        return blkmap.empty() ? 0 : blkmap[lo].second;
+    }
+    // a BGZF block header at `h` (at least 18 readable bytes)?  returns the block's size or 0
+    static uint32_t bgzf_block_at(const uint8_t *h, size_t left) {
+        if (left < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+        const uint32_t xlen = rd16(h + 10);
+        if (12 + (size_t)xlen > left) return 0;
+        uint32_t bsize = 0;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *e = h + 12 + x;
+            const uint32_t slen = rd16(e + 2);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint32_t)rd16(e + 4) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > left) return 0;
+        return bsize;
+    }
+    // The first BGZF block that starts at or after file offset `from`: the magic and a BC field are not proof (compressed data can hold
+    // the same bytes), a chain of three blocks that follow each other -- or end the file -- is.  Returns `size` when there is none.
+    size_t seek_block(size_t from) const {
+        for (size_t p = from; p + 28 <= size; ++p) {
+            if (map[p] != 0x1f || map[p + 1] != 0x8b) continue;
+            size_t q = p;
+            int ok = 0;
+            while (ok < 3 && q < size) {
+                const uint32_t b = bgzf_block_at(map + q, size - q);
+                if (!b) break;
+                q += b;
+                ++ok;
+            }
+            if (ok == 3 || (ok > 0 && q == size)) return p;
+        }
+        return size;
+    }
+    // continue the stream at the block that starts at file offset `at` (everything buffered is dropped)
+    void restart_at(size_t at) {
+        buf.resize(0);
+        bpos = 0;
+        blkmap.clear();
+        cpos = at;
+        eof = cpos >= size;
+    }
     struct DevBlk {  // engine.hip's BgzfBlk
         unsigned long long coff, uoff;
         uint32_t clen, ulen;
@@ -279,6 +335,12 @@ struct BgzfIn {
         if (bpos) {
             memmove(buf.data(), buf.data() + bpos, buf.size() - bpos);
             buf.resize(buf.size() - bpos);
+            if (ranged) {  // the blocks' places move with the bytes; blocks consumed whole are forgotten (the one that holds byte 0 stays)
+                size_t keep = 0;
+                while (keep + 1 < blkmap.size() && blkmap[keep + 1].first <= bpos) ++keep;
+                blkmap.erase(blkmap.begin(), blkmap.begin() + (long)keep);
+                for (auto &e : blkmap) e.first = e.first > bpos ? e.first - bpos : 0;
+            }
             bpos = 0;
         }
         const size_t cpos0 = cpos;
@@ -329,6 +391,7 @@ struct BgzfIn {
             b.ulen = rd32(h + bsize - 4);
             b.uoff = u;
             if (b.ulen > 65536) return fail(PLO_ERR_IO, "BGZF block larger than 64 KiB");
+            if (ranged && b.ulen) blkmap.emplace_back(u, cpos);
             u += b.ulen;
             cpos += bsize;
             blks.push_back(b);

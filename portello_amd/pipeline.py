@@ -71,7 +71,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
                    cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
                    device_finish: bool = False, read_threads: Optional[int] = None, build_threads: Optional[int] = None,
-                   write_threads: Optional[int] = None, ramp: bool = True) -> PipelineStats:  # noqa: E501
+                   write_threads: Optional[int] = None, ramp: bool = True, part: Optional[int] = None, n_parts: int = 1) -> PipelineStats:  # noqa: E501
     """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
     (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
     plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
@@ -79,7 +79,10 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     sparse_margin: the windows' read bases go to the device as PLO_SEQ_BAM4_SPARSE (granules within that many bases of an indel;
     the complete bases stay in the window's records for the engine's second look); None = dense bases.  device_inflate: the BGZF
     blocks of the input are inflated on the GPU (leaves the host cores to record assembly and output; falls back to the host without
-    a device), None = as the environment says"""
+    a device), None = as the environment says.
+    part / n_parts: this process's share of the input (plo_bam_open_range: a split by compressed offset) -- with several GPUs every rank
+    runs the pipeline over its part and writes its own output shard (the reference's output order is unspecified: the shards'
+    concatenation is a valid result)"""
     # threads inside the stages (inflate / batch construction, record assembly per worker, BGZF output).  The stages run at the same
     # time: half of io_threads each by default (tools/bench_e2e_threads.py on the 16-core GPU box, best of three runs: 80.6-81.4 k reads/s
     # with 8 / 4-8 / 6-8 threads against 77.1 k with 16 each; the input and output stages are bound by the page cache either way)
@@ -89,7 +92,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     write_threads = write_threads or half
     st = PipelineStats()
     ixd = index_data.to_desc()
-    rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)))
+    rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)),
+                       part=part, n_parts=n_parts)
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
     wr = bam.BamWriter(out_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level, n_threads=write_threads)

@@ -597,3 +597,44 @@ def test_cpu_pipeline_baseline_writes_the_expected_records(tmp_path):
     assert st["reads"] == w.n_reads and st["windows"] >= 3
     v = expect.verify_lifted_bam(inp, outp, ixd, cn, rn, window=50, every=1, threads=2, unassembled_bam=unp)
     assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st["records_out"], v
+
+
+@pytest.mark.parametrize("level", [1, 0])
+def test_parts_of_a_bam_are_disjoint_and_complete(tmp_path, level):
+    """plo_bam_open_range (missing #4): a BAM cut by compressed offset into n parts, every part finding its first BGZF block and its
+    first record without an index -- the parts' primary records, in part order, are exactly the file's, each once (records that straddle
+    a cut, cuts inside the header, parts without a block of their own, the unmapped tail in the last parts); what the reference does with
+    one IndexedReader per worker (src/worker_thread_data.rs:21-30, src/read_alignment_scanner.rs:382)"""
+    w = synth.generate(synth.config("tiny", n_reads=400, seed=77, split_read_frac=0.3, sorted_reads=True, read_len_mean=3000, read_len_sd=800))
+    path = str(tmp_path / "reads.bam")
+    bamsynth.write_read_bam(w, path, level=level, n_unmapped=40)
+
+    def read_all(**kw):
+        rd = bam.BamReader(path, 2, **kw)
+        recs, unm = [], b""
+        while True:
+            win = rd.read_window(37)
+            if win is None:
+                break
+            recs += [win.record_bytes(i) for i in range(win.n_records)]
+            unm += win.unmapped_bytes()[0]
+            win.close()
+        rd.close()
+        return recs, unm
+
+    whole, whole_unm = read_all()
+    assert len(whole) >= 400 and len(whole_unm) > 0
+    size = os.path.getsize(path)
+    n_blocks = len(bamcheck.bgzf_blocks(path))
+    for n_parts in (1, 2, 3, 7, 16, n_blocks + 5, 4 * n_blocks):
+        got, got_unm, per_part = [], b"", []
+        for part in range(n_parts):
+            r, u = read_all(part=part, n_parts=n_parts)
+            got += r
+            got_unm += u
+            per_part.append(len(r))
+        assert got == whole, f"{n_parts} parts: {per_part}"
+        assert got_unm == whole_unm
+        if n_parts in (2, 3, 7):
+            assert sum(1 for k in per_part if k) == n_parts  # (every part of a few has records of its own)
+    assert size > 0
