@@ -27,7 +27,8 @@ extern "C" uint32_t plo_internal_bgzf_slots(void);  // blocks the device inflate
 extern "C" void plo_internal_bgzf_acquire(void);
 extern "C" void plo_internal_bgzf_release(void);
 extern "C" int plo_internal_bgzf_set_device(int dev);
-extern "C" int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);
+extern "C" int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes,
+                                       const uint32_t *crcs);
 extern "C" int plo_internal_bgzf_wait(int slot);
 extern "C" int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes);  // bam_host.cpp: the message plo_bam_last_error() returns (per thread)
 
@@ -172,6 +173,9 @@ struct RawBuf {
     }
 };
 void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads);
+// n bytes of the file behind `fd` from offset `off` straight into dst (page-locked staging of the device inflate): positional reads, no
+// page faults on a file mapping and no second copy; false when the file ends early
+bool parallel_pread(int fd, uint8_t *dst, size_t off, size_t n, int threads);
 
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -408,23 +412,33 @@ struct BgzfIn {
             if (!dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
             const size_t ng = (blks.size() + dev_slots - 1) / dev_slots;
             std::vector<DevBlk> db[2];
+            std::vector<uint32_t> dcrc[2];
+            // PLO_BGZF_HOST_CRC=1: the CRCs are checked on the host as in round 4 (the device's check is then skipped)
+            const bool host_crc = getenv("PLO_BGZF_HOST_CRC") != nullptr;
             int rc = 0;
             auto begin = [&](size_t g) -> int {
                 const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
                 const size_t c0 = blks[lo].coff, u0 = blks[lo].uoff;
                 std::vector<DevBlk> &d = db[g & 1];
                 d.resize(hi - lo);
-                for (size_t i = lo; i < hi; ++i) d[i - lo] = DevBlk{blks[i].coff - c0, blks[i].uoff - u0, (uint32_t)blks[i].clen, (uint32_t)blks[i].ulen};
+                std::vector<uint32_t> &dc = dcrc[g & 1];
+                dc.resize(hi - lo);
+                for (size_t i = lo; i < hi; ++i) {
+                    d[i - lo] = DevBlk{blks[i].coff - c0, blks[i].uoff - u0, (uint32_t)blks[i].clen, (uint32_t)blks[i].ulen};
+                    dc[i - lo] = blks[i].crc;
+                }
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0, ubytes = blks[hi - 1].uoff + blks[hi - 1].ulen - u0;
                 RawBuf &cs = cstage2[g & 1];
                 cs.pinned = true;
                 if (!cs.resize(cbytes + 16)) return -101;
-                parallel_copy(cs.data(), map + c0, cbytes, threads);
-                return plo_internal_bgzf_begin((int)(g & 1), cs.data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes);
+                // compressed bytes: positional reads straight into the page-locked stage (round 4 copied them out of the file mapping)
+                if (!parallel_pread(fd, cs.data(), c0, cbytes, threads)) parallel_copy(cs.data(), map + c0, cbytes, threads);
+                return plo_internal_bgzf_begin((int)(g & 1), cs.data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
             };
             auto finish = [&](size_t g) -> int {
                 int r = plo_internal_bgzf_wait((int)(g & 1));
                 if (r) return r;
+                if (!host_crc) return 0;  // (k_bgzf_crc has checked every block: a mismatch came back as the group's status)
                 const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
                 parallel_for(hi - lo, threads, [&](size_t i) {
                     const Blk &b = blks[lo + i];
@@ -509,6 +523,24 @@ struct BgzfIn {
     }
 };
 
+bool parallel_pread(int fd, uint8_t *dst, size_t off, size_t n, int threads) {
+    const size_t piece = 4u << 20;
+    const size_t np = (n + piece - 1) / piece;
+    std::atomic<int> bad{0};
+    parallel_for(np, std::min<int>(threads, 16), [&](size_t i) {
+        size_t o = i * piece, left = std::min(piece, n - o);
+        while (left) {
+            const ssize_t k = pread(fd, dst + o, left, (off_t)(off + o));
+            if (k <= 0) {
+                bad = 1;
+                return;
+            }
+            o += (size_t)k;
+            left -= (size_t)k;
+        }
+    });
+    return bad == 0;
+}
 void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int threads) {
     const size_t piece = 4u << 20;
     const size_t np = (n + piece - 1) / piece;

@@ -1106,6 +1106,20 @@ __global__ __launch_bounds__(INF_WAVES * 64) void k_bgzf_inflate(const uint8_t *
     }
 }
 
+// The CRC-32 of every inflated block against the one its BGZF trailer carries (crc32_wave, inflate.hpp: a wave per block), behind
+// k_bgzf_inflate on the same stream: the host then never reads the inflated bytes to check them (round 4: the CRC pass and the copy of the
+// compressed bytes out of the file mapping were 50 of the 63 ms a 470 MB refill took).  status: -10 where the CRC differs.
+__global__ __launch_bounds__(INF_WAVES * 64) void k_bgzf_crc(const uint8_t *out, const BgzfBlk *blks, uint32_t n, const uint32_t *crcs, int *status) {
+    __shared__ uint32_t tab[256];
+    tab[threadIdx.x & 255u] = crc32_table_entry(threadIdx.x & 255u);
+    __syncthreads();
+    for (uint32_t b = blockIdx.x * INF_WAVES + (uint32_t)wv::wave_id(); b < n; b += gridDim.x * INF_WAVES) {
+        const BgzfBlk k = blks[b];
+        const uint32_t c = k.ulen ? crc32_wave(out + k.uoff, k.ulen, tab) : 0u;
+        if (wv::lane() == 0 && k.ulen && status[b] == 0 && c != crcs[b]) status[b] = -10;
+    }
+}
+
 // ---- self-test of the wave primitives (plo_selftest) -------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_selftest(const int *in, int *out) {
     int lane = wv::lane();
@@ -2533,7 +2547,7 @@ void plo_internal_bgzf_release(void) {
     g_inf_prev_dev = -1;
     g_inf_mu.unlock();
 }
-int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
+int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes, const uint32_t *crcs) {
     if (slot < 0 || slot > 1) return -101;
     if (!g_inf_cur) {  // no set_device(): the calling thread's current device
         int dev = 0;
@@ -2553,20 +2567,26 @@ int plo_internal_bgzf_begin(int slot, const uint8_t *comp, size_t comp_bytes, co
     q.n = n;
     q.busy = false;
     if (!n) return 0;
-    if (q.d_comp.ensure(comp_bytes + 16) != hipSuccess || q.d_out.ensure(out_bytes + 16) != hipSuccess || q.d_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess ||
-        q.d_st.ensure((size_t)n * 4) != hipSuccess || q.h_blk.ensure((size_t)n * sizeof(BgzfBlk)) != hipSuccess || q.h_st.ensure((size_t)n * 4) != hipSuccess)
+    // (the blocks' descriptors and, behind them, their expected CRCs travel as one array)
+    const size_t blk_bytes = (size_t)n * sizeof(BgzfBlk), crc_bytes = crcs ? (size_t)n * 4 : 0;
+    if (q.d_comp.ensure(comp_bytes + 16) != hipSuccess || q.d_out.ensure(out_bytes + 16) != hipSuccess || q.d_blk.ensure(blk_bytes + crc_bytes) != hipSuccess ||
+        q.d_st.ensure((size_t)n * 4) != hipSuccess || q.h_blk.ensure(blk_bytes + crc_bytes) != hipSuccess || q.h_st.ensure((size_t)n * 4) != hipSuccess)
         return -101;
     const bool dbg = getenv("PLO_DEBUG_INFLATE") != nullptr;
     if (dbg && !q.ev[0])
         for (auto &e : q.ev) (void)hipEventCreate(&e);
-    memcpy(q.h_blk.p, blks, (size_t)n * sizeof(BgzfBlk));  // (the caller's array may go away before the copy runs)
+    memcpy(q.h_blk.p, blks, blk_bytes);  // (the caller's arrays may go away before the copy runs)
+    if (crcs) memcpy((uint8_t *)q.h_blk.p + blk_bytes, crcs, crc_bytes);
     hipStream_t st = q.st;
     if (dbg) (void)hipEventRecord(q.ev[0], st);
     if (hipMemcpyAsync(q.d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
-    if (hipMemcpyAsync(q.d_blk.p, q.h_blk.p, (size_t)n * sizeof(BgzfBlk), hipMemcpyHostToDevice, st) != hipSuccess) return -102;
+    if (hipMemcpyAsync(q.d_blk.p, q.h_blk.p, blk_bytes + crc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -102;
     if (dbg) (void)hipEventRecord(q.ev[1], st);
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(std::min<uint32_t>((n + INF_WAVES - 1) / INF_WAVES, bgzf_workgroups())), dim3(INF_WAVES * 64), 0, st,
                        (const uint8_t *)q.d_comp.p, (const BgzfBlk *)q.d_blk.p, n, (uint8_t *)q.d_out.p, (int *)q.d_st.p);
+    if (crcs)
+        hipLaunchKernelGGL(k_bgzf_crc, dim3(std::min<uint32_t>((n + INF_WAVES - 1) / INF_WAVES, (uint32_t)bgzf_workgroups() * 4u)), dim3(INF_WAVES * 64), 0, st,
+                           (const uint8_t *)q.d_out.p, (const BgzfBlk *)q.d_blk.p, n, (const uint32_t *)((const uint8_t *)q.d_blk.p + blk_bytes), (int *)q.d_st.p);
     if (hipGetLastError() != hipSuccess) return -103;
     if (dbg) (void)hipEventRecord(q.ev[2], st);
     if (hipMemcpyAsync(out, q.d_out.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -104;
@@ -2599,7 +2619,7 @@ int plo_internal_bgzf_wait(int slot) {
 int plo_internal_bgzf_inflate(const uint8_t *comp, size_t comp_bytes, const void *blks, uint32_t n, uint8_t *out, size_t out_bytes) {
     std::lock_guard<std::mutex> g(g_inf_mu);
     g_inf_cur = nullptr;
-    int rc = plo_internal_bgzf_begin(0, comp, comp_bytes, blks, n, out, out_bytes);
+    int rc = plo_internal_bgzf_begin(0, comp, comp_bytes, blks, n, out, out_bytes, nullptr);
     rc = rc ? rc : plo_internal_bgzf_wait(0);
     g_inf_cur = nullptr;
     return rc;

@@ -625,4 +625,68 @@ PLO_HD int inflate_block(Par &par, const uint8_t *in, uint32_t in_len, uint8_t *
     return INF_OK;
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// CRC-32 of an inflated BGZF block by ONE WAVE (RFC 1952 section 8: the IEEE 802.3 polynomial, reflected, 0xEDB88320), so that the
+// host need not read the inflated bytes to check them (k_bgzf_crc behind k_bgzf_inflate).  The block is cut into 64 consecutive chunks,
+// lane i runs the table-driven CRC over chunk i, and the chunks' CRCs are combined with the identity
+//     crc(A || B) = crc(A) * x^(8 |B|)  xor  crc(B)        (polynomials over GF(2) modulo the generator)
+// i.e. lane i multiplies its CRC by x^(8 * bytes behind its chunk) -- a square-and-multiply power, 32-step carry-less products -- and
+// the wave XORs the products.  `tab`: the 256-entry byte table in LDS (crc32_table_entry), shared by the workgroup.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t CRC32_POLY = 0xEDB88320u;
+PLO_HD uint32_t crc32_table_entry(uint32_t e) {
+    uint32_t c = e;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC32_POLY : 0u);
+    return c;
+}
+// a(x) * b(x) mod p(x) in the reflected representation (bit 31 = x^0)
+PLO_HD uint32_t crc32_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? CRC32_POLY : 0u);  // b * x
+    }
+    return p;
+}
+PLO_HD uint32_t crc32_xpow8(uint32_t n_bytes) {  // x^(8 n) mod p
+    uint32_t r = 0x80000000u, base = 0x00800000u;   // 1, x^8
+    for (uint32_t n = n_bytes; n; n >>= 1) {
+        if (n & 1u) r = crc32_mulmod(r, base);
+        base = crc32_mulmod(base, base);
+    }
+    return r;
+}
+// wave-uniform call; every lane returns the block's CRC-32
+PLO_DEV uint32_t crc32_wave(const uint8_t *p, uint32_t n, const uint32_t *tab) {
+    const uint32_t lane = (uint32_t)wv::lane();
+    const uint32_t per = (n + 63u) / 64u;
+    const uint32_t lo = lane * per < n ? lane * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t c = 0xffffffffu;
+    uint32_t a = lo;
+    const PLO_GLOBAL uint8_t *g = (const PLO_GLOBAL uint8_t *)p;
+    while (a < hi && (((uintptr_t)(p + a)) & 3u)) {
+        c = tab[(c ^ g[a]) & 0xffu] ^ (c >> 8);
+        ++a;
+    }
+    while (a + 4u <= hi) {
+        uint32_t w = *(const PLO_GLOBAL uint32_t *)(p + a);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c = tab[(c ^ w) & 0xffu] ^ (c >> 8);
+            w >>= 8;
+        }
+        a += 4u;
+    }
+    while (a < hi) {
+        c = tab[(c ^ g[a]) & 0xffu] ^ (c >> 8);
+        ++a;
+    }
+    c = hi > lo ? c ^ 0xffffffffu : 0u;  // (the CRC of no bytes is 0: an empty chunk adds nothing)
+    uint32_t s = crc32_mulmod(crc32_xpow8(n - hi), c);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) s ^= wv::shfl(s, (int)(lane ^ (uint32_t)d));
+    return s;
+}
+
 }  // namespace plo

@@ -515,6 +515,20 @@ extern "C" int emu_finish_batch(const plo_batch_in *in, const plo_finish_in *fin
 // the device comp_base (lift_core.hpp), for an exhaustive comparison with the oracle
 extern "C" int emu_comp_base(int b) { return plo::comp_base(b); }
 
+// crc32_wave (k_bgzf_crc's wave per BGZF block, inflate.hpp) under the emulator
+extern "C" uint32_t emu_crc32_wave(const uint8_t *p, uint32_t n, unsigned order_seed) {
+    uint32_t tab[256];
+    for (uint32_t e = 0; e < 256; ++e) tab[e] = plo::crc32_table_entry(e);
+    uint32_t res = 0;
+    wv::EmuWave w;
+    w.order_seed = order_seed;
+    w.run([&]() {
+        uint32_t c = plo::crc32_wave(p, n, tab);
+        if (wv::lane() == 17) res = c;
+    });
+    return res;
+}
+
 // build_segment_map_wave (k_map_build's wave per contig segment) under the emulator, and the sequential build_segment_map beside it
 extern "C" int emu_map_build(const uint32_t *cigar, uint32_t n, long long ref_pos, int wave, plo::KV *out, unsigned order_seed) {
     if (!wave) return plo::build_segment_map(cigar, n, ref_pos, out);

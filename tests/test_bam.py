@@ -448,6 +448,46 @@ def test_device_inflate_matches_host_inflate(tmp_path, monkeypatch):
         assert got["0"] == got["1"] and sum(x[0] for x in got["1"]) == w.n_reads
 
 
+@pytest.mark.gpu
+def test_device_crc_rejects_a_block_whose_bytes_or_crc_were_changed(tmp_path, monkeypatch):
+    """k_bgzf_crc (a wave per inflated block behind k_bgzf_inflate): a BGZF block whose stored CRC-32 -- or whose data, in a stored block --
+    was changed must fail the read with device inflate exactly as on the host, and the untouched file reads the same with the device's check
+    as with the host's (PLO_BGZF_HOST_CRC=1)"""
+    w = synth.generate(synth.config("tiny", n_reads=600, seed=415, split_read_frac=0.2, sorted_reads=True))
+    good = str(tmp_path / "good.bam")
+    bamsynth.write_read_bam(w, good, level=0)
+    blocks = bamcheck.bgzf_blocks(good)
+    assert len(blocks) > 4
+
+    def read_all(path):
+        rd = bam.BamReader(path, 4, device_inflate=0)
+        n = 0
+        while True:
+            win = rd.read_window(200)
+            if win is None:
+                break
+            n += win.n_records
+            win.close()
+        rd.close()
+        return n
+
+    n_dev = read_all(good)
+    monkeypatch.setenv("PLO_BGZF_HOST_CRC", "1")
+    assert read_all(good) == n_dev == w.n_reads
+    monkeypatch.delenv("PLO_BGZF_HOST_CRC")
+    raw = bytearray(open(good, "rb").read())
+    k = len(blocks) // 2
+    off, size = sum(b[0] for b in blocks[:k]), blocks[k][0]  # (bgzf_blocks gives sizes: the block's file offset is the sum of those before it)
+    for name, at in (("crc", off + size - 8), ("data", off + size - 8 - 100)):  # (stored blocks: a data byte changes the content, not the stream)
+        bad = bytearray(raw)
+        bad[at] ^= 0x5A
+        p = str(tmp_path / f"bad_{name}.bam")
+        open(p, "wb").write(bad)
+        with pytest.raises(Exception) as ei:
+            read_all(p)
+        assert "CRC" in str(ei.value) or "crc" in str(ei.value) or "corrupt" in str(ei.value).lower(), str(ei.value)
+
+
 def test_unmapped_record_placed_on_a_contig_is_a_data_error(tmp_path):
     """flag 0x4 with a reference id: the reference's window loop asserts !record.is_unmapped() (read_alignment_scanner.rs:396);
     only tid = -1 records reach its pass-through copy (:544)"""

@@ -139,3 +139,21 @@ def test_wave_decode_rejects_truncated_and_damaged_blocks():
         rc, out = _inflate(bytes(b), len(data), wave=True)
         bad += rc < 0 or out != data
     assert bad >= 10
+
+
+def test_crc32_by_a_wave_equals_zlib():
+    """k_bgzf_crc's crc32_wave (inflate.hpp): 64 chunk CRCs combined with x^(8 n) products over GF(2) -- against zlib.crc32 for every
+    length around the chunking's edges (0, 1, 63, 64, 65, ... a full 64 KiB block) and odd alignments"""
+    import ctypes as C
+    import zlib
+
+    L = emu_lib.lib()
+    L.emu_crc32_wave.restype = C.c_uint32
+    L.emu_crc32_wave.argtypes = [C.c_void_p, C.c_uint32, C.c_uint]
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, size=65536 + 64, dtype=np.uint8)
+    for n in (0, 1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096, 4097, 40000, 65535, 65536):
+        for off in (0, 1, 3):
+            buf = np.ascontiguousarray(data[off:off + n])
+            got = L.emu_crc32_wave(buf.ctypes.data, n, 0 if n % 2 else 11)
+            assert got == (zlib.crc32(buf.tobytes()) & 0xffffffff), (n, off)
