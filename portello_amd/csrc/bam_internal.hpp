@@ -375,7 +375,11 @@ struct BgzfIn {
         // always a whole chunk of NEW data: a window larger than one chunk must not degenerate into one small refill (thread
         // start-up, or a device round trip) per record
         const size_t target = std::max(want, u + CHUNK);
-        while (cpos < size && u < target) {
+        // device inflate: whole rounds of resident waves -- a group takes one block's decode time (~7 ms) however few blocks it has, so
+        // the refill goes on to the next multiple of the wave slots (17 blocks left over used to cost a round of their own)
+        if (device == 1 && !dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
+        const size_t round_to = device == 1 ? dev_slots : 1;
+        while (cpos < size && (u < target || blks.size() % round_to != 0)) {
             if (size - cpos < 28) return fail(PLO_ERR_IO, "truncated BGZF block header");
             const uint8_t *h = map + cpos;
             if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(PLO_ERR_IO, "not a BGZF block");
