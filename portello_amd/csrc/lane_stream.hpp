@@ -22,9 +22,10 @@
 //     header starts it in the waves behind: a team's time is the sum of its items' ops / 64 at the pace of the slowest STAGE, not
 //     groups x longest item x all stages;
 //   * every wave holds ONE stage's state in registers (the three together spill), so more waves fit a SIMD;
-//   * the only global traffic is the input CIGAR (8 ops per lane and refill, asked for at the top of a step and stored into [IN] at
-//     its end), the probes, the output (8 ops per flush, straight into the item's slot of the output buffer, allocated when the item
-//     reaches the last wave from its region bound) and the per-item descriptors / results.
+//   * the only global traffic is the input CIGAR (16 ops per lane and refill, asked for at the top of a step and stored into [IN] at
+//     its end), the probes, the output (an aligned 64-byte line of 16 ops per flush, straight into the item's slot of the output buffer,
+//     allocated when the item reaches the last wave from its region bound) and the per-item descriptors / results: 2.9 x the
+//     algorithmic bytes on the stress profile (k_lift_lanes_g: 5.5 x).
 // An item whose unreleased tail outgrows a ring (its producer cannot make progress though the consumer has taken all there is) or
 // whose output outgrows its slot is handed to the retry list -> wave-cooperative code, like every item a lane kernel cannot hold.
 //
@@ -163,7 +164,15 @@ constexpr int STREAM_A_PUSH = 8;    // most ops one step of a stage can flush in
 constexpr int STREAM_B_PUSH = 2;    // liftover: gap deletion + piece,
 constexpr int STREAM_C_PUSH = 5;    // simplify: M I D M + the copied op
 constexpr int STREAM_END_PUSH = 2;  // an item's end: the open run + the end marker
-constexpr int STREAM_REFILL = 8;    // ops per refill of IN / per flush of Q3 (two 16-byte accesses per lane)
+#ifndef PLO_PIPE_REFILL
+#define PLO_PIPE_REFILL 16
+#endif
+constexpr int STREAM_REFILL = PLO_PIPE_REFILL;  // ops per refill of IN (16-byte loads): 16 = a 64-byte stretch per lane (8: FETCH_SIZE +10 %, a line's second half
+                                                // is often fetched again)
+#ifndef PLO_PIPE_FLUSH
+#define PLO_PIPE_FLUSH 16
+#endif
+constexpr int STREAM_FLUSH = PLO_PIPE_FLUSH;  // ops per flush of Q3: 16 = one aligned 64-byte line per lane (the items' slots start on lines)
 constexpr int STREAM_A_MIN_IN = 4;  // a shift step is worth starting with this many ops of input in the ring (or the input's end)
 #ifndef PLO_PIPE_BURST
 #define PLO_PIPE_BURST 4
@@ -183,7 +192,7 @@ constexpr int PIPE_CTL = 4;         // control words per lane: Q1 released, Q1 c
 constexpr int PIPE_WAVES = 3;
 PLO_DEV constexpr int stream_lds_dwords(int ni, int n1, int n2, int n3) { return 64 * (ni + n1 + n2 + n3 + PIPE_CTL) + LANE_KVS_DWORDS; }
 // slot of the output buffer an item is given when it reaches the last wave: its region bound (enumerate.hpp lane_region_dwords) + one flush
-PLO_DEV int stream_out_alloc(int n_m, int w0, int w1) { return lane_region_dwords(n_m, w0, w1) + STREAM_REFILL; }
+PLO_DEV int stream_out_alloc(int n_m, int w0, int w1) { return (lane_region_dwords(n_m, w0, w1) + STREAM_FLUSH + STREAM_FLUSH - 1) / STREAM_FLUSH * STREAM_FLUSH; }
 
 // the team's LDS
 template <int NI, int N1, int N2, int N3>
@@ -789,8 +798,9 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
     ReadSeq rd = item_read_seq<SP>(bt, 0ull, 0, 0);
     int c_ref_head = 0, c_read_head = 0, c_del = 0, c_ins = 0, c_blk_ref = 0, c_blk_read = 0, cmp = 0;
     bool c_in_blk = false, spanic = false, zero_m = false;
-    LaneRing<N3> q3;  // (both sides in this wave: rk = entries flushed)
+    LaneRing<N3> q3;  // (both sides in this wave)
     q3.b = pm.q3;
+    int flushed = 0;  // ops of the item written out; q3.rk = the start of the chunk that holds the next one (its ops go out again with it)
     int streak = 0;  // trips without a step (wave-uniform)
     for (;;) {
         rel2 = (int)*pm.q2_rel;
@@ -865,35 +875,39 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
                 q3.rel = mine ? 0 : q3.rel;
                 q3.rk = mine ? 0 : q3.rk;
                 q3.base = mine ? 0 : q3.base;
+                flushed = mine ? 0 : flushed;
             }
         }
         // ---- the flush: eight ops of Q3 -> the item's slot (the ops behind `rel` in the chunk are not final: they are written again
         // by the next flush, which starts at the new `rk`) ----
-        const int f_have = q3.rel - q3.rk;
+        const int f_have = q3.rel - flushed;
         const bool q3_tight = ring_room(q3) < STREAM_C_PUSH;
-        const bool f_rdy = (live | flushing) & !ovf & ((f_have >= STREAM_REFILL) | ((f_have > 0) & (q3_tight | flushing)));
+        const bool f_rdy = (live | flushing) & !ovf & ((f_have >= STREAM_FLUSH) | ((f_have > 0) & (q3_tight | flushing)));
         const unsigned long long mF = wv::ballot(f_rdy);
         if (mF != 0ull) {
-            const bool room_ok = q3.rk + STREAM_REFILL <= alloc;
+            // (whole chunks from a chunk's start: the lane's stores are aligned 64-byte lines; ops already out are written again with the rest)
+            const int f0 = flushed & ~(STREAM_FLUSH - 1);
+            const bool room_ok = f0 + STREAM_FLUSH <= alloc;
             ovf = ovf | (f_rdy & !room_ok);  // the output outgrew its slot (the region bound): retry list
             const bool go = f_rdy & room_ok & fits;
             if (go) {
-                uint32_t *const dst = wk.out_cigar + out_base + (unsigned long long)q3.rk;
+                uint32_t *const dst = wk.out_cigar + out_base + (unsigned long long)f0;
 #pragma unroll
-                for (int qd = 0; qd < STREAM_REFILL / 4; ++qd) {
+                for (int qd = 0; qd < STREAM_FLUSH / 4; ++qd) {
                     Ops4 v;
-                    v.x = q3.b[((q3.rk + 4 * qd) & (N3 - 1)) * 64];
-                    v.y = q3.b[((q3.rk + 4 * qd + 1) & (N3 - 1)) * 64];
-                    v.z = q3.b[((q3.rk + 4 * qd + 2) & (N3 - 1)) * 64];
-                    v.w = q3.b[((q3.rk + 4 * qd + 3) & (N3 - 1)) * 64];
+                    v.x = q3.b[((f0 + 4 * qd) & (N3 - 1)) * 64];
+                    v.y = q3.b[((f0 + 4 * qd + 1) & (N3 - 1)) * 64];
+                    v.z = q3.b[((f0 + 4 * qd + 2) & (N3 - 1)) * 64];
+                    v.w = q3.b[((f0 + 4 * qd + 3) & (N3 - 1)) * 64];
                     *(PLO_GLOBAL Ops4 *)(dst + 4 * qd) = v;
                 }
             }
-            q3.rk = (f_rdy & room_ok) ? wv::imin(q3.rk + STREAM_REFILL, q3.rel) : q3.rk;
+            flushed = (f_rdy & room_ok) ? wv::imin(f0 + STREAM_FLUSH, q3.rel) : flushed;
+            q3.rk = flushed & ~(STREAM_FLUSH - 1);
         }
         // ---- an item's results, once all of it is out (or it has none) ----
         {
-            const bool em = flushing & (ovf | (q3.rk >= q3.rel));
+            const bool em = flushing & (ovf | (flushed >= q3.rel));
             if (wv::ballot(em) != 0ull) {
                 const bool re = em & ovf;  // items a ring or the output slot could not hold: the wave-cooperative code takes them
                 const unsigned long long om = wv::ballot(re);
@@ -929,7 +943,7 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
         // (an item that has overflowed is read to its end without writing)
         const bool c_rdy = live & c_avail & (ovf | room_ok);
         // no room, nothing to flush: Q3 is full of the item's unreleased tail -> retry list
-        ovf = ovf | (live & !room_ok & (q3.rel <= q3.rk));
+        ovf = ovf | (live & !room_ok & (q3.rel <= flushed));
         const unsigned long long mC = pipe_worth(wv::ballot(c_rdy), wv::ballot(live), streak) ? wv::ballot(c_rdy) : 0ull;
         if (mC != 0ull) {
           bool cm = c_rdy;
@@ -1044,7 +1058,7 @@ template <bool SP, int NI, int N1, int N2, int N3>
 PLO_DEV void pipe_team(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t b, uint32_t e, bool has_shift, uint32_t *lds, WaveCtx &ctx) {
     static_assert((NI & (NI - 1)) == 0 && (N1 & (N1 - 1)) == 0 && (N2 & (N2 - 1)) == 0 && (N3 & (N3 - 1)) == 0, "ring sizes are powers of two");
     static_assert(NI >= STREAM_REFILL + STREAM_A_MIN_IN, "IN: a refill fits while a step's worth of input is left");
-    static_assert(N1 >= PIPE_H1 + STREAM_A_PUSH && N2 >= PIPE_H2 + STREAM_B_PUSH + STREAM_END_PUSH && N3 >= STREAM_C_PUSH + STREAM_REFILL, "a fresh item's first step fits behind its header");
+    static_assert(N1 >= PIPE_H1 + STREAM_A_PUSH && N2 >= PIPE_H2 + STREAM_B_PUSH + STREAM_END_PUSH && N3 >= STREAM_C_PUSH + STREAM_FLUSH + 4, "a fresh item's first step fits behind its header");
     const int role = wv::wave_id(), lane = wv::lane();
     PipeMem<NI, N1, N2, N3> pm(lds, lane);
     if (role == 0) {

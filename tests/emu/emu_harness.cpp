@@ -209,7 +209,7 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
             if (const char *e = getenv("PLO_EMU_HEAVY_STRIDE")) stride = std::max(LANE_REGION_PAD + 64, atoi(e)) & ~31;  // (regions too small for the longer items: retry list)
             std::vector<uint32_t> regions((size_t)lane_heavy_per * stride + 16, 0xdeadbeefu), windows((size_t)64 * LANE_WIN_DWORDS + LANE_KVS_DWORDS, 0xdeadbeefu);
             const bool stream = lane_stream > 0 && (stages & PLO_STAGES_ALL) == PLO_STAGES_ALL;
-            std::vector<uint32_t> slds((size_t)stream_lds_dwords(16, 16, 16, 32) + 16, 0xdeadbeefu);
+            std::vector<uint32_t> slds((size_t)stream_lds_dwords(32, 16, 16, 32) + 16, 0xdeadbeefu);
             if (stream) {
                 // teams of three waves (lane_stream.hpp): `lane_heavy_per` items per team, the forward class first
                 const uint32_t lo_ = n_small, mid_ = n_small + r2[n_items], hi_ = n_items;
@@ -226,11 +226,11 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                         bool hs;
                         pipe_team_span(team, t0, t1, lo_, mid_, hi_, b_, e_, hs);
                         if (lane_stream == 1) {
-                            if (sp) pipe_team<true, 16, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
-                            else pipe_team<false, 16, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            if (sp) pipe_team<true, 32, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            else pipe_team<false, 32, 16, 16, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
                         } else {
-                            if (sp) pipe_team<true, 16, 16, 8, 16>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
-                            else pipe_team<false, 16, 16, 8, 16>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            if (sp) pipe_team<true, 32, 16, 8, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
+                            else pipe_team<false, 32, 16, 8, 32>(ix, bt, wk, b_, e_, hs, slds.data(), ctx);
                         }
                         // the waves of the emulated workgroup share the one statistics slot: one wave at a time
                         for (int ww = 0; ww < PIPE_WAVES; ++ww) {
