@@ -363,6 +363,75 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
         shutil.rmtree(d, ignore_errors=True)
 
 
+def end_to_end_sharded(w, index, sample_reads: int, window_reads: int, n_workers: int, dist, rank: int, world: int, verify: bool = True):
+    """N > 1: ONE read->contig BAM lifted by all ranks -- BASELINE configs[3] as a BAM run.  Rank 0 writes the sample as a BGZF level-1 BAM
+    on the node's file system; every rank opens ITS PART of it (plo_bam_open_range: a split by compressed offset, first block and first
+    record found without an index -- the reference gives every worker an IndexedReader, src/worker_thread_data.rs:21-30), runs the whole
+    pipeline over it (inflate -> batches -> lift + finish on its GPU -> record bytes -> BGZF level 0) and writes its own output shard; no
+    collective on the data path.  Timed between two barriers, max over ranks.  Rank 0 then checks the shards' union against the expectation."""
+    import shutil
+    import tempfile
+
+    from portello_amd import bamsynth, pipeline
+
+    n = min(sample_reads, w.n_reads)
+    lo = max(0, (w.n_reads - n) // 2)
+    box = [None]
+    if rank == 0:
+        box[0] = tempfile.mkdtemp(prefix="plo_e2e_sharded_")
+    dist.broadcast_object_list(box, src=0)
+    d = box[0]
+    io_threads = max(2, min(64, pipeline_cpus()) // world)
+    inp = os.path.join(d, "reads.bam")
+    try:
+        ixd = w.index_data()
+        cn, rn = bamsynth.contig_names(w), bamsynth.ref_names(w)
+        rl = [int(s_.numel()) for s_ in w.chrom_seq]
+        if rank == 0:
+            bamsynth.write_read_bam(w, inp, lo, lo + n, level=1, n_threads=max(2, min(64, pipeline_cpus())))
+        dist.barrier()
+        outp, unp = os.path.join(d, f"lifted.{rank}.bam"), os.path.join(d, f"unassembled.{rank}.bam")
+        kw = dict(window_reads=window_reads, n_workers=n_workers, io_threads=io_threads, part=rank, n_parts=world)
+        pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, **dict(kw, window_reads=min(window_reads, 2000), n_workers=1))  # warm-up
+        dist.barrier()
+        t0 = time.perf_counter()
+        st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, unassembled_path=unp, **kw)
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt, float(st.reads), float(st.records_out), float(st.bytes_out)], dtype=torch.float64)
+        tmax = t.clone()
+        if dist.get_backend() == "nccl":
+            t, tmax = t.cuda(), tmax.cuda()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, int(st.reads))
+        res = None
+        if rank == 0:
+            res = {"value": float(t[1]) / float(tmax[0]), "unit": "reads/s", "reads": int(t[1]), "seconds": float(tmax[0]), "ranks": world,
+                   "reads_per_rank": per_rank, "records_out": int(t[2]), "output_MB": float(t[3]) / 1e6, "io_threads_per_rank": io_threads,
+                   "input_bam_MB": os.path.getsize(inp) / 1e6,
+                   "note": "one input BAM, every rank lifts its part (plo_bam_open_range) and writes its own output shard; no data-path collective"}
+            if verify:
+                try:
+                    from oracle import expect
+
+                    every = max(1, (n // 500) // 12)
+                    v = expect.verify_lifted_bam(inp, [os.path.join(d, f"lifted.{r}.bam") for r in range(world)], ixd, cn, rn, window=500, every=every,
+                                                 threads=min(16, max(2, pipeline_cpus())), unassembled_bam=[os.path.join(d, f"unassembled.{r}.bam") for r in range(world)])
+                    res["records_verified"] = v["records_verified"] if v["ok"] and int(t[1]) == n else 0
+                    res["verification"] = v
+                except Exception as e:  # noqa: BLE001
+                    log(f"[bench] end_to_end_sharded verification could not run: {e!r}")
+                    res["records_verified"] = None
+        dist.barrier()
+        return res
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+
+
 def stream_main(args, cfg, dev, dev_index, chunk_reads):
     """A read set larger than one batch (stress at 2 M reads, wgs30x at 6.2 M): chunks generated on one set of
     contigs, all resident in HBM, lifted batch after batch.  One step = one pass over all batches.  The timed passes use one host
@@ -534,6 +603,8 @@ def finalize(result) -> int:
         why.append("end_to_end (device-finished records): the written BAM differs from the expected records")
     if (result.get("verify") or {}).get("gathered_equals_single_gpu_result") is False:
         why.append("gathered records differ from the single-GPU result")
+    if (result.get("end_to_end_sharded") or {}).get("records_verified") == 0 and "verification" in (result.get("end_to_end_sharded") or {}):
+        why.append("end_to_end_sharded: the ranks' output shards differ from the expected records")
     if why:
         result["parity_failed"] = True
         result["parity_failure"] = why
@@ -996,9 +1067,10 @@ def main():
                 print(json.dumps(result), flush=True)
             os._exit(4)  # the headline (gathered) measurement is complete and printed; a collective of the supplementary part hung
 
-        watchdog = threading.Timer(float(os.environ.get("PLO_BENCH_SUPP_TIMEOUT", "300")), bail)
+        watchdog = threading.Timer(float(os.environ.get("PLO_BENCH_SUPP_TIMEOUT", "900")), bail)
         watchdog.daemon = True
         watchdog.start()
+    e2e_sh = None
     try:
         no_gather = verify = None
         # ---- supplementary distributed numbers (SURVEY.md 8(e) "report both") ---------------------------------------------------
@@ -1026,12 +1098,15 @@ def main():
                     step(0, gather=False)  # restore this rank's own result in the context (read by the roofline object below)
                 barrier()
 
+        # BASELINE configs[3] as a BAM run: one input BAM, every rank its part of it (plo_bam_open_range), its own output shard
+        if dist is not None and strong and args.e2e_reads > 0:
+            e2e_sh = end_to_end_sharded(w, index, args.e2e_reads, args.e2e_window, args.e2e_workers, dist, rank, world, verify=not args.no_cpu_baseline)
     except Exception as e:  # noqa: BLE001 -- supplementary objects must never hide the measurement
         log(f"[bench] supplementary distributed measurements failed: {e!r}")
     if watchdog is not None:
         watchdog.cancel()
     for name, obj in (("shard", shard_info), ("overlap", overlap), ("window_50k", window_50k), ("no_gather", no_gather), ("gather_modes", gather_modes),
-                      ("verify", verify)):
+                      ("verify", verify), ("end_to_end_sharded", e2e_sh)):
         if obj is not None:
             result[name] = obj
     ixd_host = None

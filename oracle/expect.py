@@ -50,7 +50,10 @@ def verify_lifted_bam(in_bam, out_bam, ix: abi.IndexData, contig_names, ref_name
     from portello_amd import bam
 
     pyoracle.build()
-    _, _, out_recs = bamcheck.read_bam(out_bam)
+    # (`out_bam`: one file, or the shards several ranks wrote -- their union is the output, plo_bam_open_range / INTEGRATION.md section 6)
+    out_recs = []
+    for p_ in ([out_bam] if isinstance(out_bam, (str, bytes)) else list(out_bam)):
+        out_recs += bamcheck.read_bam(p_)[2]
     have = Counter(out_recs)
     _, _, in_recs = bamcheck.read_bam(in_bam)
     prim = [r for r in in_recs if not (struct.unpack_from("<H", r, 18)[0] & 0x804)]
@@ -83,8 +86,11 @@ def verify_lifted_bam(in_bam, out_bam, ix: abi.IndexData, contig_names, ref_name
         ok = ok and sum(want_all.values()) == len(out_recs)
     out = {"ok": bool(ok), "reads_verified": reads_checked, "records_verified": recs_checked, "records_missing_or_different": missing,
            "records_in_output": len(out_recs), "windows_of": window, "every_nth_window": every}
-    if unassembled_bam is not None and os.path.exists(unassembled_bam):
-        _, _, un = bamcheck.read_bam(unassembled_bam)
+    un_paths = [] if unassembled_bam is None else ([unassembled_bam] if isinstance(unassembled_bam, (str, bytes)) else list(unassembled_bam))
+    if un_paths and all(os.path.exists(p_) for p_ in un_paths):
+        un = []
+        for p_ in un_paths:
+            un += bamcheck.read_bam(p_)[2]
         out["unassembled_records"] = len(un)
         out["unassembled_ok"] = len(un) >= n_unmapped_in
     return out

@@ -51,7 +51,7 @@ def test_bench_starts_two_ranks_by_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PLO_BENCH_SHARE_GPU"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "chr20", "--reads", "30000",
-                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+                        "--steps", "3", "--warmup", "1", "--e2e-reads", "4000", "--e2e-window", "700"], env=env, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout  # ONE JSON line
@@ -60,3 +60,8 @@ def test_bench_starts_two_ranks_by_itself():
     assert r["verify"]["gathered_equals_single_gpu_result"] is True
     assert r["config"]["dist_backend"] == "gloo" and r["config"]["launched_by"].startswith("bench.py")
     assert len(r["shard"]["windows_per_rank"]) == 2 and all(n > 0 for n in r["shard"]["windows_per_rank"])
+    # ... and BASELINE configs[3] as a BAM run: one input BAM, every rank lifts its part (plo_bam_open_range) into its own shard; the shards'
+    # union holds the expected records
+    sh = r["end_to_end_sharded"]
+    assert sh["ranks"] == 2 and sh["reads"] == 4000 and all(n > 0 for n in sh["reads_per_rank"]) and sh["value"] > 0
+    assert sh["records_verified"] >= 300 and sh["verification"]["ok"] is True
