@@ -63,7 +63,7 @@ constexpr uint32_t SEG_LANES = PLO_SEG_LANES, SEG_UNROLL = 32 / SEG_LANES < 2 ? 
 // It is also the boundary check of the device path (the kernels index with what the batch says): bit 0 of *err = an index
 // outside its array (PLO_ERR_INVALID_ARG), bit 1 = a coordinate outside the 31-bit BAM range, an op code above 8 or a CIGAR
 // spanning more than 2^30 bases (PLO_ERR_RANGE) -- what the reference's types rule out by construction.
-enum { VERR_INDEX = 1u, VERR_RANGE = 2u };
+enum { VERR_INDEX = 1u, VERR_RANGE = 2u, VERR_CAP = 4u };
 __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uint32_t *seg_cnt, int *seg_reflen, uint32_t *seg_readlen,
                                                    uint32_t *seg_nm, uint32_t *err) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -172,11 +172,17 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
 }
 
 // thread per read segment: resolve the descriptors of its items (build_item_desc) at their scanned offsets
-__global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off, int *seg_reflen) {
+// `item_cap` (the one-round-trip path, liftover_fast): the item arrays hold that many items; a batch with more raises VERR_CAP and writes
+// none beyond them (the host then takes the path that asks for the count first)
+__global__ void k_item_emit(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, const uint32_t *seg_off, int *seg_reflen, uint32_t item_cap, uint32_t *err) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bt.n_segs) return;
     // (level 0 of the descriptor loads goes out with the offsets: enumerate.hpp)
     const uint32_t o0 = seg_off[s], o1 = seg_off[s + 1];
+    if (o1 > item_cap) {
+        if (o1 > o0) atomicOr(err, (uint32_t)VERR_CAP);
+        return;
+    }
     const int ref_len = seg_reflen[s];
     SegInfo si;
     seg_info_level0(si, bt, wk, stages, s);
@@ -254,8 +260,10 @@ __device__ __forceinline__ void load8(const uint32_t *a, uint32_t base, uint32_t
         for (uint32_t k = 0; k < 8; ++k) v[k] = base + k < n ? a[base + k] : fill;
     }
 }
-__global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial) {
+// (`n_dev` != NULL: the item count is read from device memory -- the one-round-trip path launches with the arrays' capacity)
+__global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial, const uint32_t *n_dev) {
     __shared__ uint32_t acc[6];
+    if (n_dev) n = *n_dev;
     if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
@@ -340,8 +348,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, ui
     }
 }
 __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *partial, const uint32_t *totals,
-                                                          uint32_t n, uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w) {
+                                                          uint32_t n, uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w, const uint32_t *n_dev) {
     __shared__ unsigned wt[4];
+    if (n_dev) n = *n_dev;
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
     // every load in front of the scans and of the stores (a load behind a store waits for the store: the memory counter is in order)
     uint32_t cls[CLS_PER], wgt[CLS_PER];
@@ -504,8 +513,12 @@ __global__ __launch_bounds__(LANE_SORT_THREADS) void k_chunk_sort(uint32_t *perm
 // The same sort for the default geometry -- windows of at most 128 positions, fixed groups: one WAVE per window (two items per lane, four bins
 // per lane), four windows per workgroup, no workgroup barrier and 4 KB of LDS (k_chunk_sort: a workgroup and 25 KB per window).
 __global__ __launch_bounds__(256) void k_chunk_sort_w(uint32_t *perm, const uint32_t *n_m, const uint32_t *w0, const uint32_t *w1, uint32_t n0, uint32_t n1,
-                                                      uint32_t chunk) {
+                                                      uint32_t chunk, const uint32_t *totals_dev) {
     __shared__ uint32_t hist_all[4][256];
+    if (totals_dev) {  // (the class counts from device memory: k_cls_scan's totals)
+        n0 = totals_dev[0];
+        n1 = totals_dev[1];
+    }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *const hist = hist_all[wave];
     const uint32_t c0 = (n0 + chunk - 1) / chunk, c1 = (n1 + chunk - 1) / chunk;
@@ -794,11 +807,19 @@ __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu
     lift_lanes_kernel<false, false>(ix, bt, wk, stages, 0u, n1, gs, capw, base, slab_wave0);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t n1, uint32_t gs, int capw) {
+                                                                                                   uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
+    if (totals_dev) {  // (the one-round-trip path: the class counts are on the device only)
+        n0 = totals_dev[0];
+        n1 = totals_dev[1];
+    }
     lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                      uint32_t n1, uint32_t gs, int capw) {
+                                                                                                      uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
+    if (totals_dev) {
+        n0 = totals_dev[0];
+        n1 = totals_dev[1];
+    }
     lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 
@@ -1281,6 +1302,11 @@ struct plo_ctx {
     bool lane_budget = false;  // (measured, MI355X, wgs30x 2 M reads: 1.42 ms with windows of 512 against 1.29 ms with fixed groups in windows of 128 -- DESIGN.md section 6)
     int lane_budget_window = 512;
     bool lane_stream = true;       // heavy items of all-stage batches through the streaming kernel (lane_stream.hpp)
+    // the one-round-trip path (liftover_fast): what the last batch of this context left -- the segments / items its arrays are sized for, its
+    // class counts, whether it had heavy items (a context that sees windows of one shape lifts them without asking the device for counts)
+    bool fast = true;
+    uint32_t fast_ns_cap = 0, fast_item_cap = 0, fast_n0 = 0, fast_n1 = 0;
+    bool fast_light_only = false;
     uint32_t lane_groups_cap = 0;  // groups the list of the budget-cut groups has room for (set with the list, attempt 0 of a batch)
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
     // batches with at least that many heavy items; < 0 (default) = by lane_heavy_ratio, see the routing in liftover_core (0: never).
@@ -1535,6 +1561,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
     if (const char *e = getenv("PLO_LANE_HEAVY_RATIO")) c->lane_heavy_ratio = std::max(0, atoi(e));
     if (const char *e = getenv("PLO_LANE_STREAM_RATIO")) c->lane_stream_ratio = std::max(1, atoi(e));
+    if (const char *e = getenv("PLO_FAST_PATH")) c->fast = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1610,6 +1637,52 @@ static plo_status scan_u32(plo_ctx *c, const uint32_t *in, uint32_t n, uint32_t 
     return PLO_OK;
 }
 
+// the item work list and the per-item outputs of a batch of `n_items` items in the context's buffers
+static void fill_work(plo_ctx *c, DevWork &wk, uint32_t n_items) {
+    memset(&wk, 0, sizeof(wk));
+    wk.n_items = n_items;
+    wk.item_seg = c->item_seg.as<uint32_t>();
+    wk.item_cseg = c->item_cseg.as<uint32_t>();
+    wk.item_nin = c->item_nin.as<uint32_t>();
+    wk.item_cls = c->item_cls.as<uint32_t>();
+    wk.perm = c->perm.as<uint32_t>();
+    wk.retry_list = c->retry_list.as<uint32_t>();
+    wk.lane_max_w = c->lane_max_w;
+    wk.item_op_prefix = c->op_prefix.as<uint32_t>();
+    wk.d.in_off = c->d_in_off.as<uint32_t>();
+    wk.d.n_in = c->d_n_in.as<uint32_t>();
+    wk.d.n_m = c->d_n_m.as<uint32_t>();
+    wk.d.pos1 = c->d_pos1.as<int>();
+    wk.d.w0 = c->d_w0.as<uint32_t>();
+    wk.d.w1 = c->d_w1.as<uint32_t>();
+    wk.d.kv0 = c->d_kv0.as<uint32_t>();
+    wk.d.kv1 = c->d_kv1.as<uint32_t>();
+    wk.d.flags = c->d_flags.as<uint32_t>();
+    wk.d.contig = c->d_contig.as<uint32_t>();
+    wk.d.seq_len = c->d_seq_len.as<uint32_t>();
+    wk.d.seq_off = c->d_seq_off.as<uint64_t>();
+    wk.d.shift_ref = c->d_shift_ref.as<uint64_t>();
+    wk.d.shift_ref_len = c->d_shift_ref_len.as<int>();
+    wk.d.chrom_ref = c->d_chrom_ref.as<uint64_t>();
+    wk.d.chrom_ref_len = c->d_chrom_ref_len.as<int>();
+    wk.d.read_len = c->d_read_len.as<uint32_t>();
+    wk.seg_readlen = c->seg_readlen.as<uint32_t>();
+    wk.seg_nm = c->seg_nm.as<uint32_t>();
+    wk.status = c->o_status.as<uint8_t>();
+    wk.flip = c->o_flip.as<uint8_t>();
+    wk.mapq = c->o_mapq.as<uint8_t>();
+    wk.chrom = c->o_chrom.as<uint32_t>();
+    wk.pos = c->o_pos.as<int64_t>();
+    wk.cig_off = c->o_coff.as<uint64_t>();
+    wk.cig_len = c->o_clen.as<uint32_t>();
+    wk.counters = c->counters.as<unsigned long long>();
+    wk.big_list = c->big_list.as<uint32_t>();
+    wk.miss_list = c->miss_list.as<uint32_t>();
+    wk.wave_stats = c->wave_stats.as<unsigned long long>();
+}
+
+static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t stages, plo_batch_out *out, const DevBatch &bt, bool &fallback);
+
 plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t stages, plo_batch_out *out) {
     if (!c || !in || !out) return PLO_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
@@ -1646,6 +1719,18 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->ev_big = false;
     c->ev_mid = false;
 
+    // A context that has just lifted a batch of light items only, with arrays that hold this one too: everything is launched with counts
+    // read from device memory and the host looks ONCE, at the end (liftover_fast); a batch that turns out not to fit -- more items than
+    // the arrays hold, heavy items, an overflow -- is run again on the path below, which asks for the counts first
+    if (c->fast && c->fast_light_only && !in->item_seg && !sp && in->n_segs && in->n_segs <= c->fast_ns_cap && c->fast_item_cap && c->lane_max_w >= 0 && c->lane_sort &&
+        !c->lane_budget && c->lane_sort_window <= 128 && c->o_cigar.cap && !getenv("PLO_LANE_SPLIT")) {
+        bool fallback = false;
+        plo_status fs = liftover_fast(c, in, stages, out, bt, fallback);
+        if (!fallback) return fs;
+        c->fast_light_only = false;
+        memset(out, 0, sizeof(*out));
+        memset(&c->timing, 0, sizeof(c->timing));
+    }
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     // ---- items: count -> scan -> resolve descriptors -> scan op counts -> tile bounds ----
     uint32_t n_items = 0;
@@ -1716,43 +1801,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     if (in->seq_fmt == PLO_SEQ_BAM4_SPARSE) HIP_TRY(c, c->miss_list.ensure(ni * 4));
     HIP_TRY(c, c->counters.ensure(CNT_N * 8));
     DevWork wk;
-    memset(&wk, 0, sizeof(wk));
-    wk.n_items = n_items;
-    wk.item_seg = c->item_seg.as<uint32_t>();
-    wk.item_cseg = c->item_cseg.as<uint32_t>();
-    wk.item_nin = c->item_nin.as<uint32_t>();
-    wk.item_cls = c->item_cls.as<uint32_t>();
-    wk.perm = c->perm.as<uint32_t>();
-    wk.retry_list = c->retry_list.as<uint32_t>();
-    wk.lane_max_w = c->lane_max_w;
-    wk.item_op_prefix = c->op_prefix.as<uint32_t>();
-    wk.d.in_off = c->d_in_off.as<uint32_t>();
-    wk.d.n_in = c->d_n_in.as<uint32_t>();
-    wk.d.n_m = c->d_n_m.as<uint32_t>();
-    wk.d.pos1 = c->d_pos1.as<int>();
-    wk.d.w0 = c->d_w0.as<uint32_t>();
-    wk.d.w1 = c->d_w1.as<uint32_t>();
-    wk.d.kv0 = c->d_kv0.as<uint32_t>();
-    wk.d.kv1 = c->d_kv1.as<uint32_t>();
-    wk.d.flags = c->d_flags.as<uint32_t>();
-    wk.d.contig = c->d_contig.as<uint32_t>();
-    wk.d.seq_len = c->d_seq_len.as<uint32_t>();
-    wk.d.seq_off = c->d_seq_off.as<uint64_t>();
-    wk.d.shift_ref = c->d_shift_ref.as<uint64_t>();
-    wk.d.shift_ref_len = c->d_shift_ref_len.as<int>();
-    wk.d.chrom_ref = c->d_chrom_ref.as<uint64_t>();
-    wk.d.chrom_ref_len = c->d_chrom_ref_len.as<int>();
-    wk.d.read_len = c->d_read_len.as<uint32_t>();
-    wk.seg_readlen = c->seg_readlen.as<uint32_t>();
-    wk.seg_nm = c->seg_nm.as<uint32_t>();
-    wk.status = c->o_status.as<uint8_t>();
-    wk.flip = c->o_flip.as<uint8_t>();
-    wk.mapq = c->o_mapq.as<uint8_t>();
-    wk.chrom = c->o_chrom.as<uint32_t>();
-    wk.pos = c->o_pos.as<int64_t>();
-    wk.cig_off = c->o_coff.as<uint64_t>();
-    wk.cig_len = c->o_clen.as<uint32_t>();
-    wk.counters = c->counters.as<unsigned long long>();
+    fill_work(c, wk, n_items);
     {   // statistic slots of the lift kernels' waves: zeroed once, cleared again by every k_sum_stats
         const size_t want = (size_t)STAT_SLOTS * STAT_WORDS * 8;
         if (c->wave_stats.cap < want) {
@@ -1790,7 +1839,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                                in->item_cseg, c->verr.as<uint32_t>());
         else
             hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages,
-                               (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>());
+                               (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>(), 0xffffffffu, c->verr.as<uint32_t>());
         HIP_TRY(c, hipGetLastError());
     }
     // ---- class order: block counts -> scan -> permutation (three launches); the host learns the class counts and the weights'
@@ -1806,7 +1855,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         memset(m_, 0, 8 * 4);
         if (n_items) {
             hipLaunchKernelGGL(k_cls_hist, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(),
-                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, cls_nb, c->cls_partial.as<uint32_t>());
+                               (const uint32_t *)c->item_nin.as<uint32_t>(), n_items, cls_nb, c->cls_partial.as<uint32_t>(), (const uint32_t *)nullptr);
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_THREADS), 0, st, c->cls_partial.as<uint32_t>(), cls_nb, c->misc.as<uint32_t>());
             HIP_TRY(c, hipMemcpyAsync(m_, c->misc.p, 6 * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipMemcpyAsync(m_ + 6, c->verr.p, 4, hipMemcpyDeviceToHost, st));
@@ -1814,7 +1863,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             hipLaunchKernelGGL(k_permute2, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(),
                                (const uint32_t *)c->item_nin.as<uint32_t>(), (const uint32_t *)c->cls_partial.as<uint32_t>(),
                                (const uint32_t *)c->misc.as<uint32_t>(), n_items, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
-                               c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu);
+                               c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu, (const uint32_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventSynchronize(c->ev_cls)); ++n_syncs;  // (the copies are done; k_permute2 may still be running)
         }
@@ -1971,7 +2020,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 }
                 if (!budget && ch <= 128u)
                     hipLaunchKernelGGL(k_chunk_sort_w, dim3((chunks + 3u) / 4u), dim3(256), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
-                                       (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch);
+                                       (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch, (const uint32_t *)nullptr);
                 else
                     hipLaunchKernelGGL(k_chunk_sort, dim3(chunks), dim3(LANE_SORT_THREADS), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
                                        (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), n0, n1, ch,
@@ -1987,7 +2036,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
+            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
             else if (getenv("PLO_LANE_SPLIT") && !wk.lane_groups && n0 && n1) {
                 // (experiment: the classes as two launches, the forward one without the shift stage's code; both over the whole grid)
                 hipLaunchKernelGGL(k_lift_lanes_fwd, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, gs, c->lane_capw);
@@ -1996,7 +2045,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
                 wk2.stat_base = stat_used;
                 stat_used += nblk * LANE_WAVES;
                 hipLaunchKernelGGL(k_lift_lanes_rev, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk2, stages, n0, n1, gs, c->lane_capw, 0u);
-            } else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw);
+            } else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
@@ -2267,6 +2316,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_heavy_lane_items = heavy_lanes ? n_items - n_small : 0u;
     c->timing.heavy_kernel = heavy_kernel;
     c->timing.host_syncs = n_syncs;
+    c->fast_ns_cap = ns;
+    c->fast_item_cap = n_items;
+    c->fast_n0 = h_cls[0];
+    c->fast_n1 = h_cls[1];
+    c->fast_light_only = n_items > 0 && n_items == n_small && n_retry == 0 && n_big == 0 && n_miss == 0;
     c->timing.n_retry_items = n_retry;
     if (c->adaptive && c->cap == TILE_CAP_SMALL && n_retry > n_items / 200) c->small_window_tight = true;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
@@ -2287,6 +2341,146 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     out->item_cigar_len = c->o_clen.as<uint32_t>();
     out->cigar = c->o_cigar.as<uint32_t>();
     out->n_cigar = hc[CNT_CIGAR] + wk.slab_offset;
+    c->last_wk = wk;
+    c->last_bt = bt;
+    c->have_last = true;
+    c->have_finish = false;
+    return PLO_OK;
+}
+
+// One host round trip per batch.  The enumerate kernels, the class order, k_lift_lanes and k_lift_retry are launched
+// back to back with the item and class counts read from DEVICE memory (k_cls_hist / k_permute2 / k_chunk_sort_w / k_lift_lanes take them by
+// pointer; grids are sized by the arrays' capacity, surplus workgroups leave at once); the one copy at the end brings the item count, the
+// validation flags, the class counts and the counters.  `fallback`: the batch does not fit what the context's last batch left (more items
+// than the arrays hold, heavy items, items handed on by the retry kernel, an output overflow): nothing of it is used.
+static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t stages, plo_batch_out *out, const DevBatch &bt, bool &fallback) {
+    fallback = false;
+    const DevIndex &ix = c->ix->d;
+    hipStream_t st = c->stream;
+    const uint32_t ns = in->n_segs, cap = c->fast_item_cap;
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    HIP_TRY(c, hipMemsetAsync(c->verr.p, 0, 16, st));
+    HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
+    hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>(),
+                       c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->seg_nm.as<uint32_t>(), c->verr.as<uint32_t>());
+    plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
+    if (s != PLO_OK) return s;
+    const uint32_t *n_dev = c->seg_off.as<uint32_t>() + ns, *totals_dev = c->misc.as<uint32_t>();
+    DevWork wk;
+    fill_work(c, wk, cap);
+    hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages, (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>(),
+                       cap, c->verr.as<uint32_t>());
+    const uint32_t cls_nb = (cap + CLS_BLOCK - 1) / CLS_BLOCK;
+    HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 6 * 4));
+    hipLaunchKernelGGL(k_cls_hist, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(), cap,
+                       cls_nb, c->cls_partial.as<uint32_t>(), n_dev);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_THREADS), 0, st, c->cls_partial.as<uint32_t>(), cls_nb, c->misc.as<uint32_t>());
+    hipLaunchKernelGGL(k_permute2, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
+                       (const uint32_t *)c->cls_partial.as<uint32_t>(), (const uint32_t *)c->misc.as<uint32_t>(), cap, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
+                       c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu, n_dev);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    // launch geometry from the last batch's class counts (a window of the same shape has the same): group size, persistent grid
+    uint32_t lane_gs = 64, lane_nblk = 0;
+    const size_t lane_lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;
+    {
+        int occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_lanes, LANE_WAVES * 64, lane_lds) != hipSuccess || occ < 1) occ = 1;
+        const uint32_t n0 = c->fast_n0, n1 = c->fast_n1, slots = (uint32_t)(c->n_cus * occ) * LANE_WAVES;
+        while (lane_gs > 8u && (n0 + lane_gs / 2 - 1) / (lane_gs / 2) + (n1 + lane_gs / 2 - 1) / (lane_gs / 2) <= slots) lane_gs >>= 1;
+        if (const char *e = getenv("PLO_LANE_GROUP")) lane_gs = std::min(64u, std::max(1u, (uint32_t)atoi(e)));
+        // (groups of this batch: at most cap / gs + 2 -- one partial group per class)
+        const uint32_t groups = cap / lane_gs + 2;
+        lane_nblk = std::min<uint32_t>((groups + LANE_WAVES - 1) / LANE_WAVES, (uint32_t)(c->n_cus * occ));
+        lane_nblk = (lane_nblk + 7u) & ~7u;
+    }
+    const uint32_t ch = (uint32_t)c->lane_sort_window;
+    hipLaunchKernelGGL(k_chunk_sort_w, dim3((cap / ch + 2u + 3u) / 4u), dim3(256), 0, st, c->perm.as<uint32_t>(), (const uint32_t *)c->d_n_m.as<uint32_t>(),
+                       (const uint32_t *)c->d_w0.as<uint32_t>(), (const uint32_t *)c->d_w1.as<uint32_t>(), 0u, 0u, ch, totals_dev);
+    wk.out_cigar = c->o_cigar.as<uint32_t>();
+    wk.out_cap = c->o_cigar.cap / 4;
+    wk.slab_pre = 1u;
+    wk.slab_offset = (unsigned long long)lane_nblk * LANE_WAVES * SLAB_OPS;
+    wk.n_small = cap;  // (unused by the lane kernel; the retry kernel's tiles take their items from the retry list)
+    wk.lane_n_groups = c->misc.as<uint32_t>() + 32;
+    wk.stat_base = 0;
+    uint32_t stat_used = lane_nblk * LANE_WAVES;
+    if (wk.slab_offset + SLAB_OPS > wk.out_cap) {  // the output buffer of the last batch does not even hold the waves' first slabs
+        fallback = true;
+        return PLO_OK;
+    }
+    if (c->seq_pending) {  // (plo_liftover_batch: the read bases arrive on the copy stream)
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_seq, 0));
+        c->seq_pending = false;
+    }
+    hipLaunchKernelGGL(k_lift_lanes, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    {
+        const int retry_cap = 320;
+        const uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15), nw = (uint32_t)c->n_cus * 2u;
+        wk.stat_base = stat_used;
+        stat_used += nw;
+        hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, 256, retry_cap);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    hipLaunchKernelGGL(k_sum_stats, dim3(std::min<uint32_t>((stat_used + 255) / 256, 16u)), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), stat_used,
+                       c->counters.as<unsigned long long>());
+    // the one look: counters, item count, validation flags, class totals
+    unsigned long long *hc = c->h_counters.as<unsigned long long>();
+    uint32_t *hx = (uint32_t *)(hc + CNT_N);
+    HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hx, n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hx + 1, c->verr.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hx + 2, c->misc.p, 6 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint32_t n_items = hx[0], verr = hx[1], n0 = hx[2], n1 = hx[3];
+    if (verr & (VERR_INDEX | VERR_RANGE)) {
+        if (verr & VERR_INDEX) {
+            c->err = "plo_batch_in: an index points outside its array (seg_read / seg_contig / seg_cigar_off / read_seq_off / item_seg / item_cseg)";
+            return PLO_ERR_INVALID_ARG;
+        }
+        c->err = "plo_batch_in: coordinate outside the 31-bit BAM range, CIGAR op code above 8, or a CIGAR spanning more than 2^30 bases";
+        return PLO_ERR_RANGE;
+    }
+    const unsigned long long all_ops = (unsigned long long)hx[6] | ((unsigned long long)hx[7] << 32);
+    if ((verr & VERR_CAP) || n_items > cap || n0 + n1 != n_items || all_ops > 0x7fffffffull || hc[CNT_OVERFLOW] || hc[CNT_NBIG] || hc[CNT_NMISS] || hc[CNT_ERROR] ||
+        (unsigned long long)(n0 / lane_gs + n1 / lane_gs + 2) > (unsigned long long)lane_nblk * LANE_WAVES * 0xffffull) {
+        fallback = true;  // more items than the arrays hold / heavy items / handed-on items / output overflow: the careful path runs the batch
+        return PLO_OK;
+    }
+    memset(&c->timing, 0, sizeof(c->timing));
+    c->ev_big = false;
+    c->ev_mid = false;
+    c->timing.n_items = n_items;
+    c->timing.tile_cap = (uint32_t)c->cap;
+    c->timing.tile_window = (uint32_t)c->window;
+    c->timing.n_lane_items = n_items;
+    c->timing.n_retry_items = (uint32_t)hc[CNT_NRETRY];
+    c->timing.n_in_ops = hc[CNT_IN_OPS];
+    c->timing.n_out_ops = hc[CNT_OUT_OPS];
+    c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
+    c->timing.lane_utilisation = hc[CNT_LANE_TRIPS] ? (float)((double)hc[CNT_LANE_ACT] / (64.0 * (double)hc[CNT_LANE_TRIPS])) : 0.0f;
+    c->timing.host_syncs = 1;
+    for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
+    c->fast_n0 = n0;
+    c->fast_n1 = n1;
+    out->n_items = n_items;
+    out->item_seg = c->item_seg.as<uint32_t>();
+    out->item_cseg = c->item_cseg.as<uint32_t>();
+    out->item_status = c->o_status.as<uint8_t>();
+    out->item_need_flipped = c->o_flip.as<uint8_t>();
+    out->item_mapq = c->o_mapq.as<uint8_t>();
+    out->item_chrom_index = c->o_chrom.as<uint32_t>();
+    out->item_ref_pos = c->o_pos.as<int64_t>();
+    out->item_cigar_off = c->o_coff.as<uint64_t>();
+    out->item_cigar_len = c->o_clen.as<uint32_t>();
+    out->cigar = c->o_cigar.as<uint32_t>();
+    out->n_cigar = hc[CNT_CIGAR] + wk.slab_offset;
+    wk.n_items = n_items;
+    wk.n_small = n_items;
     c->last_wk = wk;
     c->last_bt = bt;
     c->have_last = true;

@@ -702,3 +702,50 @@ def test_one_process_two_indexes(oracle):
         e.close()
     for i in indexes:
         i.close()
+
+
+def test_one_host_round_trip_path(oracle, monkeypatch):
+    """liftover_fast: a context whose last batch was light items only lifts the next batch with ONE host round trip
+    (counts read from device memory by the kernels) -- same results as the oracle and as the careful path; a batch that does not fit what
+    the last one left (more items than the arrays hold; heavy items) is run again on the careful path and is right too"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("chr20", n_reads=30_000), device="cuda")
+    ix = w.index_data()
+    index = api.Index(w.index_data_device())
+    eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    parts = [(0, 8000), (0, 8000), (16000, 30000), (1000, 3000)]  # a window, the same again (fast), a larger one (falls back), a smaller one (fast)
+    syncs = []
+    for lo, hi in parts:
+        db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+        torch.cuda.synchronize()
+        got = devbatch.run_and_download(eng, db)
+        syncs.append(int(eng.timing().host_syncs))
+        ref = oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8)
+        assert got.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
+    assert syncs[0] >= 3 and syncs[1] == 1 and syncs[2] >= 3 and syncs[3] == 1, syncs
+    # the same batches with the path switched off give the same results (and three round trips)
+    monkeypatch.setenv("PLO_FAST_PATH", "0")
+    eng2 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    for lo, hi in parts[:2]:
+        db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+        torch.cuda.synchronize()
+        got2 = devbatch.run_and_download(eng2, db)
+        assert int(eng2.timing().host_syncs) >= 3
+        assert got2.canonical() == oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8).canonical()
+    eng2.close()
+    monkeypatch.delenv("PLO_FAST_PATH")
+    # a batch with heavy items behind a light one: careful path, right results; the light batch after it is fast again only after a careful one
+    ws = synth.generate(synth.config("stress_small", n_reads=300), device="cuda")
+    index_s = api.Index(ws.index_data_device())
+    eng_s = api.Engine(index_s, stream=torch.cuda.current_stream().cuda_stream)
+    for k in range(2):
+        got = devbatch.run_and_download(eng_s, devbatch.DeviceBatch.from_workload(ws))
+        assert int(eng_s.timing().host_syncs) >= 3  # (heavy items: never the fast path)
+        assert got.canonical() == oracle.liftover_batch(ws.index_data(), ws.batch_data(), abi.STAGES_ALL, os.cpu_count() or 8).canonical()
+    eng_s.close()
+    index_s.close()
+    eng.close()
+    index.close()
