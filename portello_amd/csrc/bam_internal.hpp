@@ -337,7 +337,11 @@ struct BgzfIn {
     plo_status fill(size_t want) {
         if (avail() >= want || eof) return PLO_OK;
         if (bpos) {
-            memmove(buf.data(), buf.data() + bpos, buf.size() - bpos);
+            // (the unconsumed tail to the front: with several threads when it does not overlap its new place -- the usual case, a window
+            // has just been cut off the front -- it used to be a single-threaded memmove of up to a refill's 256 MB)
+            const size_t left = buf.size() - bpos;
+            if (left <= bpos && left > ((size_t)8 << 20)) parallel_copy(buf.data(), buf.data() + bpos, left, threads);
+            else memmove(buf.data(), buf.data() + bpos, left);
             buf.resize(buf.size() - bpos);
             if (ranged) {  // the blocks' places move with the bytes; blocks consumed whole are forgotten (the one that holds byte 0 stays)
                 size_t keep = 0;
