@@ -368,48 +368,75 @@ def end_to_end_sharded(w, index, sample_reads: int, window_reads: int, n_workers
     on the node's file system; every rank opens ITS PART of it (plo_bam_open_range: a split by compressed offset, first block and first
     record found without an index -- the reference gives every worker an IndexedReader, src/worker_thread_data.rs:21-30), runs the whole
     pipeline over it (inflate -> batches -> lift + finish on its GPU -> record bytes -> BGZF level 0) and writes its own output shard; no
-    collective on the data path.  Timed between two barriers, max over ranks.  Rank 0 then checks the shards' union against the expectation."""
+    collective on the data path.  Timed between two barriers, max over ranks.  Rank 0 then checks the shards' union against the expectation.
+    Every collective below is reached by every rank whatever happens to its own work (a rank that fails says so in the next reduction)."""
     import shutil
     import tempfile
 
     from portello_amd import bamsynth, pipeline
 
+    on_gpu = dist.get_backend() == "nccl"
+
+    def reduce(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64)
+        if on_gpu:
+            t = t.cuda()
+        dist.all_reduce(t, op=op)
+        return [float(x) for x in t.cpu()]
+
     n = min(sample_reads, w.n_reads)
     lo = max(0, (w.n_reads - n) // 2)
     box = [None]
     if rank == 0:
-        box[0] = tempfile.mkdtemp(prefix="plo_e2e_sharded_")
+        try:
+            box[0] = tempfile.mkdtemp(prefix="plo_e2e_sharded_")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] end_to_end_sharded: no temporary directory: {e!r}")
     dist.broadcast_object_list(box, src=0)
     d = box[0]
     io_threads = max(2, min(64, pipeline_cpus()) // world)
-    inp = os.path.join(d, "reads.bam")
+    ok, ixd, cn, rn, rl, inp = d is not None, None, None, None, None, None
     try:
-        ixd = w.index_data()
-        cn, rn = bamsynth.contig_names(w), bamsynth.ref_names(w)
-        rl = [int(s_.numel()) for s_ in w.chrom_seq]
-        if rank == 0:
-            bamsynth.write_read_bam(w, inp, lo, lo + n, level=1, n_threads=max(2, min(64, pipeline_cpus())))
-        dist.barrier()
+        if ok:
+            inp = os.path.join(d, "reads.bam")
+            ixd = w.index_data()
+            cn, rn = bamsynth.contig_names(w), bamsynth.ref_names(w)
+            rl = [int(s_.numel()) for s_ in w.chrom_seq]
+            if rank == 0:
+                bamsynth.write_read_bam(w, inp, lo, lo + n, level=1, n_threads=max(2, min(64, pipeline_cpus())))
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] end_to_end_sharded set-up failed on rank {rank}: {e!r}")
+        ok = False
+    ok = reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] > 0.5  # (also the barrier behind rank 0's file)
+    res = None
+    st = None
+    if ok:
         outp, unp = os.path.join(d, f"lifted.{rank}.bam"), os.path.join(d, f"unassembled.{rank}.bam")
         kw = dict(window_reads=window_reads, n_workers=n_workers, io_threads=io_threads, part=rank, n_parts=world)
-        pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, **dict(kw, window_reads=min(window_reads, 2000), n_workers=1))  # warm-up
+        try:
+            pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, **dict(kw, window_reads=min(window_reads, 2000), n_workers=1))  # warm-up
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] end_to_end_sharded warm-up failed on rank {rank}: {e!r}")
+            ok = False
         dist.barrier()
         t0 = time.perf_counter()
-        st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, unassembled_path=unp, **kw)
+        try:
+            if ok:
+                st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, unassembled_path=unp, **kw)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] end_to_end_sharded run failed on rank {rank}: {e!r}")
+            ok = False
         dist.barrier()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt, float(st.reads), float(st.records_out), float(st.bytes_out)], dtype=torch.float64)
-        tmax = t.clone()
-        if dist.get_backend() == "nccl":
-            t, tmax = t.cuda(), tmax.cuda()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ok = reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] > 0.5
+        mine = [dt, float(st.reads) if st else 0.0, float(st.records_out) if st else 0.0, float(st.bytes_out) if st else 0.0]
+        tmax = reduce(mine, dist.ReduceOp.MAX)
+        tsum = reduce(mine, dist.ReduceOp.SUM)
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, int(st.reads))
-        res = None
-        if rank == 0:
-            res = {"value": float(t[1]) / float(tmax[0]), "unit": "reads/s", "reads": int(t[1]), "seconds": float(tmax[0]), "ranks": world,
-                   "reads_per_rank": per_rank, "records_out": int(t[2]), "output_MB": float(t[3]) / 1e6, "io_threads_per_rank": io_threads,
+        dist.all_gather_object(per_rank, int(st.reads) if st else 0)
+        if rank == 0 and ok:
+            res = {"value": tsum[1] / tmax[0], "unit": "reads/s", "reads": int(tsum[1]), "seconds": tmax[0], "ranks": world,
+                   "reads_per_rank": per_rank, "records_out": int(tsum[2]), "output_MB": tsum[3] / 1e6, "io_threads_per_rank": io_threads,
                    "input_bam_MB": os.path.getsize(inp) / 1e6,
                    "note": "one input BAM, every rank lifts its part (plo_bam_open_range) and writes its own output shard; no data-path collective"}
             if verify:
@@ -419,17 +446,17 @@ def end_to_end_sharded(w, index, sample_reads: int, window_reads: int, n_workers
                     every = max(1, (n // 500) // 12)
                     v = expect.verify_lifted_bam(inp, [os.path.join(d, f"lifted.{r}.bam") for r in range(world)], ixd, cn, rn, window=500, every=every,
                                                  threads=min(16, max(2, pipeline_cpus())), unassembled_bam=[os.path.join(d, f"unassembled.{r}.bam") for r in range(world)])
-                    res["records_verified"] = v["records_verified"] if v["ok"] and int(t[1]) == n else 0
+                    res["records_verified"] = v["records_verified"] if v["ok"] and int(tsum[1]) == n else 0
                     res["verification"] = v
                 except Exception as e:  # noqa: BLE001
                     log(f"[bench] end_to_end_sharded verification could not run: {e!r}")
                     res["records_verified"] = None
-        dist.barrier()
-        return res
-    finally:
-        dist.barrier()
-        if rank == 0:
-            shutil.rmtree(d, ignore_errors=True)
+        elif rank == 0:
+            res = {"value": None, "note": "a rank's pipeline failed (see stderr)"}
+    dist.barrier()
+    if rank == 0 and d is not None:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
 
 
 def stream_main(args, cfg, dev, dev_index, chunk_reads):
