@@ -329,10 +329,18 @@ def test_full_size_wgs30x(oracle):
 
 
 def test_full_size_stress(oracle):
-    """BASELINE configs[4] read profile (20 kb, 5 % indel-dense, ~2 000 ops per read) on the wgs30x contigs: every item is
-    far heavier than a shared tile holds, so this is the test of the workgroup-per-item kernel (60 k heavy items: fewer than
-    the lane-per-item kernel for heavy items asks for)"""
-    _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
+    """BASELINE configs[4] read profile (20 kb, 5 % indel-dense, ~2 000 ops per read) on the wgs30x contigs: every item is far heavier than a
+    shared tile holds; 60 k reads are a reference-sized window task (src/read_alignment_scanner.rs:508-534) -- since round 5 routed to the
+    streaming kernel (k_lift_stream: 40 k - 200 k heavy items), before that to the workgroup-per-item kernel, which the second pass
+    (PLO_LANE_STREAM=0) still checks"""
+    t = _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
+    assert int(t.heavy_kernel) == 3 and t.n_heavy_lane_items > 50_000  # (k_lift_stream took the window)
+    os.environ["PLO_LANE_STREAM"] = "0"
+    try:
+        t = _full_size("stress", oracle, 40, 50, min_lifted=0.9, n_reads=60_000)
+        assert int(t.heavy_kernel) == 0 and t.n_mid_items > 50_000  # (the workgroup-per-item kernel)
+    finally:
+        del os.environ["PLO_LANE_STREAM"]
 
 
 def test_full_size_stress_2m_reads_streamed(oracle):
