@@ -230,6 +230,7 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                                       "stage_busy_s": {"decode": sd.read_s, "batch construction": sd.batch_s, "lift + finish (H2D, kernels, D2H), summed over workers": sd.lift_s,
                                                        "record assembly, summed over workers": sd.build_s, "bgzf write": sd.write_s,
                                                        "device (HIP events): lift": sd.device_ms / 1e3, "device (HIP events): finish + revcomp + SA": sd.finish_device_ms / 1e3},
+                                      "lift_stage_steps_s": dict(sd.lift_detail_s),
                                       "same_records_out_and_bytes": bool(sd.records_out == st.records_out and sd.bytes_out == st.bytes_out)}
         except Exception as e:  # noqa: BLE001
             log(f"[bench] end_to_end with device finishing failed: {e!r}")

@@ -163,8 +163,12 @@ __global__ __launch_bounds__(256) void k_seg_count(DevIndex ix, DevBatch bt, uin
     for (uint32_t g = gl + SEG_LANES; g < g1; g += SEG_LANES)  // contigs with more segments than lanes
         if (r_end >= (long long)ix.cs_start[g] && r_start < (long long)ix.cs_end[g]) ++n;
 #pragma unroll
-    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) n += (uint32_t)__shfl_xor((int)n, (int)d, 64);
+    for (uint32_t d = 1; d < SEG_LANES; d <<= 1) {
+        n += (uint32_t)__shfl_xor((int)n, (int)d, 64);
+        bad |= (uint32_t)__shfl_xor((int)bad, (int)d, 64);
+    }
     if (!live || sub != 0) return;
+    if (bad) n = 0;  // (a segment that fails the checks has no items: the one-round-trip path launches the lift kernels before the host sees the flag)
     seg_reflen[s] = (int)part;
     seg_readlen[s] = rpart > 0xfffffffeull ? 0xffffffffu : (uint32_t)rpart;
     seg_nm[s] = (c1 - c0) - pairs;
@@ -260,10 +264,12 @@ __device__ __forceinline__ void load8(const uint32_t *a, uint32_t base, uint32_t
         for (uint32_t k = 0; k < 8; ++k) v[k] = base + k < n ? a[base + k] : fill;
     }
 }
-// (`n_dev` != NULL: the item count is read from device memory -- the one-round-trip path launches with the arrays' capacity)
+// (`n_dev` != NULL: the item count is read from device memory -- the one-round-trip path launches with the arrays' capacity `n`; a count above
+// it means k_item_emit raised VERR_CAP and the arrays hold a mixture of this batch's and the last one's descriptors: the class totals then
+// come out zero, so that k_permute2, k_chunk_sort_w and the lift kernels touch nothing before the host sees the flag and takes the other path)
 __global__ __launch_bounds__(CLS_THREADS) void k_cls_hist(const uint32_t *item_cls, const uint32_t *item_w, uint32_t n, uint32_t nb, uint32_t *partial, const uint32_t *n_dev) {
     __shared__ uint32_t acc[6];
-    if (n_dev) n = *n_dev;
+    if (n_dev) n = *n_dev <= n ? *n_dev : 0u;  // (more items than the arrays hold, VERR_CAP: k_item_emit left stale descriptors -- nothing is classified, nothing lifted)
     if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cls_scan(uint32_t *partial, ui
 __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *partial, const uint32_t *totals,
                                                           uint32_t n, uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w, const uint32_t *n_dev) {
     __shared__ unsigned wt[4];
-    if (n_dev) n = *n_dev;
+    if (n_dev) n = *n_dev <= n ? *n_dev : 0u;
     const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
     // every load in front of the scans and of the stores (a load behind a store waits for the store: the memory counter is in order)
     uint32_t cls[CLS_PER], wgt[CLS_PER];

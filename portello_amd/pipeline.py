@@ -11,6 +11,7 @@ passed through to the "unassembled" writer (scan_unmapped_reads, :537-559).
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 import time
@@ -63,6 +64,7 @@ class PipelineStats:
     write_s: float = 0.0     # BGZF output (writer thread busy time)
     device_ms: float = 0.0   # HIP-event time of the lift calls
     finish_device_ms: float = 0.0  # device_finish: HIP-event time of the finishing, reverse-complement and SA-text kernels
+    lift_detail_s: dict = field(default_factory=dict)  # device_finish: the lift stage by step (host clock; the steps that wait for the device carry its time)
     errors: List[str] = field(default_factory=list)
 
 
@@ -182,6 +184,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 tstream = torch.cuda.Stream(device=dev)  # uploads, kernels and downloads of this worker, in order
                 eng = api.Engine(index, stream=tstream.cuda_stream)
                 sa_in, _sa_keep = devbatch.sa_inputs(ref_names, dev)
+                arena = devbatch.PinnedArena() if not os.environ.get("PLO_PIPELINE_PAGEABLE_RESULTS") else None
             else:
                 eng = api.Engine(index)
             while True:
@@ -193,15 +196,27 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 if desc is not None:
                     t = time.perf_counter()
                     if device_finish:
+                        marks = [("start", t)]
                         with torch.cuda.stream(tstream):
                             up = devbatch.upload_window(desc[0], desc[1], dev)
+                            marks.append(("upload (issue)", time.perf_counter()))
                             ddesc = up.batch.desc()
                             out = eng.liftover_batch_dev(ddesc)
+                            marks.append(("liftover", time.perf_counter()))
                             eng.compact_output_dev(out)
+                            marks.append(("compact", time.perf_counter()))
                             fo = eng.finish_batch_dev(ddesc, up.finish_in())
+                            marks.append(("finish", time.perf_counter()))
                             so = eng.sa_segments_dev(sa_in)
-                            host = devbatch.HostResults(eng, out, fo, so, win.n_records)
+                            marks.append(("sa text", time.perf_counter()))
+                            if arena is not None:
+                                arena.reset()
+                            host = devbatch.HostResults(eng, out, fo, so, win.n_records, arena=arena, dev=dev)
+                            marks.append(("download", time.perf_counter()))
                         t1 = time.perf_counter()
+                        with lock:
+                            for (_, a), (name, b) in zip(marks, marks[1:]):
+                                st.lift_detail_s[name] = st.lift_detail_s.get(name, 0.0) + (b - a)
                         rb = win.build_records_finished_raw(host.lift, host.fin, host.sa, ixd, contig_names, ref_names, is_target_region, build_threads)
                         with lock:
                             st.finish_device_ms += float(fo.finish_ms) + float(fo.revcomp_ms) + float(so.sa_ms)

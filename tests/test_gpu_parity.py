@@ -650,17 +650,22 @@ def test_device_entry_point_checks_its_batch():
             getattr(db, name)[idx] = val
         return f
 
-    assert run(set_("seg_contig", 0, 1_000_000)) == abi.PLO_ERR_INVALID_ARG
-    assert run(set_("seg_read", 3, 10_000_000)) == abi.PLO_ERR_INVALID_ARG
-    assert run(set_("seg_pos", 1, 2**31 + 7)) == abi.PLO_ERR_RANGE
-    assert run(set_("seg_pos", 1, -4)) == abi.PLO_ERR_RANGE
-    assert run(set_("cigar", 5, (7 << 4) | 12)) == abi.PLO_ERR_RANGE
-    assert run(set_("read_seq_off", 2, 2**40)) == abi.PLO_ERR_INVALID_ARG
-
     def swap_offsets(db):
         db.seg_cigar_off[4] = db.seg_cigar_off[5] + 3
 
-    assert run(swap_offsets) == abi.PLO_ERR_INVALID_ARG
+    for armed in (False, True):
+        if armed:
+            # the same on a context whose last batch left the one-round-trip path armed: there the lift kernels are launched BEFORE the host sees
+            # the flags, so a segment that fails the checks must have no items (k_seg_count)
+            for _ in range(2):
+                assert int(eng.liftover_batch_dev(good.desc()).n_items) > 0
+        assert run(set_("seg_contig", 0, 1_000_000)) == abi.PLO_ERR_INVALID_ARG
+        assert run(set_("seg_read", 3, 10_000_000)) == abi.PLO_ERR_INVALID_ARG
+        assert run(set_("seg_pos", 1, 2**31 + 7)) == abi.PLO_ERR_RANGE
+        assert run(set_("seg_pos", 1, -4)) == abi.PLO_ERR_RANGE
+        assert run(set_("cigar", 5, (7 << 4) | 12)) == abi.PLO_ERR_RANGE
+        assert run(set_("read_seq_off", 2, 2**40)) == abi.PLO_ERR_INVALID_ARG
+        assert run(swap_offsets) == abi.PLO_ERR_INVALID_ARG
     # and the context is usable afterwards
     assert int(eng.liftover_batch_dev(good.desc()).n_items) > 0
     eng.close()
@@ -734,6 +739,29 @@ def test_one_host_round_trip_path(oracle, monkeypatch):
         ref = oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8)
         assert got.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
     assert syncs[0] >= 3 and syncs[1] == 1 and syncs[2] >= 3 and syncs[3] == 1, syncs
+    # a batch with no more segments than the last one but MORE ITEMS than the item arrays hold: the launches made with the arrays' capacity
+    # must touch nothing (k_item_emit leaves stale descriptors behind VERR_CAP; round 5 lifted them once -- reads through the last batch's
+    # offsets, a memory fault under the BAM pipeline) and the careful path gives the right answer
+    cand = [(lo, lo + 8000) for lo in range(0, 22001, 2000)]
+    shapes = {}
+    for lo, hi in cand:
+        b = w.batch_data(lo, hi)
+        shapes[(lo, hi)] = (int(len(b.seg_read)), int(len(oracle.liftover_batch(ix, b, abi.STAGES_ALL, os.cpu_count() or 8).item_seg)))
+    pairs = [(a, b) for a in cand for b in cand if shapes[b][0] <= shapes[a][0] and shapes[b][1] > shapes[a][1]]
+    assert pairs, shapes  # (windows of 8 000 reads differ by tens of segments and items either way)
+    for a, b in pairs[:3]:
+        eng3 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+        syncs3 = []
+        for lo, hi in (a, a, b, b):
+            db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+            torch.cuda.synchronize()
+            got = devbatch.run_and_download(eng3, db)
+            syncs3.append(int(eng3.timing().host_syncs))
+            ref = oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8)
+            assert int(eng3.timing().n_items) == shapes[(lo, hi)][1]
+            assert got.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
+        assert syncs3[1] == 1 and syncs3[2] >= 3 and syncs3[3] == 1, (syncs3, shapes[a], shapes[b])
+        eng3.close()
     # the same batches with the path switched off give the same results (and three round trips)
     monkeypatch.setenv("PLO_FAST_PATH", "0")
     eng2 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
