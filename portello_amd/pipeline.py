@@ -64,6 +64,7 @@ class PipelineStats:
     write_s: float = 0.0     # BGZF output (writer thread busy time)
     device_ms: float = 0.0   # HIP-event time of the lift calls
     finish_device_ms: float = 0.0  # device_finish: HIP-event time of the finishing, reverse-complement and SA-text kernels
+    stage_done_s: dict = field(default_factory=dict)  # when each stage's thread ended, and the closes behind them (seconds after the start)
     lift_detail_s: dict = field(default_factory=dict)  # device_finish: the lift stage by step (host clock; the steps that wait for the device carry its time)
     errors: List[str] = field(default_factory=list)
 
@@ -147,6 +148,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.errors.append(f"reader: {e!r}")
             abort.set()
         finally:
+            st.stage_done_s["reader"] = time.perf_counter() - t0
             put(q_win, None)
 
     def batcher():
@@ -168,6 +170,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.errors.append(f"batcher: {e!r}")
             abort.set()
         finally:
+            st.stage_done_s["batcher"] = time.perf_counter() - t0
             for _ in range(n_workers):
                 put(q_in, None)
 
@@ -242,6 +245,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.errors.append(f"lift worker {k}: {e!r}")
             abort.set()
         finally:
+            st.stage_done_s[f"lift worker {k}"] = time.perf_counter() - t0
             if eng is not None:
                 eng.close()
             put(q_out, None)
@@ -268,17 +272,21 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
         except BaseException as e:  # noqa: BLE001
             st.errors.append(f"writer: {e!r}")
             abort.set()
+        st.stage_done_s["writer"] = time.perf_counter() - t0
 
+    st.stage_done_s["set up"] = time.perf_counter() - t0
     threads = [threading.Thread(target=reader), threading.Thread(target=batcher), threading.Thread(target=writer)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
     wr.close()
+    st.stage_done_s["output closed"] = time.perf_counter() - t0
     if un is not None:
         un.close()
     rd.close()
     st.seconds = time.perf_counter() - t0
+    st.stage_done_s["all closed"] = st.seconds
     if st.errors:
         raise RuntimeError("; ".join(st.errors))
     return st
