@@ -394,6 +394,97 @@ __global__ __launch_bounds__(CLS_THREADS) void k_permute2(const uint32_t *item_c
     }
 }
 
+// k_cls_scan and k_permute2 in one launch (the one-round-trip path: every launch of an enumerate pass costs ~5 us of dispatch latency, as
+// much as these kernels' work on a 50 k-read window): every block adds up k_cls_hist's raw rows itself -- the blocks in front of it for its
+// offsets, all of them for the class totals -- and block 0 leaves the totals ([0..5] as k_cls_scan, [6] = the item count as the scan left it).
+__global__ __launch_bounds__(CLS_THREADS) void k_permute2_s(const uint32_t *item_cls, const uint32_t *item_nin, const uint32_t *partial, uint32_t *totals, uint32_t n,
+                                                            uint32_t nb, uint32_t *perm, uint32_t *nin_p, uint32_t huge_w, const uint32_t *n_dev) {
+    __shared__ unsigned wt[4];
+    __shared__ uint32_t red[6];
+    __shared__ unsigned long long rsum;
+    __shared__ unsigned rmax;
+    const uint32_t n_raw = *n_dev;
+    n = n_raw <= n ? n_raw : 0u;
+    const uint32_t base = blockIdx.x * CLS_BLOCK + threadIdx.x * CLS_PER;
+    uint32_t cls[CLS_PER], wgt[CLS_PER];
+    load8(item_cls, base, n, 3u, cls);
+    load8(item_nin, base, n, 0u, wgt);
+    if (threadIdx.x < 6) red[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        rsum = 0;
+        rmax = 0;
+    }
+    __syncthreads();
+    {
+        uint32_t t0 = 0, t1 = 0, t2 = 0, q0 = 0, q1 = 0, q2 = 0;
+        unsigned mx = 0;
+        unsigned long long sum = 0;
+        for (uint32_t b = threadIdx.x; b < nb; b += CLS_THREADS) {
+            const uint32_t v0 = partial[b], v1 = partial[nb + b], v2 = partial[2 * nb + b];
+            t0 += v0, t1 += v1, t2 += v2;
+            if (b < blockIdx.x) q0 += v0, q1 += v1, q2 += v2;
+            if (blockIdx.x == 0) {
+                const unsigned m = partial[3 * nb + b];
+                mx = m > mx ? m : mx;
+                sum += (unsigned long long)partial[4 * nb + b] + ((unsigned long long)partial[5 * nb + b] << 16);
+            }
+        }
+        const uint32_t r[6] = {(uint32_t)wv::reduce_add((int)t0), (uint32_t)wv::reduce_add((int)t1), (uint32_t)wv::reduce_add((int)t2),
+                               (uint32_t)wv::reduce_add((int)q0), (uint32_t)wv::reduce_add((int)q1), (uint32_t)wv::reduce_add((int)q2)};
+        if (blockIdx.x == 0) {
+            mx = (unsigned)wv::reduce_max((int)(mx & 0x7fffffffu));
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (r[k]) atomicAdd(&red[k], r[k]);
+            if (blockIdx.x == 0) {
+                atomicMax(&rmax, mx);
+                atomicAdd(&rsum, sum);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n0 = red[0], n1 = red[1], n2 = red[2], p0 = red[3], p1 = red[4], p2 = red[5];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        totals[0] = n0;
+        totals[1] = n1;
+        totals[2] = n2;
+        totals[3] = rmax;
+        totals[4] = (uint32_t)(rsum & 0xffffffffull);
+        totals[5] = (uint32_t)(rsum >> 32);
+        totals[6] = n_raw;
+    }
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CLS_PER; ++k) {
+        c0 += cls[k] == 0;
+        c1 += cls[k] == 1;
+        c2 += cls[k] == 2;
+    }
+    unsigned tot;
+    const unsigned i01 = block_scan_incl(c0 | (c1 << 16), wt, tot);
+    const unsigned i2 = block_scan_incl(c2, wt, tot);
+    uint32_t r0 = p0 + (i01 & 0xffffu) - c0;
+    uint32_t r1 = p1 + (i01 >> 16) - c1;
+    uint32_t r2 = p2 + i2 - c2;
+#pragma unroll
+    for (uint32_t k = 0; k < CLS_PER; ++k) {
+        const uint32_t i = base + k;
+        if (i >= n) break;
+        const uint32_t c = cls[k];
+        const uint32_t j = class_order_pos(i, c, r0, r1, r2, n0, n1, n2);
+        perm[j] = i;
+        const uint32_t w = wgt[k];
+        nin_p[j] = (c >= 2 && w <= huge_w) ? w : 0u;
+        r0 += c == 0;
+        r1 += c == 1;
+        r2 += c == 2;
+    }
+}
+
 // The lane-per-item kernel runs a group of 64 items for as long as its longest item takes -- in batch order about twice the average.
 // Inside windows of LANE_SORT_WINDOW consecutive positions of the class order (two groups: the reads of a window still share their
 // descriptor / CIGAR / block-map cache lines) the items are therefore sorted by weight: a group of the longer and a group of the
@@ -692,6 +783,72 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in,
     unsigned inc = block_scan_incl(s, wt, tot);
     unsigned run = before + inc - s;
     if (base + SCAN_PER_THREAD <= n) {  // (two 16-byte stores; out comes from hipMalloc and base is a multiple of 8)
+        uint4 x, y;
+        x.x = run, x.y = x.x + v[0], x.z = x.y + v[1], x.w = x.z + v[2];
+        y.x = x.w + v[3], y.y = y.x + v[4], y.z = y.y + v[5], y.w = y.z + v[6];
+        *(uint4 *)(out + base) = x;
+        *(uint4 *)(out + base + 4) = y;
+    } else {
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+            if (base + k < n) out[base + k] = run;
+            run += v[k];
+        }
+    }
+}
+
+// The exclusive scan in ONE launch (decoupled look-back), an experiment of the one-round-trip path that stays switched off (PLO_SCAN_CHAIN=1):
+// two launches fewer, but the chain of look-backs costs more than their ~5 us each -- wgs30x 2 M reads (1 006 tiles): enumerate pass 0.273 ms
+// against 0.261, step 1.512 against 1.490 ms; 50 k-read window (25 tiles): 0.249-0.258 against 0.250 ms (tools/exp_scan.sh).
+// How it works: tiles of SCAN_BLOCK values take their number from a ticket, so a tile only ever waits for tiles that started before
+// it; a tile publishes {1, its sum}, looks back over the words of the tiles in front of it -- 64 at a time, one per lane of its first wave,
+// adding sums until a word {2, inclusive prefix} turns up -- and publishes {2, its inclusive prefix}.  State and value travel in one 64-bit
+// word (no ordering between two stores to rely on).  `state` (a word per tile) and `ticket` are zero at launch.  out[n] = the total.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const uint32_t *in, uint32_t n, uint32_t *out, unsigned long long *state, uint32_t *ticket) {
+    __shared__ unsigned wt[4];
+    __shared__ uint32_t sh_tile, sh_before;
+    if (threadIdx.x == 0) sh_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = sh_tile;
+    const uint32_t base = tile * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    load8(in, base, n, 0u, v);
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) s += v[k];
+    unsigned tot;
+    const unsigned inc = block_scan_incl(s, wt, tot);
+    if (threadIdx.x < 64u) {
+        const int lane = (int)threadIdx.x;
+        if (lane == 0) __hip_atomic_store(state + tile, ((tile ? 1ull : 2ull) << 32) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned before = 0;
+        if (tile) {
+            int j0 = (int)tile - 1;
+            for (;;) {
+                const int j = j0 - lane;
+                unsigned long long w = 2ull << 32;  // (in front of tile 0: a prefix of zero)
+                if (j >= 0) {
+                    for (;;) {
+                        w = __hip_atomic_load(state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((w >> 32) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const unsigned long long pm = __ballot((w >> 32) == 2ull);
+                const int first = pm ? __builtin_ctzll(pm) : 63;
+                before += (unsigned)wv::reduce_add((int)(lane <= first ? (unsigned)w : 0u));
+                if (pm) break;
+                j0 -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(before + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            sh_before = before;
+            if (tile + 1u == gridDim.x) out[n] = before + tot;
+        }
+    }
+    __syncthreads();
+    unsigned run = sh_before + inc - s;
+    if (base + SCAN_PER_THREAD <= n) {
         uint4 x, y;
         x.x = run, x.y = x.x + v[0], x.z = x.y + v[1], x.w = x.z + v[2];
         y.x = x.w + v[3], y.y = y.x + v[4], y.z = y.y + v[5], y.w = y.z + v[6];
@@ -1273,6 +1430,9 @@ struct plo_ctx {
         d_chrom_ref, d_chrom_ref_len, d_read_len;
     // outputs (device)
     DevBuf o_status, o_flip, o_mapq, o_chrom, o_pos, o_coff, o_clen, o_cigar, o_dense_off, o_cigar_dense, wave_stats;
+    DevBuf fast_blk;  // liftover_fast: class totals, validation flags and batch counters in one block (one fill, one copy back)
+    bool fast_timing = false;  // the last batch took liftover_fast: events 0, 1, 4 only
+    bool scan_chain = false;   // liftover_fast: the segments' item offsets by k_scan_chain (PLO_SCAN_CHAIN=1; measured slower than the three scan launches)
     // host staging for plo_liftover_batch
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
@@ -1568,6 +1728,7 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     if (const char *e = getenv("PLO_LANE_HEAVY_RATIO")) c->lane_heavy_ratio = std::max(0, atoi(e));
     if (const char *e = getenv("PLO_LANE_STREAM_RATIO")) c->lane_stream_ratio = std::max(1, atoi(e));
     if (const char *e = getenv("PLO_FAST_PATH")) c->fast = atoi(e) != 0;
+    if (const char *e = getenv("PLO_SCAN_CHAIN")) c->scan_chain = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1588,7 +1749,7 @@ void plo_ctx_destroy(plo_ctx *c) {
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_n_m, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
-                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
+                      &c->o_coff, &c->o_clen, &c->o_cigar, &c->o_dense_off, &c->o_cigar_dense, &c->wave_stats, &c->fast_blk, &c->i_read_rev, &c->i_read_len, &c->i_read_off, &c->i_seq,
                       &c->i_seg_read, &c->i_seg_contig, &c->i_seg_pos, &c->i_seg_fwd, &c->i_seg_coff, &c->i_cigar,
                       &c->i_item_seg, &c->i_item_cseg, &c->miss_list, &c->miss_info, &c->miss_vals, &c->miss_seq_off, &c->miss_side};
     for (DevBuf *b : bufs) b->release();
@@ -1721,6 +1882,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     const bool sp = in->seq_fmt == PLO_SEQ_BAM4_SPARSE;  // the `_sp` kernels: probes look granules up
     hipStream_t st = c->stream;
     memset(&c->timing, 0, sizeof(c->timing));
+    c->fast_timing = false;
     uint32_t n_syncs = 0;  // host round trips of the call
     c->ev_big = false;
     c->ev_mid = false;
@@ -2364,26 +2526,45 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     const DevIndex &ix = c->ix->d;
     hipStream_t st = c->stream;
     const uint32_t ns = in->n_segs, cap = c->fast_item_cap;
+    // Everything the kernels of this path count in, one block: cleared by ONE fill and read back by ONE copy (a launch of any size costs
+    // ~5 us on the stream: three fills and four copies were a quarter of a 50 k-read call's kernels, tools/trace_window.sh)
+    //   [0, 256) the class totals ([6] = the item count) and the lane kernel's group counter, [256, 272) the validation flags,
+    //   [512, 512 + 8 CNT_N) the batch counters
+    constexpr size_t FB_VERR = 256, FB_COUNTERS = 512, FB_BYTES = 1024, FB_BACK = FB_COUNTERS + CNT_N * 8;
+    static_assert(FB_BACK <= FB_BYTES, "fast block");
+    //   [288, 292) the scan's ticket, [FB_BYTES, ...) the scan's tile words
+    constexpr size_t FB_TICKET = 288;
+    const bool chain = c->scan_chain;
+    const uint32_t scan_nb = std::max(1u, (ns + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    const size_t fb_bytes = FB_BYTES + (chain ? (size_t)scan_nb * 8 : 0);
+    HIP_TRY(c, c->fast_blk.ensure(fb_bytes));
+    HIP_TRY(c, c->h_counters.ensure(FB_BYTES));
+    uint8_t *const fb = c->fast_blk.as<uint8_t>();
+    uint32_t *const misc_d = (uint32_t *)fb, *const verr_d = (uint32_t *)(fb + FB_VERR);
+    unsigned long long *const counters_d = (unsigned long long *)(fb + FB_COUNTERS);
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    HIP_TRY(c, hipMemsetAsync(c->verr.p, 0, 16, st));
-    HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 256, st));
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_N * 8, st));
+    HIP_TRY(c, hipMemsetAsync(fb, 0, fb_bytes, st));
     hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>(),
-                       c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->seg_nm.as<uint32_t>(), c->verr.as<uint32_t>());
-    plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
-    if (s != PLO_OK) return s;
-    const uint32_t *n_dev = c->seg_off.as<uint32_t>() + ns, *totals_dev = c->misc.as<uint32_t>();
+                       c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->seg_nm.as<uint32_t>(), verr_d);
+    if (chain) {
+        hipLaunchKernelGGL(k_scan_chain, dim3(scan_nb), dim3(SCAN_THREADS), 0, st, (const uint32_t *)c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>(),
+                           (unsigned long long *)(fb + FB_BYTES), (uint32_t *)(fb + FB_TICKET));
+    } else {
+        plo_status s = scan_u32(c, c->seg_cnt.as<uint32_t>(), ns, c->seg_off.as<uint32_t>());
+        if (s != PLO_OK) return s;
+    }
+    const uint32_t *n_dev = c->seg_off.as<uint32_t>() + ns, *totals_dev = misc_d;
     DevWork wk;
     fill_work(c, wk, cap);
+    wk.counters = counters_d;
     hipLaunchKernelGGL(k_item_emit, dim3((ns + 255) / 256), dim3(256), 0, st, ix, bt, wk, stages, (const uint32_t *)c->seg_off.as<uint32_t>(), c->seg_reflen.as<int>(),
-                       cap, c->verr.as<uint32_t>());
+                       cap, verr_d);
     const uint32_t cls_nb = (cap + CLS_BLOCK - 1) / CLS_BLOCK;
     HIP_TRY(c, c->cls_partial.ensure((size_t)std::max(1u, cls_nb) * 6 * 4));
     hipLaunchKernelGGL(k_cls_hist, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(), cap,
                        cls_nb, c->cls_partial.as<uint32_t>(), n_dev);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_THREADS), 0, st, c->cls_partial.as<uint32_t>(), cls_nb, c->misc.as<uint32_t>());
-    hipLaunchKernelGGL(k_permute2, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
-                       (const uint32_t *)c->cls_partial.as<uint32_t>(), (const uint32_t *)c->misc.as<uint32_t>(), cap, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
+    hipLaunchKernelGGL(k_permute2_s, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
+                       (const uint32_t *)c->cls_partial.as<uint32_t>(), misc_d, cap, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
                        c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu, n_dev);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     // launch geometry from the last batch's class counts (a window of the same shape has the same): group size, persistent grid
@@ -2408,7 +2589,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     wk.slab_pre = 1u;
     wk.slab_offset = (unsigned long long)lane_nblk * LANE_WAVES * SLAB_OPS;
     wk.n_small = cap;  // (unused by the lane kernel; the retry kernel's tiles take their items from the retry list)
-    wk.lane_n_groups = c->misc.as<uint32_t>() + 32;
+    wk.lane_n_groups = misc_d + 32;
     wk.stat_base = 0;
     uint32_t stat_used = lane_nblk * LANE_WAVES;
     if (wk.slab_offset + SLAB_OPS > wk.out_cap) {  // the output buffer of the last batch does not even hold the waves' first slabs
@@ -2421,8 +2602,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     }
     hipLaunchKernelGGL(k_lift_lanes, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
     {
         const int retry_cap = 320;
         const uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15), nw = (uint32_t)c->n_cus * 2u;
@@ -2431,17 +2611,15 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
         hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, 256, retry_cap);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(c->ev[5], st));
     hipLaunchKernelGGL(k_sum_stats, dim3(std::min<uint32_t>((stat_used + 255) / 256, 16u)), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), stat_used,
-                       c->counters.as<unsigned long long>());
-    // the one look: counters, item count, validation flags, class totals
-    unsigned long long *hc = c->h_counters.as<unsigned long long>();
-    uint32_t *hx = (uint32_t *)(hc + CNT_N);
-    HIP_TRY(c, hipMemcpyAsync(hc, c->counters.p, CNT_N * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hx, n_dev, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hx + 1, c->verr.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hx + 2, c->misc.p, 6 * 4, hipMemcpyDeviceToHost, st));
+                       counters_d);
+    // the one look: class totals and item count, validation flags, counters
+    uint8_t *const hb = c->h_counters.as<uint8_t>();
+    HIP_TRY(c, hipMemcpyAsync(hb, fb, FB_BACK, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    const unsigned long long *hc = (const unsigned long long *)(hb + FB_COUNTERS);
+    const uint32_t *const hm = (const uint32_t *)hb;
+    const uint32_t hx[8] = {hm[6], *(const uint32_t *)(hb + FB_VERR), hm[0], hm[1], hm[2], hm[3], hm[4], hm[5]};
     const uint32_t n_items = hx[0], verr = hx[1], n0 = hx[2], n1 = hx[3];
     if (verr & (VERR_INDEX | VERR_RANGE)) {
         if (verr & VERR_INDEX) {
@@ -2470,6 +2648,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     c->timing.algo_bytes = hc[CNT_ALGO_BYTES];
     c->timing.lane_utilisation = hc[CNT_LANE_TRIPS] ? (float)((double)hc[CNT_LANE_ACT] / (64.0 * (double)hc[CNT_LANE_TRIPS])) : 0.0f;
     c->timing.host_syncs = 1;
+    c->fast_timing = true;
     for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
     c->fast_n0 = n0;
     c->fast_n1 = n1;
@@ -2856,8 +3035,10 @@ plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     float a = 0, l = 0, b = 0, r = 0, g = 0, md = 0;
     (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&l, c->ev[1], c->ev[4]);
-    (void)hipEventElapsedTime(&b, c->ev[4], c->ev[2]);
-    (void)hipEventElapsedTime(&r, c->ev[2], c->ev[5]);
+    if (!c->fast_timing) {  // (liftover_fast records events 0, 1 and 4 only: its retry launch and the counters' sum are not timed)
+        (void)hipEventElapsedTime(&b, c->ev[4], c->ev[2]);
+        (void)hipEventElapsedTime(&r, c->ev[2], c->ev[5]);
+    }
     if (c->ev_mid) (void)hipEventElapsedTime(&md, c->ev[5], c->ev[6]);
     if (c->ev_big) (void)hipEventElapsedTime(&g, c->ev_mid ? c->ev[6] : c->ev[5], c->ev[3]);
     c->timing.enumerate_ms = a;

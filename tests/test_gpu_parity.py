@@ -311,7 +311,9 @@ def _full_size(name, oracle, n_blocks, block, min_lifted=0.95, threads=8, **over
     assert (res2.item_status == res.item_status).all()
     for i in range(0, res.n_items, 97):
         assert np.array_equal(res.item_cigar(i), res2.item_cigar(i))
-    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, n_blocks, block, threads=threads)
+    # (the oracle sample is taken from the SECOND call's results: on wgs30x that is the one-round-trip path -- one-launch scan, fused class
+    # kernels -- at 1 006 scan tiles and 1 012 class blocks)
+    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res2, oracle, n_blocks, block, threads=threads)
     _dump(f"full_size_{name}.json", {"reads": w.n_reads, "items": int(res.n_items), "items_compared_with_oracle": n_cmp,
                                      "of_them_flipped": n_flip, "contigs_in_sample": n_contigs, "large_items": int(t.n_big_items),
                                      "mid_items": int(getattr(t, "n_mid_items", 0)), "retry_items": int(t.n_retry_items),
@@ -762,6 +764,17 @@ def test_one_host_round_trip_path(oracle, monkeypatch):
             assert got.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
         assert syncs3[1] == 1 and syncs3[2] >= 3 and syncs3[3] == 1, (syncs3, shapes[a], shapes[b])
         eng3.close()
+    # the one-launch scan of the segments' item offsets (k_scan_chain, an experiment that stays switched off) gives the same results
+    monkeypatch.setenv("PLO_SCAN_CHAIN", "1")
+    eng4 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    for lo, hi in [(0, 30000), (0, 30000), (2000, 29000)]:
+        db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+        torch.cuda.synchronize()
+        got4 = devbatch.run_and_download(eng4, db)
+        assert got4.canonical() == oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8).canonical()
+    assert int(eng4.timing().host_syncs) == 1
+    eng4.close()
+    monkeypatch.delenv("PLO_SCAN_CHAIN")
     # the same batches with the path switched off give the same results (and three round trips)
     monkeypatch.setenv("PLO_FAST_PATH", "0")
     eng2 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
