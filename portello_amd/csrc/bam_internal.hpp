@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -236,7 +237,7 @@ struct BgzfIn {
     const uint8_t *map = nullptr;
     size_t size = 0, cpos = 0;
     RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
-    RawBuf cstage2[2];  // device inflate: page-locked copies of two groups' compressed bytes
+    RawBuf cstage3[3];  // device inflate: page-locked copies of three groups' compressed bytes (two on the device, the third being staged)
     size_t bpos = 0;
     int threads = 1;
     bool eof = false;
@@ -244,6 +245,19 @@ struct BgzfIn {
     int dev_id = 0;  // HIP device of the device inflate
     int device = -1;  // -1 undecided (environment), -2 undecided (requested), 0 host inflate, 1 blocks are inflated on the GPU
     static constexpr size_t CHUNK = 256u << 20;
+    // Inflated bytes a refill adds.  On the device a refill's groups of blocks run two at a time and the pair in flight drains at the end of
+    // every refill: the first refill stays at CHUNK (the first window is out after one group's latency), the later ones take `later_chunk`
+    // (PLO_BGZF_CHUNK_MB), so that the drain is paid once per gigabyte instead of once per two groups.
+    size_t later_chunk = 0, n_fills = 0;
+    size_t chunk_now() {
+        if (!later_chunk) {
+            const char *e = getenv("PLO_BGZF_CHUNK_MB");
+            const long mb = e ? atol(e) : 0;
+            later_chunk = mb >= 64 && mb <= 8192 ? (size_t)mb << 20 : (device == 1 ? DEVICE_CHUNK : CHUNK);
+        }
+        return n_fills == 0 ? CHUNK : later_chunk;
+    }
+    static constexpr size_t DEVICE_CHUNK = 256u << 20;
     // A PART of the file (plo_bam_open_range): records whose first byte lies in a BGZF block that starts in [range_lo, range_end) of the
     // compressed file.  `blkmap`: where in `buf` every block of the current contents starts and where that block starts in the file.
     size_t range_end = (size_t)-1;
@@ -336,6 +350,10 @@ struct BgzfIn {
     // makes at least `want` bytes available (fewer only at the end of the file)
     plo_status fill(size_t want) {
         if (avail() >= want || eof) return PLO_OK;
+        const bool dbgf = getenv("PLO_DEBUG_READER") != nullptr;  // where a refill's time goes: tail move / header walk / buffer / staging / waits
+        auto clk = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tf0 = dbgf ? clk() : 0;
+        double tf_stage = 0, tf_wait = 0;
         if (bpos) {
             // (the unconsumed tail to the front: with several threads when it does not overlap its new place -- the usual case, a window
             // has just been cut off the front -- it used to be a single-threaded memmove of up to a refill's 256 MB)
@@ -351,6 +369,7 @@ struct BgzfIn {
             }
             bpos = 0;
         }
+        const double tf1 = dbgf ? clk() : 0;
         const size_t cpos0 = cpos;
         if (device < 0) {
             // opt-in (PLO_BGZF_DEVICE=1): measured on MI355X the kernel inflates 20 GB/s, three times what 16 host cores do with
@@ -378,7 +397,8 @@ struct BgzfIn {
         size_t u = buf.size();
         // always a whole chunk of NEW data: a window larger than one chunk must not degenerate into one small refill (thread
         // start-up, or a device round trip) per record
-        const size_t target = std::max(want, u + CHUNK);
+        const size_t target = std::max(want, u + chunk_now());
+        ++n_fills;
         // device inflate: whole rounds of resident waves -- a group takes one block's decode time (~7 ms) however few blocks it has, so
         // the refill goes on to the next multiple of the wave slots (17 blocks left over used to cost a round of their own)
         if (device == 1 && !dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
@@ -408,9 +428,11 @@ struct BgzfIn {
             cpos += bsize;
             blks.push_back(b);
         }
+        const double tf2 = dbgf ? clk() : 0;
         if (cpos >= size) eof = true;
         if (cpos > cpos0) madvise((void *)(map + (cpos0 & ~(size_t)4095)), cpos - (cpos0 & ~(size_t)4095), MADV_WILLNEED);
         if (!buf.resize(u)) return fail(PLO_ERR_OUT_OF_MEMORY, "out of host memory for the inflated BAM stream");
+        const double tf3 = dbgf ? clk() : 0;
         std::atomic<int> bad{0};
         if (device == 1 && !blks.empty()) {
             // On the GPU, in groups of one block per resident wave (a group of exactly that many has no second, nearly empty round),
@@ -424,7 +446,23 @@ struct BgzfIn {
             // PLO_BGZF_HOST_CRC=1: the CRCs are checked on the host as in round 4 (the device's check is then skipped)
             const bool host_crc = getenv("PLO_BGZF_HOST_CRC") != nullptr;
             int rc = 0;
-            auto begin = [&](size_t g) -> int {
+            // stage(g): the group's compressed bytes into page-locked buffer g % 3 -- host work only, done one group AHEAD of the device slots
+            // (while groups g - 2 and g - 1 are on the device; round 5 staged inside begin(), between two waits: the device idled for it);
+            // enqueue(g): upload, kernels and download of a staged group on slot g & 1
+            auto stage = [&](size_t g) -> int {
+                const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
+                const size_t c0 = blks[lo].coff;
+                const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0;
+                RawBuf &cs = cstage3[g % 3];
+                cs.pinned = true;
+                if (!cs.resize(cbytes + 16)) return -101;
+                // compressed bytes: positional reads straight into the page-locked stage (round 4 copied them out of the file mapping)
+                const double ts0 = dbgf ? clk() : 0;
+                if (!parallel_pread(fd, cs.data(), c0, cbytes, threads)) parallel_copy(cs.data(), map + c0, cbytes, threads);
+                if (dbgf) tf_stage += clk() - ts0;
+                return 0;
+            };
+            auto enqueue = [&](size_t g) -> int {
                 const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
                 const size_t c0 = blks[lo].coff, u0 = blks[lo].uoff;
                 std::vector<DevBlk> &d = db[g & 1];
@@ -436,15 +474,12 @@ struct BgzfIn {
                     dc[i - lo] = blks[i].crc;
                 }
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0, ubytes = blks[hi - 1].uoff + blks[hi - 1].ulen - u0;
-                RawBuf &cs = cstage2[g & 1];
-                cs.pinned = true;
-                if (!cs.resize(cbytes + 16)) return -101;
-                // compressed bytes: positional reads straight into the page-locked stage (round 4 copied them out of the file mapping)
-                if (!parallel_pread(fd, cs.data(), c0, cbytes, threads)) parallel_copy(cs.data(), map + c0, cbytes, threads);
-                return plo_internal_bgzf_begin((int)(g & 1), cs.data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
+                return plo_internal_bgzf_begin((int)(g & 1), cstage3[g % 3].data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
             };
             auto finish = [&](size_t g) -> int {
+                const double tw0 = dbgf ? clk() : 0;
                 int r = plo_internal_bgzf_wait((int)(g & 1));
+                if (dbgf) tf_wait += clk() - tw0;
                 if (r) return r;
                 if (!host_crc) return 0;  // (k_bgzf_crc has checked every block: a mismatch came back as the group's status)
                 const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
@@ -456,20 +491,25 @@ struct BgzfIn {
             };
             plo_internal_bgzf_acquire();
             rc = plo_internal_bgzf_set_device(dev_id);
-            if (rc == 0) rc = begin(0);
+            // groups g and g + 1 on the device, g + 2 staged while they run: enqueue(g + 2) follows finish(g) at once
+            if (rc == 0) rc = stage(0);
+            if (rc == 0) rc = enqueue(0);
+            if (rc == 0 && ng > 1) rc = stage(1);
+            if (rc == 0 && ng > 1) rc = enqueue(1);
             for (size_t g = 0; g < ng && rc == 0; ++g) {
-                int rn = g + 1 < ng ? begin(g + 1) : 0;
+                int rs = g + 2 < ng ? stage(g + 2) : 0;
                 rc = finish(g);
-                if (rc == 0 && rn != 0) {
-                    (void)plo_internal_bgzf_wait((int)((g + 1) & 1));
-                    rc = rn;
-                }
+                if (rc == 0) rc = rs;
+                if (rc == 0 && g + 2 < ng) rc = enqueue(g + 2);
             }
             if (rc != 0) {  // leave nothing in flight
                 (void)plo_internal_bgzf_wait(0);
                 (void)plo_internal_bgzf_wait(1);
             }
             plo_internal_bgzf_release();
+            if (dbgf)
+                fprintf(stderr, "[plo] refill: %zu blocks in %zu groups, %.3f s: tail move %.4f, header walk %.4f, buffer %.4f, staging %.4f, waits %.4f, rest %.4f\n", blks.size(), ng,
+                        clk() - tf0, tf1 - tf0, tf2 - tf1, tf3 - tf2, tf_stage, tf_wait, (clk() - tf3) - tf_stage - tf_wait);
             if (rc == 0) {
                 if (bad) return fail(PLO_ERR_IO, "BGZF block CRC mismatch after device inflate");
                 return PLO_OK;

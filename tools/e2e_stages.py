@@ -51,6 +51,22 @@ try:
                     best = (t, tb)
             print(f"reader alone ({threads} threads){' + batch construction in the same thread' if with_batch else ''}: {k} reads in {best[0]:.3f} s = "
                   f"{k / best[0] / 1e3:.0f} k reads/s" + (f" (batch construction {best[1]:.3f} s)" if with_batch else ""), flush=True)
+    if os.environ.get("PLO_E2E_WRITER_AB"):
+        # the writer's variants, same pipeline otherwise (two lift workers, a new output file per run)
+        for env in ({}, {"PLO_BGZF_CHUNK_MB": "1024"}, {"PLO_BGZF_CHUNK_MB": "1024", "PLO_BGZF_FALLOCATE": "1"}, {"PLO_BGZF_CHUNK_MB": "2048", "PLO_BGZF_FALLOCATE": "1"}, {}):
+            for k in ("PLO_BGZF_FALLOCATE", "PLO_BGZF_COPY_BLOCKS", "PLO_BGZF_CHUNK_MB"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            best = None
+            for r in range(4):
+                outp = os.path.join(d, f"w_{r}.bam")
+                st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, rl, device_finish=True, window_reads=7500, io_threads=16, n_workers=2)
+                os.unlink(outp)
+                if best is None or st.seconds < best.seconds:
+                    best = st
+            print(f"writer {env or 'default'}: {best.reads / best.seconds / 1e3:.1f} k reads/s ({best.seconds:.3f} s; busy: read {best.read_s:.2f} batch {best.batch_s:.2f} "
+                  f"lift {best.lift_s:.2f} build {best.build_s:.2f} write {best.write_s:.2f}); done at: " + ", ".join(f"{k} {v:.3f}" for k, v in best.stage_done_s.items()), flush=True)
+        sys.exit(0)
     for kw in (dict(n_workers=2), dict(n_workers=4), dict(n_workers=3, read_threads=16, build_threads=4, write_threads=16)):
         a = dict(window_reads=7500, io_threads=16)
         a.update(kw)

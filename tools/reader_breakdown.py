@@ -41,16 +41,32 @@ try:
     inp = os.path.join(d, "reads.bam")
     lo = (w.n_reads - n) // 2
     bamsynth.write_read_bam(w, inp, lo, lo + n, level=1, n_threads=16)
-    for threads in (8, 16):
+    for threads, chunk in ((16, 0),) if os.environ.get("PLO_DEBUG_INFLATE") else ((8, 0), (16, 0), (16, 1024)):
         e = dict(os.environ, PLO_DEBUG_READER="1")
+        if chunk:
+            e["PLO_BGZF_CHUNK_MB"] = str(chunk)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", inp, str(threads)], env=e, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=300)
         runs = r.stderr.split("RUN ")
         last = runs[-2] if len(runs) >= 2 else r.stderr  # the lines in front of the last "RUN": the second pass
         f = w_ = c = 0.0
         for m in re.finditer(r"inflate \(fill\) ([0-9.]+) s, record walk ([0-9.]+) s, copy ([0-9.]+) s", last):
             f += float(m.group(1)); w_ += float(m.group(2)); c += float(m.group(3))
-        print(f"{threads} threads: {[x.splitlines()[0] for x in runs[1:]]}; second pass: inflate (fill) {f:.3f} s, record walk {w_:.3f} s, window copy {c:.3f} s", flush=True)
+        print(f"{threads} threads, refills of {chunk or 256} MB: {[x.splitlines()[0] for x in runs[1:]]}; second pass: inflate (fill) {f:.3f} s, record walk {w_:.3f} s, window copy {c:.3f} s", flush=True)
         other = [ln for ln in last.splitlines() if "[plo]" in ln and "read_window" not in ln]
         print("\n".join(other[:12]), flush=True)
+        acc = [0.0] * 7
+        nf = 0
+        for m in re.finditer(r"refill: \d+ blocks in \d+ groups, ([0-9.]+) s: tail move ([0-9.]+), header walk ([0-9.]+), buffer ([0-9.]+), staging ([0-9.]+), waits ([0-9.]+), rest (-?[0-9.]+)", last):
+            for q in range(7):
+                acc[q] += float(m.group(q + 1))
+            nf += 1
+        if nf:
+            print(f"{nf} refills, {acc[0]:.3f} s: tail move {acc[1]:.3f}, header walk {acc[2]:.3f}, buffer {acc[3]:.3f}, staging {acc[4]:.3f}, waits {acc[5]:.3f}, rest {acc[6]:.3f}", flush=True)
+        h = k = dd = 0.0
+        n = 0
+        for m in re.finditer(r"H2D ([0-9.]+) ms, kernel ([0-9.]+) ms, D2H ([0-9.]+) ms", last):
+            h += float(m.group(1)); k += float(m.group(2)); dd += float(m.group(3)); n += 1
+        if n:
+            print(f"device inflate, {n} groups: H2D {h:.1f} ms, kernels {k:.1f} ms, D2H {dd:.1f} ms in all (per group {h / n:.2f} / {k / n:.2f} / {dd / n:.2f})", flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)
