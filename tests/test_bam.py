@@ -115,6 +115,26 @@ def test_writer_output_is_a_valid_bam_and_reader_round_trips(small_bam, tmp_path
     assert bamcheck.read_bam(p0)[2] == recs
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_writer_with_blocks_reserved_ahead_writes_the_same_file(small_bam, tmp_path, monkeypatch, level):
+    """PLO_BGZF_FALLOCATE=1 (the output's blocks reserved a gigabyte ahead of the writes, FALLOC_FL_KEEP_SIZE): the same bytes, and the file
+    ends where its last block ends -- what was reserved behind it is given back when the writer closes"""
+    _, path, _ = small_bam
+    text, refs, recs = bamcheck.read_bam(path)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PLO_BGZF_FALLOCATE", mode)
+        p = str(tmp_path / f"reserved_{mode}.bam")
+        wr = bam.BamWriter(p, text, [n for n, _ in refs], [l for _, l in refs], level=level, n_threads=3)
+        for k in range(0, len(recs), 50):  # several writes: blocks straddle them
+            wr.write(b"".join(recs[k:k + 50]))
+        wr.close()
+        out[mode] = open(p, "rb").read()
+        st = os.stat(p)
+        assert st.st_size == len(out[mode]) and st.st_blocks * 512 < st.st_size + (8 << 20)  # (no gigabyte left allocated behind the end)
+    assert out["0"] == out["1"] and bamcheck.read_bam(str(tmp_path / "reserved_1.bam"))[2] == recs
+
+
 def test_window_batch_matches_python_split_segments(small_bam):
     w, path, meta = small_bam
     _, _, recs = bamcheck.read_bam(path)
