@@ -1126,8 +1126,8 @@ struct plo_bam_writer {
     RawBuf scratch;
     static constexpr size_t BLOCK = 0xff00;  // htslib's BGZF_BLOCK_SIZE
     plo_status emit(const uint8_t *src, size_t n);  // n bytes -> ceil(n / BLOCK) BGZF blocks, written out
-    // PLO_BGZF_FALLOCATE=1: the file's blocks are reserved ahead of the writes (FALLOC_FL_KEEP_SIZE, a gigabyte or more at a time; what is
-    // left over is given back when the writer closes).  Buffered writes into ONE file are serialised by the inode's lock whatever the number of
+    // The file's blocks are reserved ahead of the writes (FALLOC_FL_KEEP_SIZE, a gigabyte or more at a time; what is left over is given back
+    // when the writer closes; PLO_BGZF_FALLOCATE=0 switches it off, a filesystem without fallocate does so by itself).  Buffered writes into ONE file are serialised by the inode's lock whatever the number of
     // threads (tools/write_bench.cpp on the GPU box: 9.5 GB/s into one file, 61-126 GB/s into one file per thread); reserved blocks shorten
     // the time under the lock by the allocation (10.0-10.8 GB/s there).
     uint64_t reserved = 0;
@@ -1136,7 +1136,7 @@ struct plo_bam_writer {
         if (!seekable || falloc == 0) return;
         if (falloc < 0) {
             const char *e = getenv("PLO_BGZF_FALLOCATE");
-            falloc = (e && atoi(e) != 0) ? 1 : 0;
+            falloc = (e && atoi(e) == 0) ? 0 : 1;
             if (!falloc) return;
         }
         if (upto <= reserved) return;

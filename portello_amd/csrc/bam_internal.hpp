@@ -238,6 +238,18 @@ struct BgzfIn {
     size_t size = 0, cpos = 0;
     RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
     RawBuf cstage3[3];  // device inflate: page-locked copies of three groups' compressed bytes (two on the device, the third being staged)
+    uint32_t stage_base = 0;  // staging buffer of a refill's group g: (stage_base + g) % 3
+    // The NEXT refill, prepared while the last groups of this one are on the device and the host would only wait (device inflate): its block
+    // headers walked (a page fault per block on the file mapping) and its first one or two groups staged.  Used by the next fill() when the
+    // stream is still where the walk began (restart_at drops it).  PLO_BGZF_NO_PREFETCH=1 switches it off.
+    struct NextBlk {
+        size_t coff, clen, urel, ulen, fpos;
+        uint32_t crc;
+    };
+    std::vector<NextBlk> nx_blks;
+    size_t nx_pos0 = 0, nx_pos_end = 0;
+    uint32_t nx_staged = 0;
+    bool nx_valid = false;
     size_t bpos = 0;
     int threads = 1;
     bool eof = false;
@@ -313,6 +325,8 @@ struct BgzfIn {
         blkmap.clear();
         cpos = at;
         eof = cpos >= size;
+        nx_valid = false;
+        nx_staged = 0;
     }
     struct DevBlk {  // engine.hip's BgzfBlk
         unsigned long long coff, uoff;
@@ -403,6 +417,24 @@ struct BgzfIn {
         // the refill goes on to the next multiple of the wave slots (17 blocks left over used to cost a round of their own)
         if (device == 1 && !dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
         const size_t round_to = device == 1 ? dev_slots : 1;
+        uint32_t pre_staged = 0;  // leading groups of this refill whose compressed bytes are in their staging buffers already
+        if (nx_valid && device == 1 && nx_pos0 == cpos && !nx_blks.empty()) {
+            for (const NextBlk &nb : nx_blks) {
+                Blk b;
+                b.coff = nb.coff;
+                b.clen = nb.clen;
+                b.crc = nb.crc;
+                b.ulen = nb.ulen;
+                b.uoff = u + nb.urel;
+                if (ranged && b.ulen) blkmap.emplace_back(b.uoff, nb.fpos);
+                blks.push_back(b);
+            }
+            u += nx_blks.back().urel + nx_blks.back().ulen;
+            cpos = nx_pos_end;
+            pre_staged = nx_staged;
+        }
+        nx_valid = false;
+        nx_staged = 0;
         while (cpos < size && (u < target || blks.size() % round_to != 0)) {
             if (size - cpos < 28) return fail(PLO_ERR_IO, "truncated BGZF block header");
             const uint8_t *h = map + cpos;
@@ -453,7 +485,8 @@ struct BgzfIn {
                 const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
                 const size_t c0 = blks[lo].coff;
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0;
-                RawBuf &cs = cstage3[g % 3];
+                if (g < pre_staged) return 0;  // (staged while the last refill's final groups were on the device)
+                RawBuf &cs = cstage3[(stage_base + g) % 3];
                 cs.pinned = true;
                 if (!cs.resize(cbytes + 16)) return -101;
                 // compressed bytes: positional reads straight into the page-locked stage (round 4 copied them out of the file mapping)
@@ -474,7 +507,7 @@ struct BgzfIn {
                     dc[i - lo] = blks[i].crc;
                 }
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0, ubytes = blks[hi - 1].uoff + blks[hi - 1].ulen - u0;
-                return plo_internal_bgzf_begin((int)(g & 1), cstage3[g % 3].data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
+                return plo_internal_bgzf_begin((int)(g & 1), cstage3[(stage_base + g) % 3].data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
             };
             auto finish = [&](size_t g) -> int {
                 const double tw0 = dbgf ? clk() : 0;
@@ -491,13 +524,75 @@ struct BgzfIn {
             };
             plo_internal_bgzf_acquire();
             rc = plo_internal_bgzf_set_device(dev_id);
+            // the next refill's headers and first groups, in the time the host would wait for this refill's last groups
+            double tf_pre = 0;
+            auto prestage_upto = [&](size_t kmax) {
+                if (cpos >= size || getenv("PLO_BGZF_NO_PREFETCH")) return;
+                const double tp0 = dbgf ? clk() : 0;
+                if (!nx_valid) {
+                    nx_blks.clear();
+                    nx_pos0 = cpos;
+                    nx_staged = 0;
+                    size_t pos = cpos, ur = 0;
+                    const size_t chunk = chunk_now();
+                    bool ok = true;
+                    while (pos < size && (ur < chunk || nx_blks.size() % dev_slots != 0)) {
+                        if (size - pos < 28) { ok = false; break; }
+                        const uint8_t *h = map + pos;
+                        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { ok = false; break; }
+                        const uint32_t xlen = rd16(h + 10);
+                        uint32_t bsize = 0;
+                        if (12 + (size_t)xlen > size - pos) { ok = false; break; }
+                        for (uint32_t x = 0; x + 4 <= xlen;) {
+                            const uint8_t *e = h + 12 + x;
+                            const uint32_t slen = rd16(e + 2);
+                            if (e[0] == 'B' && e[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint32_t)rd16(e + 4) + 1;
+                            x += 4 + slen;
+                        }
+                        if (bsize < 12 + xlen + 8 || bsize > size - pos) { ok = false; break; }
+                        NextBlk nb;
+                        nb.coff = pos + 12 + xlen;
+                        nb.clen = bsize - 12 - xlen - 8;
+                        nb.crc = rd32(h + bsize - 8);
+                        nb.ulen = rd32(h + bsize - 4);
+                        nb.urel = ur;
+                        nb.fpos = pos;
+                        if (nb.ulen > 65536) { ok = false; break; }
+                        ur += nb.ulen;
+                        pos += bsize;
+                        nx_blks.push_back(nb);
+                    }
+                    if (!ok || nx_blks.empty()) {  // (an irregular block: the next fill() walks the headers itself and reports it)
+                        nx_blks.clear();
+                        if (dbgf) tf_pre += clk() - tp0;
+                        return;
+                    }
+                    nx_pos_end = pos;
+                    nx_valid = true;
+                }
+                while (nx_staged <= kmax) {
+                    const size_t lo = (size_t)nx_staged * dev_slots;
+                    if (lo >= nx_blks.size()) break;
+                    const size_t hi = std::min(nx_blks.size(), lo + dev_slots);
+                    if (hi - lo < dev_slots && nx_pos_end < size) break;  // (only groups that are final: full, or cut by the end of the file)
+                    const size_t c0 = nx_blks[lo].coff, cbytes = nx_blks[hi - 1].coff + nx_blks[hi - 1].clen - c0;
+                    RawBuf &cs = cstage3[(stage_base + ng + nx_staged) % 3];
+                    cs.pinned = true;
+                    if (!cs.resize(cbytes + 16)) break;
+                    if (!parallel_pread(fd, cs.data(), c0, cbytes, threads)) parallel_copy(cs.data(), map + c0, cbytes, threads);
+                    ++nx_staged;
+                }
+                if (dbgf) tf_pre += clk() - tp0;
+            };
             // groups g and g + 1 on the device, g + 2 staged while they run: enqueue(g + 2) follows finish(g) at once
             if (rc == 0) rc = stage(0);
             if (rc == 0) rc = enqueue(0);
             if (rc == 0 && ng > 1) rc = stage(1);
             if (rc == 0 && ng > 1) rc = enqueue(1);
             for (size_t g = 0; g < ng && rc == 0; ++g) {
-                int rs = g + 2 < ng ? stage(g + 2) : 0;
+                int rs = 0;
+                if (g + 2 < ng) rs = stage(g + 2);
+                else prestage_upto(std::min<size_t>(1, g + 2 - ng));  // (buffer of next group k: free once this refill's group ng + k - 3 is done, k <= g + 2 - ng)
                 rc = finish(g);
                 if (rc == 0) rc = rs;
                 if (rc == 0 && g + 2 < ng) rc = enqueue(g + 2);
@@ -507,9 +602,14 @@ struct BgzfIn {
                 (void)plo_internal_bgzf_wait(1);
             }
             plo_internal_bgzf_release();
+            if (rc != 0) {  // (what was prepared lies in buffers counted from this refill's groups: dropped with it)
+                nx_valid = false;
+                nx_staged = 0;
+            }
+            stage_base = (uint32_t)((stage_base + ng) % 3);
             if (dbgf)
-                fprintf(stderr, "[plo] refill: %zu blocks in %zu groups, %.3f s: tail move %.4f, header walk %.4f, buffer %.4f, staging %.4f, waits %.4f, rest %.4f\n", blks.size(), ng,
-                        clk() - tf0, tf1 - tf0, tf2 - tf1, tf3 - tf2, tf_stage, tf_wait, (clk() - tf3) - tf_stage - tf_wait);
+                fprintf(stderr, "[plo] refill: %zu blocks in %zu groups, %.3f s: tail move %.4f, header walk %.4f, buffer %.4f, staging %.4f, waits %.4f, rest %.4f (next refill prepared in %.4f, %u groups staged)\n", blks.size(), ng,
+                        clk() - tf0, tf1 - tf0, tf2 - tf1, tf3 - tf2, tf_stage, tf_wait, (clk() - tf3) - tf_stage - tf_wait, tf_pre, nx_staged);
             if (rc == 0) {
                 if (bad) return fail(PLO_ERR_IO, "BGZF block CRC mismatch after device inflate");
                 return PLO_OK;

@@ -469,6 +469,50 @@ def test_device_inflate_matches_host_inflate(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level", [0, 1])
+def test_device_inflate_over_several_refills(tmp_path, monkeypatch, level):
+    """A file of several refills through the device inflate: groups of 2 048 blocks on two device slots, the next group staged while they run,
+    the NEXT REFILL's headers walked and first groups staged while the last groups are waited for (bam_internal.hpp, BgzfIn::fill).  Stored
+    blocks make refills of three groups, compressed ones of two, refills of 64 MB of one; every combination gives the records the host inflate
+    gives, whole file and as three parts (a part starts with restart_at, which drops what was prepared)."""
+    import hashlib
+
+    w = synth.generate(synth.config("chr20", n_reads=26_000, seed=431), device="cuda")
+    path = str(tmp_path / f"big{level}.bam")
+    bamsynth.write_read_bam(w, path, level=level, n_threads=8)
+
+    def read_all(device, part=None, n_parts=1):
+        rd = bam.BamReader(path, 8, device_inflate=device, part=part, n_parts=n_parts)
+        out = []
+        while True:
+            win = rd.read_window(3000)
+            if win is None:
+                break
+            b = win.batch_data()
+            h = hashlib.sha1()
+            for a in (b.seq, b.cigar, b.seg_pos, b.read_seq_len):
+                h.update(a.tobytes())
+            out.append((b.n_reads, h.hexdigest(), win.unmapped_bytes()))
+            win.close()
+        rd.close()
+        return out
+
+    want = read_all(-1)
+    assert sum(x[0] for x in want) == w.n_reads
+    want_parts = [read_all(-1, k, 3) for k in range(3)]
+    assert sum(x[0] for p_ in want_parts for x in p_) == w.n_reads
+    for chunk in (None, "64"):
+        for no_prefetch in (None, "1"):
+            for name, val in (("PLO_BGZF_CHUNK_MB", chunk), ("PLO_BGZF_NO_PREFETCH", no_prefetch)):
+                if val is None:
+                    monkeypatch.delenv(name, raising=False)
+                else:
+                    monkeypatch.setenv(name, val)
+            assert read_all(0) == want, (level, chunk, no_prefetch)
+            assert [read_all(0, k, 3) for k in range(3)] == want_parts, (level, chunk, no_prefetch)
+
+
+@pytest.mark.gpu
 def test_device_crc_rejects_a_block_whose_bytes_or_crc_were_changed(tmp_path, monkeypatch):
     """k_bgzf_crc (a wave per inflated block behind k_bgzf_inflate): a BGZF block whose stored CRC-32 -- or whose data, in a stored block --
     was changed must fail the read with device inflate exactly as on the host, and the untouched file reads the same with the device's check
