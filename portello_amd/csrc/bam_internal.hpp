@@ -239,6 +239,21 @@ struct BgzfIn {
     RawBuf buf;  // inflated bytes not yet consumed: [bpos, buf.size())
     RawBuf cstage3[3];  // device inflate: page-locked copies of three groups' compressed bytes (two on the device, the third being staged)
     uint32_t stage_base = 0;  // staging buffer of a refill's group g: (stage_base + g) % 3
+    // TEST HOOK (tests/test_bam.py, CPU): PLO_BGZF_TEST_HOST_SLOTS=n runs the device path's bookkeeping -- groups of n blocks, three staging
+    // buffers, refill preparation -- with zlib standing in for the device AT WAIT TIME (a group is inflated from its staging buffer when
+    // finish() is called, so a buffer that is reused too early shows up as wrong bytes); PLO_BGZF_TEST_CHUNK_BYTES = the refill size.
+    // Never set outside the tests: the page-locked buffers and the kernels are what the device path is for.
+    int test_slots = -1;  // -1 undecided, 0 off
+    size_t test_chunk = 0;
+    int test_mode() {
+        if (test_slots < 0) {
+            const char *e = getenv("PLO_BGZF_TEST_HOST_SLOTS");
+            test_slots = e ? std::max(0, atoi(e)) : 0;
+            const char *c2 = getenv("PLO_BGZF_TEST_CHUNK_BYTES");
+            test_chunk = c2 ? (size_t)std::max(1L, atol(c2)) : 0;
+        }
+        return test_slots;
+    }
     // The NEXT refill, prepared while the last groups of this one are on the device and the host would only wait (device inflate): its block
     // headers walked (a page fault per block on the file mapping) and its first one or two groups staged.  Used by the next fill() when the
     // stream is still where the walk began (restart_at drops it).  PLO_BGZF_NO_PREFETCH=1 switches it off.
@@ -267,6 +282,7 @@ struct BgzfIn {
             const long mb = e ? atol(e) : 0;
             later_chunk = mb >= 64 && mb <= 8192 ? (size_t)mb << 20 : (device == 1 ? DEVICE_CHUNK : CHUNK);
         }
+        if (test_mode() && test_chunk) return test_chunk;
         return n_fills == 0 ? CHUNK : later_chunk;
     }
     static constexpr size_t DEVICE_CHUNK = 256u << 20;
@@ -391,7 +407,9 @@ struct BgzfIn {
             // nearly as much as inflating: pipelined with the device, a refill takes as long as on the host
             const char *e = getenv("PLO_BGZF_DEVICE");  // the environment has the last word; -2: asked for through plo_bam_set_device_inflate
             device = e ? (atoi(e) != 0 ? 1 : 0) : (device == -2 ? 1 : 0);
-            if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays
+            if (device && test_mode()) {
+                // (test hook: no page-locked memory, no device)
+            } else if (device) {  // page-locked stream buffer; without a usable device the allocation fails and the host path stays
                 void *q = nullptr;
                 const size_t cap0 = std::max<size_t>(CHUNK + CHUNK / 2, buf.n);
                 if (buf.pinned) {
@@ -415,7 +433,7 @@ struct BgzfIn {
         ++n_fills;
         // device inflate: whole rounds of resident waves -- a group takes one block's decode time (~7 ms) however few blocks it has, so
         // the refill goes on to the next multiple of the wave slots (17 blocks left over used to cost a round of their own)
-        if (device == 1 && !dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
+        if (device == 1 && !dev_slots) dev_slots = test_mode() ? (uint32_t)test_mode() : std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
         const size_t round_to = device == 1 ? dev_slots : 1;
         uint32_t pre_staged = 0;  // leading groups of this refill whose compressed bytes are in their staging buffers already
         if (nx_valid && device == 1 && nx_pos0 == cpos && !nx_blks.empty()) {
@@ -471,7 +489,8 @@ struct BgzfIn {
             // two groups in flight: while the device inflates group g the host stages the compressed bytes of group g + 1 in
             // page-locked memory (a large host-to-device copy straight from the file mapping would make the runtime pin file-backed
             // pages, far slower than this parallel copy) and checks the CRCs of group g - 1 (libdeflate's CRC runs at memory speed).
-            if (!dev_slots) dev_slots = std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
+            if (!dev_slots) dev_slots = test_mode() ? (uint32_t)test_mode() : std::max<uint32_t>(plo_internal_bgzf_slots(), 64u);
+            const bool test = test_mode() != 0;
             const size_t ng = (blks.size() + dev_slots - 1) / dev_slots;
             std::vector<DevBlk> db[2];
             std::vector<uint32_t> dcrc[2];
@@ -487,7 +506,7 @@ struct BgzfIn {
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0;
                 if (g < pre_staged) return 0;  // (staged while the last refill's final groups were on the device)
                 RawBuf &cs = cstage3[(stage_base + g) % 3];
-                cs.pinned = true;
+                cs.pinned = !test;
                 if (!cs.resize(cbytes + 16)) return -101;
                 // compressed bytes: positional reads straight into the page-locked stage (round 4 copied them out of the file mapping)
                 const double ts0 = dbgf ? clk() : 0;
@@ -507,10 +526,32 @@ struct BgzfIn {
                     dc[i - lo] = blks[i].crc;
                 }
                 const size_t cbytes = blks[hi - 1].coff + blks[hi - 1].clen - c0, ubytes = blks[hi - 1].uoff + blks[hi - 1].ulen - u0;
+                if (test) return 0;  // (the stand-in inflates at wait time)
                 return plo_internal_bgzf_begin((int)(g & 1), cstage3[(stage_base + g) % 3].data(), cbytes, d.data(), (uint32_t)d.size(), buf.data() + u0, ubytes, host_crc ? nullptr : dc.data());
             };
             auto finish = [&](size_t g) -> int {
                 const double tw0 = dbgf ? clk() : 0;
+                if (test) {  // zlib from the group's STAGING buffer, as the device would read it until now
+                    const size_t lo = g * dev_slots, hi = std::min(blks.size(), lo + dev_slots);
+                    const uint8_t *cs = cstage3[(stage_base + g) % 3].data();
+                    const size_t c0 = blks[lo].coff;
+                    for (size_t i = lo; i < hi; ++i) {
+                        const Blk &b = blks[i];
+                        if (!b.ulen) continue;
+                        z_stream zs;
+                        memset(&zs, 0, sizeof(zs));
+                        if (inflateInit2(&zs, -15) != Z_OK) return -200;
+                        zs.next_in = (Bytef *)(cs + (b.coff - c0));
+                        zs.avail_in = (uInt)b.clen;
+                        zs.next_out = buf.data() + b.uoff;
+                        zs.avail_out = (uInt)b.ulen;
+                        const int zr = inflate(&zs, Z_FINISH);
+                        const bool good = zr == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(0L, buf.data() + b.uoff, (uInt)b.ulen) == b.crc;
+                        inflateEnd(&zs);
+                        if (!good) return -200;
+                    }
+                    return 0;
+                }
                 int r = plo_internal_bgzf_wait((int)(g & 1));
                 if (dbgf) tf_wait += clk() - tw0;
                 if (r) return r;
@@ -522,8 +563,10 @@ struct BgzfIn {
                 });
                 return 0;
             };
-            plo_internal_bgzf_acquire();
-            rc = plo_internal_bgzf_set_device(dev_id);
+            if (!test) {
+                plo_internal_bgzf_acquire();
+                rc = plo_internal_bgzf_set_device(dev_id);
+            }
             // the next refill's headers and first groups, in the time the host would wait for this refill's last groups
             double tf_pre = 0;
             auto prestage_upto = [&](size_t kmax) {
@@ -577,7 +620,7 @@ struct BgzfIn {
                     if (hi - lo < dev_slots && nx_pos_end < size) break;  // (only groups that are final: full, or cut by the end of the file)
                     const size_t c0 = nx_blks[lo].coff, cbytes = nx_blks[hi - 1].coff + nx_blks[hi - 1].clen - c0;
                     RawBuf &cs = cstage3[(stage_base + ng + nx_staged) % 3];
-                    cs.pinned = true;
+                    cs.pinned = !test;
                     if (!cs.resize(cbytes + 16)) break;
                     if (!parallel_pread(fd, cs.data(), c0, cbytes, threads)) parallel_copy(cs.data(), map + c0, cbytes, threads);
                     ++nx_staged;
@@ -597,11 +640,11 @@ struct BgzfIn {
                 if (rc == 0) rc = rs;
                 if (rc == 0 && g + 2 < ng) rc = enqueue(g + 2);
             }
-            if (rc != 0) {  // leave nothing in flight
+            if (rc != 0 && !test) {  // leave nothing in flight
                 (void)plo_internal_bgzf_wait(0);
                 (void)plo_internal_bgzf_wait(1);
             }
-            plo_internal_bgzf_release();
+            if (!test) plo_internal_bgzf_release();
             if (rc != 0) {  // (what was prepared lies in buffers counted from this refill's groups: dropped with it)
                 nx_valid = false;
                 nx_staged = 0;

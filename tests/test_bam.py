@@ -468,6 +468,62 @@ def test_device_inflate_matches_host_inflate(tmp_path, monkeypatch):
         assert got["0"] == got["1"] and sum(x[0] for x in got["1"]) == w.n_reads
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_device_path_bookkeeping_with_zlib_standing_in_for_the_device(tmp_path, monkeypatch, capfd, level):
+    """BgzfIn::fill's device path without a device (PLO_BGZF_TEST_HOST_SLOTS: groups of n blocks, three staging buffers, the next group staged
+    while two are "on the device", the next refill prepared during the last waits; zlib inflates a group from its STAGING buffer when its wait
+    is called): refills of a few blocks with every group size, whole file and as parts, with and without the preparation, give the records the
+    plain host inflate gives.  (The same logic with the real device: test_device_inflate_over_several_refills, -m gpu.)"""
+    import hashlib
+
+    w = synth.generate(synth.config("tiny", n_reads=1500, seed=433, split_read_frac=0.2, sorted_reads=True))
+    path = str(tmp_path / f"t{level}.bam")
+    bamsynth.write_read_bam(w, path, level=level)
+    n_blocks = len(bamcheck.bgzf_blocks(path))
+    assert n_blocks > 12
+
+    def read_all(device, part=None, n_parts=1, window=157):
+        rd = bam.BamReader(path, 3, device_inflate=device, part=part, n_parts=n_parts)
+        out = []
+        while True:
+            win = rd.read_window(window)
+            if win is None:
+                break
+            b = win.batch_data()
+            h = hashlib.sha1()
+            for a in (b.seq, b.cigar, b.seg_pos, b.read_seq_len):
+                h.update(a.tobytes())
+            out.append((b.n_reads, h.hexdigest(), win.unmapped_bytes()))
+            win.close()
+        rd.close()
+        return out
+
+    want = read_all(-1)
+    want_parts = {n: [read_all(-1, k, n) for k in range(n)] for n in (2, 5)}
+    assert sum(x[0] for x in want) == w.n_reads
+    capfd.readouterr()
+    monkeypatch.setenv("PLO_DEBUG_READER", "1")
+    refills = 0
+    for slots in (1, 2, 3, 7):
+        for chunk in (1, 70_000, 200_000, 1_000_000):  # (1 byte: every refill is one round of `slots` blocks)
+            for no_prefetch in (None, "1"):
+                monkeypatch.setenv("PLO_BGZF_TEST_HOST_SLOTS", str(slots))
+                monkeypatch.setenv("PLO_BGZF_TEST_CHUNK_BYTES", str(chunk))
+                if no_prefetch:
+                    monkeypatch.setenv("PLO_BGZF_NO_PREFETCH", no_prefetch)
+                else:
+                    monkeypatch.delenv("PLO_BGZF_NO_PREFETCH", raising=False)
+                assert read_all(0) == want, (slots, chunk, no_prefetch)
+                assert read_all(0, window=10_000) == read_all(-1, window=10_000), (slots, chunk, no_prefetch)
+                for n in (2, 5):
+                    assert [read_all(0, k, n) for k in range(n)] == want_parts[n], (slots, chunk, no_prefetch, n)
+                err = capfd.readouterr().err
+                refills += err.count("[plo] refill:")
+                if not no_prefetch and chunk < 1_000_000:
+                    assert "groups staged)" in err and any(f"{k} groups staged)" in err for k in (1, 2)), "the refill preparation never ran"
+    assert refills > 200  # (the stand-in path ran: a reader that fell back to the host inflate prints no refill lines)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("level", [0, 1])
 def test_device_inflate_over_several_refills(tmp_path, monkeypatch, level):
