@@ -227,7 +227,8 @@ class PinnedArena:
     """A worker's page-locked landing area for the results of one window at a time (round 5): every array of a HostResults is a slice of ONE
     pinned block that is reused from window to window, filled by asynchronous copies on the worker's stream and waited for once.  (Round 4
     downloaded each of the ~25 arrays into a fresh numpy array with a stream synchronisation of its own: page faults on 90 MB of new
-    memory per 7 500-read window and staged copies into pageable memory -- most of the `lift + finish` stage's time.)"""
+    memory per 7 500-read window and staged copies into pageable memory.  Measured per 60 k reads: lift stage 0.317 -> 0.302 s, record
+    assembly -- which reads these arrays -- 0.163 -> 0.102 s; EXPERIMENTS.md 5.15.)"""
 
     def __init__(self, nbytes: int = 64 << 20):
         self.buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
