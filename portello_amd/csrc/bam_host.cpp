@@ -1130,17 +1130,19 @@ struct plo_bam_writer {
     // when the writer closes; PLO_BGZF_FALLOCATE=0 switches it off, a filesystem without fallocate does so by itself).  Buffered writes into ONE file are serialised by the inode's lock whatever the number of
     // threads (tools/write_bench.cpp on the GPU box: 9.5 GB/s into one file, 61-126 GB/s into one file per thread); reserved blocks shorten
     // the time under the lock by the allocation (10.0-10.8 GB/s there).
+    // Files below 64 MB reserve nothing (on a memory-backed filesystem a reservation is real, zero-filled memory); from there on the step
+    // grows with the file, a quarter of a gigabyte to two (PLO_BGZF_FALLOCATE=2: from the first byte, for the tests).
     uint64_t reserved = 0;
     int falloc = -1;  // -1 undecided
     void reserve(uint64_t upto) {
         if (!seekable || falloc == 0) return;
         if (falloc < 0) {
             const char *e = getenv("PLO_BGZF_FALLOCATE");
-            falloc = (e && atoi(e) == 0) ? 0 : 1;
+            falloc = e ? std::max(0, atoi(e)) : 1;
             if (!falloc) return;
         }
-        if (upto <= reserved) return;
-        const uint64_t to = upto + std::max<uint64_t>((uint64_t)1 << 30, 2 * (upto - reserved));
+        if (upto <= reserved || (falloc == 1 && upto < ((uint64_t)64 << 20))) return;
+        const uint64_t to = upto + std::min<uint64_t>((uint64_t)2 << 30, std::max<uint64_t>((uint64_t)256 << 20, upto));
         if (fallocate(fd, FALLOC_FL_KEEP_SIZE, (off_t)reserved, (off_t)(to - reserved)) != 0) {
             falloc = 0;  // (a filesystem without it: nothing is lost)
             return;

@@ -117,12 +117,12 @@ def test_writer_output_is_a_valid_bam_and_reader_round_trips(small_bam, tmp_path
 
 @pytest.mark.parametrize("level", [0, 1])
 def test_writer_with_blocks_reserved_ahead_writes_the_same_file(small_bam, tmp_path, monkeypatch, level):
-    """PLO_BGZF_FALLOCATE=1 (the output's blocks reserved a gigabyte ahead of the writes, FALLOC_FL_KEEP_SIZE): the same bytes, and the file
+    """The output's blocks reserved ahead of the writes (FALLOC_FL_KEEP_SIZE; the default for files beyond 64 MB): the same bytes, and the file
     ends where its last block ends -- what was reserved behind it is given back when the writer closes"""
     _, path, _ = small_bam
     text, refs, recs = bamcheck.read_bam(path)
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "2"):  # (2: reserve from the first byte -- by default files below 64 MB reserve nothing)
         monkeypatch.setenv("PLO_BGZF_FALLOCATE", mode)
         p = str(tmp_path / f"reserved_{mode}.bam")
         wr = bam.BamWriter(p, text, [n for n, _ in refs], [l for _, l in refs], level=level, n_threads=3)
@@ -132,7 +132,30 @@ def test_writer_with_blocks_reserved_ahead_writes_the_same_file(small_bam, tmp_p
         out[mode] = open(p, "rb").read()
         st = os.stat(p)
         assert st.st_size == len(out[mode]) and st.st_blocks * 512 < st.st_size + (8 << 20)  # (no gigabyte left allocated behind the end)
-    assert out["0"] == out["1"] and bamcheck.read_bam(str(tmp_path / "reserved_1.bam"))[2] == recs
+    assert out["0"] == out["2"] and bamcheck.read_bam(str(tmp_path / "reserved_2.bam"))[2] == recs
+    if level == 0:  # the default setting on a file beyond 64 MB (where it starts to reserve): the same bytes as without, nothing left behind the end
+        blob = b"".join(recs)
+        reps = (80 << 20) // len(blob) + 1
+        big = {}
+        for mode in ("0", None):
+            if mode is None:
+                monkeypatch.delenv("PLO_BGZF_FALLOCATE")
+            else:
+                monkeypatch.setenv("PLO_BGZF_FALLOCATE", mode)
+            p = str(tmp_path / f"big_{mode}.bam")
+            wr = bam.BamWriter(p, text, [n for n, _ in refs], [l for _, l in refs], level=0, n_threads=3)
+            for _ in range(reps):
+                wr.write(blob)
+            wr.close()
+            h = __import__("hashlib").sha1()
+            with open(p, "rb") as f:
+                for piece in iter(lambda: f.read(1 << 24), b""):
+                    h.update(piece)
+            st = os.stat(p)
+            big[mode] = (st.st_size, h.hexdigest())
+            assert st.st_size > (80 << 20) and st.st_blocks * 512 < st.st_size + (8 << 20)
+            os.unlink(p)
+        assert big["0"] == big[None]
 
 
 def test_window_batch_matches_python_split_segments(small_bam):
