@@ -933,16 +933,12 @@ constexpr int LANE_WAVES = 4;
 #ifndef PLO_LANE_WPE_MIN
 #define PLO_LANE_WPE_MIN PLO_LANE_WPE
 #endif
-#ifndef PLO_LANE_FWD_WPE
-#define PLO_LANE_FWD_WPE 3  // k_lift_lanes_fwd (no shift stage)
-#endif
 #ifndef PLO_LANE_G_WPE
 #define PLO_LANE_G_WPE 2  // k_lift_lanes_g: the windows' bookkeeping on top of 168 registers would spill; 12 KB of LDS per wave anyway
 #endif
 constexpr int LANE_G_WAVES = 4;
-template <bool SP, bool NOSHIFT = false>
-PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw, uint32_t base = 0,
-                               uint32_t slab_wave0 = 0) {
+template <bool SP, bool STATS>
+PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // XCD-aware placement as in lift_tiles_kernel: neighbouring groups -- reads over the same stretch of a contig -- share an L2
@@ -952,22 +948,13 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
     const uint32_t wave = tb * tw + (uint32_t)w, n_waves = nb * tw;
     WaveCtx ctx;
     if (wk.slab_pre) {
-        ctx.slab_base = (unsigned long long)(wave + slab_wave0) * SLAB_OPS;
+        ctx.slab_base = (unsigned long long)wave * SLAB_OPS;
         ctx.slab_left = SLAB_OPS;
     }
-    lane_tiles_persistent<SP, NOSHIFT>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx, base);
+    // (the ticket counter of the context's next launch: not in use during this one)
+    if (wk.lane_ticket_next && b == 0u && threadIdx.x == 0u) *wk.lane_ticket_next = 0u;
+    lane_tiles_persistent<SP, false, STATS>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx);
     wave_ctx_flush(wk, ctx, wave);
-}
-// The two light classes as two launches (PLO_LANE_SPLIT=1, an experiment of round 5): the forward class through an instantiation compiled
-// without the shift stage (k_lift_lanes_fwd), the other class through k_lift_lanes from its first position (`base`, `slab_wave0`: its waves'
-// pre-owned output slabs lie behind the first launch's)
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_FWD_WPE, PLO_LANE_FWD_WPE))) void k_lift_lanes_fwd(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t gs, int capw) {
-    lift_lanes_kernel<false, true>(ix, bt, wk, stages, n0, 0u, gs, capw);
-}
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_rev(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t base,
-                                                                                                   uint32_t n1, uint32_t gs, int capw, uint32_t slab_wave0) {
-    lift_lanes_kernel<false, false>(ix, bt, wk, stages, 0u, n1, gs, capw, base, slab_wave0);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
                                                                                                    uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
@@ -975,7 +962,16 @@ __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu
         n0 = totals_dev[0];
         n1 = totals_dev[1];
     }
-    lift_lanes_kernel<false>(ix, bt, wk, stages, n0, n1, gs, capw);
+    lift_lanes_kernel<false, false>(ix, bt, wk, stages, n0, n1, gs, capw);
+}
+// the same with the launch's statistics counted (plo_timing::algo_bytes, lane_utilisation): contexts created under PLO_LANE_STATS=1
+__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_stats(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
+                                                                                                         uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
+    if (totals_dev) {
+        n0 = totals_dev[0];
+        n1 = totals_dev[1];
+    }
+    lift_lanes_kernel<false, true>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
                                                                                                       uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
@@ -983,7 +979,7 @@ __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu
         n0 = totals_dev[0];
         n1 = totals_dev[1];
     }
-    lift_lanes_kernel<true>(ix, bt, wk, stages, n0, n1, gs, capw);
+    lift_lanes_kernel<true, false>(ix, bt, wk, stages, n0, n1, gs, capw);
 }
 
 // The same lane-per-item code for HEAVY items (too heavy for an LDS region: indel-dense or very long CIGARs), every lane's region in
@@ -1463,6 +1459,12 @@ struct plo_ctx {
     int lane_max_w = 192;
     int lane_capw = 3072;
     bool lane_sort = true;  // k_chunk_sort before the lane kernel
+    // groups of the lane kernel dealt dynamically (lane_tiles_persistent): two ticket counters used in turn (a launch zeroes the next one's),
+    // the rounds every wave takes by fixed slots first (PLO_LANE_STATIC; < 0: fixed slots only)
+    DevBuf lane_ticket;
+    uint32_t lane_epoch = 0;
+    int lane_static_rounds = 1;
+    bool lane_stats = false;  // PLO_LANE_STATS=1: the light-item kernel that counts algorithmic bytes and lane utilisation (k_lift_lanes_stats)
     int lane_sort_window = LANE_SORT_WINDOW;
     // groups cut by LDS budget inside larger sort windows (k_chunk_sort, lane_groups_cut): on for batches whose groups are of 64
     bool lane_budget = false;  // (measured, MI355X, wgs30x 2 M reads: 1.42 ms with windows of 512 against 1.29 ms with fixed groups in windows of 128 -- DESIGN.md section 6)
@@ -1720,8 +1722,11 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_retry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
     if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
+    if (const char *e = getenv("PLO_LANE_STATIC")) c->lane_static_rounds = atoi(e);
+    if (const char *e = getenv("PLO_LANE_STATS")) c->lane_stats = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = c->lane_budget_window = std::min(2048, std::max(64, atoi(e) & ~63));
     if (const char *e = getenv("PLO_LANE_BUDGET")) c->lane_budget = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
@@ -1745,7 +1750,7 @@ void plo_ctx_destroy(plo_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->f_flag, &c->f_bin, &c->f_end, &c->f_prim, &c->f_isoff, &c->f_iqoff, &c->f_iread, &c->f_nl, &c->f_pitem,
                       &c->f_uflag, &c->f_rsoff, &c->f_rqoff, &c->f_su, &c->f_qu, &c->f_soff, &c->f_qoff, &c->f_rseq, &c->f_rqual, &c->f_fflag, &c->f_frank, &c->f_flist, &c->sa_len, &c->sa_off, &c->sa_text,
-                      &c->item_region, &c->lane_groups, &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_nm, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
+                      &c->item_region, &c->lane_groups, &c->lane_ticket, &c->misc, &c->whist, &c->cls_partial, &c->lane_scratch, &c->item_cls, &c->retry_list, &c->perm, &c->nin_p, &c->seg_reflen, &c->seg_readlen, &c->seg_nm, &c->seg_cnt, &c->seg_off, &c->scan_partial, &c->item_seg, &c->item_cseg, &c->item_nin, &c->op_prefix,
                       &c->counters, &c->big_list, &c->huge_list, &c->verr, &c->scratch, &c->tile_lo, &c->d_n_m, &c->d_in_off, &c->d_n_in, &c->d_pos1,
                       &c->d_w0, &c->d_w1, &c->d_kv0, &c->d_kv1, &c->d_flags, &c->d_contig, &c->d_seq_len, &c->d_seq_off, &c->d_shift_ref,
                       &c->d_shift_ref_len, &c->d_chrom_ref, &c->d_chrom_ref_len, &c->d_read_len, &c->o_status, &c->o_flip, &c->o_mapq, &c->o_chrom, &c->o_pos,
@@ -1779,6 +1784,15 @@ plo_status plo_ctx_sync(plo_ctx *c) {
 void plo_ctx_phase_cycles(plo_ctx *c, unsigned long long *out12) {
     for (int k = 0; k < 12; ++k) out12[k] = c ? c->phase_cycles[k] : 0;
 }
+// debugging aid (timing builds): the raw statistic slots of the last batch's lift waves, STAT_WORDS words each -- [5] / [6] the wave's first and
+// last tick of the constant 100 MHz clock, [7] its HW_ID | XCC_ID << 16 (tools/wave_timeline.py); returns the slots copied
+unsigned plo_ctx_wave_clocks(plo_ctx *c, unsigned long long *out, unsigned max_slots) {
+    if (!c || !out || !c->wave_stats.p) return 0;
+    const unsigned n = (unsigned)std::min<size_t>(max_slots, c->wave_stats.cap / (STAT_WORDS * 8));
+    if (hipSetDevice(c->ix->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    if (hipMemcpy(out, c->wave_stats.p, (size_t)n * STAT_WORDS * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
 
 plo_status plo_ctx_download(plo_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
     if (!c || (bytes && (!host_dst || !dev_src))) return PLO_ERR_INVALID_ARG;
@@ -1802,6 +1816,27 @@ static plo_status scan_u32(plo_ctx *c, const uint32_t *in, uint32_t n, uint32_t 
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, c->stream, in, n, (const uint32_t *)partial, out);
     HIP_TRY(c, hipGetLastError());
     return PLO_OK;
+}
+
+// The lane kernel's ticket counters (lane_tiles_persistent): this launch's -- zero, because the context's previous launch cleared it or the
+// allocation did -- and the next launch's, which this one clears.  Without them (PLO_LANE_STATIC < 0, or no memory) the waves keep to fixed slots.
+static void lane_ticket_arm(plo_ctx *c, DevWork &wk) {
+    wk.lane_ticket = nullptr;
+    wk.lane_ticket_next = nullptr;
+    wk.lane_static_rounds = 0;
+    if (c->lane_static_rounds < 0) return;
+    if (!c->lane_ticket.p) {
+        if (c->lane_ticket.ensure(256) != hipSuccess) return;
+        if (hipMemsetAsync(c->lane_ticket.p, 0, 256, c->stream) != hipSuccess) {
+            c->lane_ticket.release();
+            return;
+        }
+    }
+    uint32_t *const t = c->lane_ticket.as<uint32_t>();  // (the two counters on lines of their own)
+    wk.lane_ticket = t + 32 * (c->lane_epoch & 1u);
+    wk.lane_ticket_next = t + 32 * ((c->lane_epoch + 1u) & 1u);
+    wk.lane_static_rounds = (uint32_t)std::max(1, c->lane_static_rounds);
+    ++c->lane_epoch;
 }
 
 // the item work list and the per-item outputs of a batch of `n_items` items in the context's buffers
@@ -1891,7 +1926,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     // read from device memory and the host looks ONCE, at the end (liftover_fast); a batch that turns out not to fit -- more items than
     // the arrays hold, heavy items, an overflow -- is run again on the path below, which asks for the counts first
     if (c->fast && c->fast_light_only && !in->item_seg && !sp && in->n_segs && in->n_segs <= c->fast_ns_cap && c->fast_item_cap && c->lane_max_w >= 0 && c->lane_sort &&
-        !c->lane_budget && c->lane_sort_window <= 128 && c->o_cigar.cap && !getenv("PLO_LANE_SPLIT")) {
+        !c->lane_budget && c->lane_sort_window <= 128 && c->o_cigar.cap) {
         bool fallback = false;
         plo_status fs = liftover_fast(c, in, stages, out, bt, fallback);
         if (!fallback) return fs;
@@ -2204,16 +2239,10 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
+            lane_ticket_arm(c, wk);
             if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
-            else if (getenv("PLO_LANE_SPLIT") && !wk.lane_groups && n0 && n1) {
-                // (experiment: the classes as two launches, the forward one without the shift stage's code; both over the whole grid)
-                hipLaunchKernelGGL(k_lift_lanes_fwd, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, gs, c->lane_capw);
-                DevWork wk2 = wk;
-                wk2.slab_pre = 0u;  // (the second launch reserves its slabs)
-                wk2.stat_base = stat_used;
-                stat_used += nblk * LANE_WAVES;
-                hipLaunchKernelGGL(k_lift_lanes_rev, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk2, stages, n0, n1, gs, c->lane_capw, 0u);
-            } else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
+            else if (c->lane_stats) hipLaunchKernelGGL(k_lift_lanes_stats, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
+            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
@@ -2600,7 +2629,9 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_seq, 0));
         c->seq_pending = false;
     }
-    hipLaunchKernelGGL(k_lift_lanes, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
+    lane_ticket_arm(c, wk);
+    if (c->lane_stats) hipLaunchKernelGGL(k_lift_lanes_stats, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
+    else hipLaunchKernelGGL(k_lift_lanes, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
     {

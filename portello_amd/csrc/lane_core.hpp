@@ -24,6 +24,12 @@
 #include <plo_wave.hpp>
 #include <stdint.h>
 
+#include <type_traits>
+#ifdef PLO_EMULATOR
+#include <stdio.h>
+#include <stdlib.h>
+#endif
+
 #include "lift_core.hpp"
 
 #ifdef PLO_EMULATOR
@@ -449,7 +455,11 @@ constexpr int LANE_KVS = 128;                  // staged entries per wave
 constexpr int LANE_KVS_DWORDS = 2 * LANE_KVS;  // behind the wave's slice (lds + capw) / windows (lds + 64 * LANE_WIN_DWORDS)
 // NOSHIFT: an instantiation for groups of the class without the shift stage (forward-mapped contig segments), compiled without that
 // stage's code and state -- lanes that would need it are handed to the retry list (the class order keeps them away).
-template <bool SP, bool WIN = false, bool NOSHIFT = false>
+// STATS: the launch counts its algorithmic bytes (SURVEY.md 8(d)'s B_item per item: plo_timing::algo_bytes) and the lanes at work per
+// loop trip (plo_timing::lane_utilisation).  The production instantiation of the light-item kernel is compiled WITHOUT them (the trip
+// counters sat in the two hot loops: an s_bcnt1 and two 64-bit adds per trip); a context asks for the counting kernel with
+// PLO_LANE_STATS=1 (bench.py's statistics pass, tools/, the tests of plo_timing).
+template <bool SP, bool WIN = false, bool NOSHIFT = false, bool STATS = true>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
                        uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre,
                        uint32_t *greg = nullptr, uint32_t *kvs = nullptr) {
@@ -747,8 +757,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             PLO_MARK("SHIFT LOOP BEGIN");
             for (unsigned long long bm; (bm = wv::ballot(!fin)) != 0ull;) {
                 PLO_LC(8, 1)
-                ctx.u_act += (unsigned)__builtin_popcountll(bm);
-                ctx.u_trips += 1;
+                if constexpr (STATS) {
+                    ctx.u_act += (unsigned)__builtin_popcountll(bm);
+                    ctx.u_trips += 1;
+                }
                 wr_room(o, shift_on, gap);
                 // the probes of the clusters that ended at the lanes' last events go out now: their round trips run under this round's scan
                 if (wv::ballot(pend) != 0ull) lane_probe_load(pr, pend, sref, shift_ref_len, rd, (const uint8_t *)plo_safe_words);
@@ -841,7 +853,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             PLO_MARK("SHIFT LOOP END");
             wr_finish(o, shift_on, gap, ext ? wl_ext : wl0 + n);  // :35-38 clean_up_cigar_edge_indels + compress
             if (shift_on) {
-                algo += 2u * (unsigned)probes;
+                if constexpr (STATS) algo += 2u * (unsigned)probes;
                 n = o.no;
                 cur_off = gap;
                 ext = false;
@@ -863,10 +875,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         bool pairs = true;
         if (stages & PLO_STAGE_LIFTOVER) {
             const bool lo_on = alive && !ovf;
-            if (lo_on) {
-                int nb = kv1 - kv0, lg = 0;
-                while ((1 << lg) < nb) ++lg;
-                algo += 16u * (unsigned)(W1 - W0) + 8u * (unsigned)lg;
+            if constexpr (STATS) {
+                if (lo_on) {
+                    const int nb = kv1 - kv0;
+                    const int lg = nb > 1 ? 32 - __builtin_clz((unsigned)(nb - 1)) : 0;  // ceil(log2(nb))
+                    algo += 16u * (unsigned)(W1 - W0) + 8u * (unsigned)lg;
+                }
             }
             LaneOut o;
             wr_open(o, 0);
@@ -876,83 +890,107 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             int t = 0, seg_start = pos, seg_end = 0, block_pos = 0, r2s = 0, r2e = 0;
             int kb = 0, vb = NONE32, kn = IMAX, vn = NONE32, kf = IMAX, vf = NONE32;
             int ni = W0 + 2;  // index of the entry to request at the next crossing
-            // entry `idx` of the block map for the lanes `on`: from the staged copy, or (items outside it) from global memory
-            auto kv_fetch = [&](bool on, int idx, int &key, int &val) {
-                if (kvs != nullptr) {
-                    // (only what was staged: the cursor's look-ahead may ask for the entry one past the item's own range)
-                    const bool l = on & kv_lds & ((unsigned)(idx - kvs_base) < (unsigned)kvs_cnt);
-                    const uint32_t *q = kvs + 2 * (l ? idx - kvs_base : 0);
-                    const int lk = (int)q[0], lv = (int)q[1];
-                    key = l ? lk : key;
-                    val = l ? lv : val;
-                    on = on & !l;
-                }
-                const bool gl = on;
-                if (wv::ballot(gl) != 0ull) {
-                    if (gl) {
-                        const KV e = ix.kv[idx];
-                        key = e.key;
-                        val = e.val;
+            // entry `idx` of the block map for the lanes `on`: from the staged copy, or (items outside it) from global memory.
+            // ALL_LDS: every lane's entries are staged (nearly every group: the items of a group are neighbours on a contig) -- the loop
+            // body is then ONE basic block: no `any lane outside` test, no global load, and none of the lane-mask merges the compiler
+            // puts at the join of a divergent branch (three scalar instructions per loop-carried flag, profiles/r05_liftover_loop.s).
+            auto run = [&](auto all_lds_c) {
+                constexpr bool ALL_LDS = decltype(all_lds_c)::value;
+                auto kv_fetch = [&](bool on, int idx, int &key, int &val) {
+                    if (kvs != nullptr) {
+                        // (only what was staged: the cursor's look-ahead may ask for the entry one past the item's own range)
+                        // (ALL_LDS: every request lies in [W0, min(kv1, W1 + 2)) -- a crossing needs a key <= block_pos < pos1 + ref_len, so at most
+                        // W1 - W0 of them happen and the last one asks for entry W1 + 1 -- which is what kv_lds says is staged)
+                        const bool l = ALL_LDS ? on : (on & kv_lds & ((unsigned)(idx - kvs_base) < (unsigned)kvs_cnt));
+#ifdef PLO_EMULATOR
+                        if (ALL_LDS && on && (unsigned)(idx - kvs_base) >= (unsigned)kvs_cnt) {
+                            fprintf(stderr, "lane_tile: block-map entry %d outside the staged range [%d, %d)\n", idx, kvs_base, kvs_base + kvs_cnt);
+                            abort();
+                        }
+#endif
+                        const uint32_t *q = kvs + 2 * (l ? idx - kvs_base : 0);
+                        const int lk = (int)q[0], lv = (int)q[1];
+                        key = l ? lk : key;
+                        val = l ? lv : val;
+                        on = on & !l;
                     }
+                    if constexpr (!ALL_LDS) {
+                        const bool gl = on;
+                        if (wv::ballot(gl) != 0ull) {
+                            if (gl) {
+                                const KV e = ix.kv[idx];
+                                key = e.key;
+                                val = e.val;
+                            }
+                        }
+                    }
+                };
+                kv_fetch(lo_on & (W0 < kv1), W0, kn, vn);
+                kv_fetch(lo_on & (W0 + 1 < kv1), W0 + 1, kf, vf);
+                PLO_MARK("LIFTOVER LOOP BEGIN");
+                for (unsigned long long bm; (bm = wv::ballot(lo_on & ((k < n) | in_op))) != 0ull;) {
+                    PLO_LC(7, 1)
+                    if constexpr (STATS) {
+                        ctx.u_act += (unsigned)__builtin_popcountll(bm);
+                        ctx.u_trips += 1;
+                    }
+                    // the next op, unless one is being cut into pieces
+                    const bool fetch = lo_on & !in_op & (k < n);
+                    wr_room(o, lo_on, 0);
+                    rd_need(k, fetch, lo_on);
+                    const uint32_t c = rd_at(k, fetch);
+                    k += fetch ? 1 : 0;
+                    const int tf = op_type(c), Lf = op_len(c);
+                    const bool copy = fetch & (((0x32u >> tf) & 1u) != 0u);  // I S H: :157-160 copied through; Pad (:213) emits nothing
+                    const bool start = fetch & b_ref_cons(tf) & (Lf > 0);
+                    t = start ? tf : t;
+                    ism = start ? b_is_match(tf) : ism;
+                    seg_end = start ? seg_start + Lf : seg_end;
+                    block_pos = start ? seg_start : block_pos;
+                    in_op = in_op | start;
+                    // the piece starts in the next block (get_ref_range walks on, read_to_ref_map.rs:79-84)
+                    const bool adv = in_op & (kn <= block_pos);
+                    int fk = IMAX, fv = NONE32;
+                    kv_fetch(adv & (ni < kv1), ni, fk, fv);  // (used at the end of the iteration)
+                    kb = adv ? kn : kb;
+                    vb = adv ? vn : vb;
+                    bvalid = bvalid | adv;
+                    kn = adv ? kf : kn;
+                    vn = adv ? vf : vn;
+                    ni += adv ? 1 : 0;
+                    // (kn <= block_pos still: the shift stage moved the start past another key; the walk goes on next iteration)
+                    const bool piece = in_op & (kn > block_pos);
+                    const int pend = wv::imin(seg_end, kn);  // :62-67
+                    const int plen = pend - block_pos;
+                    const bool mapped = bvalid & (vb != NONE32);
+                    const bool mp = piece & mapped;
+                    const bool set_start = mp & ism & !has_start;  // :84-88
+                    r2s = set_start ? wrap_add(vb, block_pos - kb) : r2s;
+                    has_start = has_start | set_start;
+                    const int d = wrap_add(vb, -r2e);  // :91-96 (wrapping: vb is NONE32 where the piece is not mapped, and then unused)
+                    // ONE writer call per trip.  A piece that enters its block behind a jump of the reference (:91-96) takes two trips:
+                    // the first emits the deletion D(d) and moves ref2_end_pos up to the block's start, so that the second -- same op,
+                    // same block, nothing else has moved -- finds d == 0 and emits the piece itself.  (The jump is live in about one
+                    // trip in twenty; the second writer call it used to have cost every trip a quarter of its vector instructions.)
+                    const bool e0 = mp & has_end & (d > 0) & has_start;
+                    has_end = has_end | mp;
+                    const bool go = piece & !e0;  // the piece is consumed in this trip
+                    r2e = mp ? wrap_add(vb, e0 ? 0 : pend - kb) : r2e;  // :98-100
+                    // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
+                    const bool e1p = go & (mapped ? (ism | has_start) : ism);
+                    const int t1p = mapped ? (t == OP_D ? (int)OP_D : (t == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
+                    block_pos = go ? pend : block_pos;
+                    const bool done = go & (pend >= seg_end);
+                    in_op = in_op & !done;
+                    seg_start = done ? seg_end : seg_start;
+                    const int wl = ext ? W : cur_off + k;  // ops below R[cur_off + k] have been read
+                    lane_push<false, ST>(o, e0 | copy | e1p, e0 ? (int)OP_D : (copy ? tf : t1p), e0 ? d : (copy ? Lf : plen), wl);
+                    kf = adv ? fk : kf;  // the entry after next (kv_fetch above)
+                    vf = adv ? fv : vf;
                 }
             };
-            kv_fetch(lo_on & (W0 < kv1), W0, kn, vn);
-            kv_fetch(lo_on & (W0 + 1 < kv1), W0 + 1, kf, vf);
-            PLO_MARK("LIFTOVER LOOP BEGIN");
-            for (unsigned long long bm; (bm = wv::ballot(lo_on & ((k < n) | in_op))) != 0ull;) {
-                PLO_LC(7, 1)
-                ctx.u_act += (unsigned)__builtin_popcountll(bm);
-                ctx.u_trips += 1;
-                // the next op, unless one is being cut into pieces
-                const bool fetch = lo_on & !in_op & (k < n);
-                wr_room(o, lo_on, 0);
-                rd_need(k, fetch, lo_on);
-                const uint32_t c = rd_at(k, fetch);
-                k += fetch ? 1 : 0;
-                const int tf = op_type(c), Lf = op_len(c);
-                const bool copy = fetch & (((0x32u >> tf) & 1u) != 0u);  // I S H: :157-160 copied through; Pad (:213) emits nothing
-                const bool start = fetch & b_ref_cons(tf) & (Lf > 0);
-                t = start ? tf : t;
-                ism = start ? b_is_match(tf) : ism;
-                seg_end = start ? seg_start + Lf : seg_end;
-                block_pos = start ? seg_start : block_pos;
-                in_op = in_op | start;
-                // the piece starts in the next block (get_ref_range walks on, read_to_ref_map.rs:79-84)
-                const bool adv = in_op & (kn <= block_pos);
-                int fk = IMAX, fv = NONE32;
-                kv_fetch(adv & (ni < kv1), ni, fk, fv);  // (used at the end of the iteration)
-                kb = adv ? kn : kb;
-                vb = adv ? vn : vb;
-                bvalid = bvalid | adv;
-                kn = adv ? kf : kn;
-                vn = adv ? vf : vn;
-                ni += adv ? 1 : 0;
-                // (kn <= block_pos still: the shift stage moved the start past another key; the walk goes on next iteration)
-                const bool piece = in_op & (kn > block_pos);
-                const int pend = wv::imin(seg_end, kn);  // :62-67
-                const int plen = pend - block_pos;
-                const bool mapped = bvalid & (vb != NONE32);
-                const bool mp = piece & mapped;
-                const bool set_start = mp & ism & !has_start;  // :84-88
-                r2s = set_start ? wrap_add(vb, block_pos - kb) : r2s;
-                has_start = has_start | set_start;
-                const int d = wrap_add(vb, -r2e);  // :91-96 (wrapping: vb is NONE32 where the piece is not mapped, and then unused)
-                const bool e0 = mp & has_end & (d > 0) & has_start;
-                has_end = has_end | mp;
-                r2e = mp ? wrap_add(vb, pend - kb) : r2e;  // :98-100
-                // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
-                const bool e1p = piece & (mapped ? (ism | has_start) : ism);
-                const int t1p = mapped ? (t == OP_D ? (int)OP_D : (t == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
-                block_pos = piece ? pend : block_pos;
-                const bool done = piece & (pend >= seg_end);
-                in_op = in_op & !done;
-                seg_start = done ? seg_end : seg_start;
-                const int wl = ext ? W : cur_off + k;  // ops below R[cur_off + k] have been read
-                lane_push<false, ST>(o, e0, OP_D, d, wl);
-                lane_push<false, ST>(o, copy | e1p, copy ? tf : t1p, copy ? Lf : plen, wl);
-                kf = adv ? fk : kf;  // the entry after next (kv_fetch above)
-                vf = adv ? fv : vf;
-            }
+            if (kvs != nullptr && wv::ballot(lo_on & !kv_lds) == 0ull) run(std::true_type{});
+            else run(std::false_type{});
             PLO_MARK("LIFTOVER LOOP END");
             PLO_LT(3)
             wr_finish(o, lo_on, 0, ext ? W : cur_off + n);  // :219-220
@@ -1071,7 +1109,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 }
                 wr_finish(o, s_on, 0, cur_off + n);  // :153-154
                 if (s_on) {
-                    algo += 2u * (unsigned)cmp;
+                    if constexpr (STATS) algo += 2u * (unsigned)cmp;
                     ovf = ovf | o.ovf | zero_m;
                     n = o.no;
                     cur_off = 0;
@@ -1143,8 +1181,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             wk.pos[g] = emit_cigar ? (int64_t)pos : (int64_t)-1;
             wk.cig_off[g] = emit_cigar ? gbase + (unsigned long long)oS : 0ull;
             wk.cig_len[g] = (uint32_t)oc;
-            ctx.algo_bytes += algo + 40u + 4u * (unsigned)n_in + 24u + 4u * (unsigned)oc;
-            ctx.in_ops += (unsigned)n_in;
+            if constexpr (STATS) ctx.algo_bytes += algo + 40u + 4u * (unsigned)n_in + 24u + 4u * (unsigned)oc;
+            ctx.in_ops += (unsigned)n_in;  // (two adds per group: plo_timing::n_in_ops / n_out_ops are always reported)
             ctx.out_ops += (unsigned)oc;
         }
         PLO_LT(6)
@@ -1164,8 +1202,14 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // descriptor, CIGAR and block-map cache lines, and a group of scattered items gives that up.  k_chunk_sort's windows of 128 items
 // are what survived of it.  Also measured and dropped: the groups dealt out by atomic queues, one per XCD, instead of the fixed
 // slots below -- 1.30 ms either way on wgs30x, the waves' loads are even enough, and a small batch pays for the atomics.)
+// DYNAMIC DEALING (round 6): with wk.lane_ticket set, a wave takes its first wk.lane_static_rounds groups by the fixed slots above and every
+// further one from a device-wide ticket counter, one group ahead (the ticket for the next group is asked for before this group is lifted
+// and looked at after it).  tools/wave_timeline.py on wgs30x: with fixed slots the 3 072 waves start within half a microsecond and end
+// between 800 and 1 380 us -- a quarter of all wave-slots of the launch idle behind waves that drew cheap groups (half the groups have no shift
+// stage and take half as long; the last round is a partial one).  The earlier attempt with one queue per XCD (round 4) kept the XCDs' unequal
+// shares; one counter for the chip levels them too.
 // `base`: class-order position of the first item (0; a launch over one class only starts at that class)
-template <bool SP, bool NOSHIFT = false>
+template <bool SP, bool NOSHIFT = false, bool STATS = true>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
                                    uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx, uint32_t base = 0) {
     const uint32_t lane = (uint32_t)wv::lane();
@@ -1203,25 +1247,65 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
     // a wave does not keep drawing the longer (or the shorter) half of every sorted window (k_chunk_sort) when the number of waves
     // is even
     auto slot = [&](uint32_t j) { return j * stride + (first + j) % stride; };
-    // software pipeline over a wave's rounds: the bounds of the group after next, the item indices of the next group
-    uint32_t lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;  // group of round j (lo1, hi1 after the shift below), of round j + 1
-    uint32_t g_next = 0;
-    if (slot(0) < n_groups) {
-        group(slot(0), lo1, hi1);
-        g_next = lo1 + lane < hi1 ? wk.perm[lo1 + lane] : 0u;
+    const bool dyn = wk.lane_ticket != nullptr;
+    const uint32_t n_static = dyn ? (wk.lane_static_rounds ? wk.lane_static_rounds : 1u) : 0xffffffffu;  // rounds by fixed slots
+    const uint32_t t_base = dyn ? n_static * stride : 0u;  // tickets count from the first group no fixed slot covers
+    // One call site of lane_tile (the kernel's code is large: a second copy costs instruction-cache misses and compile time).  Software
+    // pipeline: the item indices of the next group are fetched while this one is lifted when its index is known (fixed slots); a
+    // ticket is asked for before the group and looked at after it (the atomic's round trip runs under the group's own loads).
+    uint32_t t = slot(0), lo = 0, hi = 0, g = 0;
+    bool have = t < n_groups;
+    if (have) {
+        group(t, lo, hi);
+        g = lo + lane < hi ? wk.perm[lo + lane] : 0u;
     }
-    if (slot(1) < n_groups) group(slot(1), lo2, hi2);
-    for (uint32_t j = 0; j * stride < n_groups; ++j) {
-        const uint32_t t = slot(j), tn = slot(j + 1), tnn = slot(j + 2);
-        const uint32_t g = g_next, lo = lo1, hi = hi1;
-        lo1 = lo2;
-        hi1 = hi2;
-        if (tn < n_groups) g_next = lo1 + lane < hi1 ? wk.perm[lo1 + lane] : 0u;
-        if (tnn < n_groups) group(tnn, lo2, hi2);
-        if (t < n_groups) {
-            lane_tile<SP, false, NOSHIFT>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
-            wv::sync();
+    for (uint32_t j = 0; have; ++j) {
+        const bool next_fixed = j + 1u < n_static;
+        uint32_t tn = next_fixed ? slot(j + 1u) : 0xffffffffu, lon = 0, hin = 0, gn = 0, ticket = 0;
+        if (next_fixed) {
+            if (tn < n_groups) {
+                group(tn, lon, hin);
+                gn = lon + lane < hin ? wk.perm[lon + lane] : 0u;
+            }
+        } else if (dyn) {
+            if (lane == 0u) ticket = wv::atomic_add_global(wk.lane_ticket, 1u);
         }
+#ifdef PLO_PHASE_TIMING
+        const long long tg0 = wv::realtime(), lt0 = ctx.tph[7], sr0 = ctx.tph[8], sc0 = ctx.tph[9], rd0 = ctx.tph[11];
+#endif
+        lane_tile<SP, false, NOSHIFT, STATS>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
+        wv::sync();
+#ifdef PLO_PHASE_TIMING
+        {
+            const long long dt = wv::realtime() - tg0;
+            ctx.g_n += 1;
+            ctx.g_max = dt > ctx.g_max ? dt : ctx.g_max;
+            ctx.g_prev = ctx.g_last;
+            ctx.g_last = dt;
+            ctx.g_last_begin = tg0;
+            // the group's record behind the waves' slots (tools/group_log.py): ticks, trip counts, rounds, where it ran
+            if (lane == 0u && t < 49152u) {
+                unsigned long long *r = wk.wave_stats + (size_t)8192 * STAT_WORDS + (size_t)t * 4;
+                r[0] = (unsigned long long)dt | ((unsigned long long)(tg0 - ctx.t_begin) << 32);
+                r[1] = (unsigned long long)(ctx.tph[7] - lt0) | ((unsigned long long)(ctx.tph[8] - sr0) << 32);
+                r[2] = (unsigned long long)(ctx.tph[9] - sc0) | ((unsigned long long)(ctx.tph[11] - rd0) << 32);
+                r[3] = (unsigned long long)lo | ((unsigned long long)(hi - lo) << 32) | ((unsigned long long)first << 44);
+            }
+        }
+#endif
+        if (!next_fixed && dyn) {
+            const uint32_t k = wv::bcast_first(ticket);
+            tn = k < n_groups ? k + t_base : 0xffffffffu;  // (k < n_groups first: the sum must not wrap)
+            if (tn < n_groups) {
+                group(tn, lon, hin);
+                gn = lon + lane < hin ? wk.perm[lon + lane] : 0u;
+            }
+        }
+        have = tn < n_groups;
+        t = tn;
+        lo = lon;
+        hi = hin;
+        g = gn;
     }
 }
 

@@ -759,10 +759,17 @@ struct WaveCtx {
     unsigned long long u_act = 0, u_trips = 0;
 #ifdef PLO_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader cycles per pipeline phase, flushed once per wave
+    long long t_begin = wv::realtime();  // the wave's life on the constant 100 MHz clock (plo_ctx_wave_clocks)
+    // lane kernel: groups lifted, the longest one's ticks, the last two groups' ticks, when the last one began
+    long long g_n = 0, g_max = 0, g_last = 0, g_prev = 0, g_last_begin = 0;
 #endif
 };
 constexpr unsigned long long SLAB_OPS = 16384;
+#ifdef PLO_PHASE_TIMING
+constexpr int STAT_WORDS = 16;  // (timing builds: + the wave's life and its groups' durations, plo_ctx_wave_clocks)
+#else
 constexpr int STAT_WORDS = 8;  // 64-bit words per statistics slot of a wave (five in use)
+#endif
 
 // A retiring wave leaves its statistics in its own slot (plain stores): 3 atomics per wave on one cache line used to cost a
 // fixed ~75 us per launch (3 072 waves x 3 atomics at ~88 per microsecond and address).  k_sum_stats adds the slots up.
@@ -787,8 +794,18 @@ PLO_DEV void wave_ctx_flush(const DevWork &wk, WaveCtx &ctx, uint32_t slot) {
     ctx.in_ops = 0;
     ctx.out_ops = 0;
 #ifdef PLO_PHASE_TIMING
-    if (wv::lane() == 0)
+    if (wv::lane() == 0) {
         for (int k = 0; k < 12; ++k) wv::atomic_add_global(&wk.counters[CNT_PHASE0 + k], (unsigned long long)ctx.tph[k]);
+        unsigned long long *w = wk.wave_stats + (size_t)(wk.stat_base + slot) * STAT_WORDS;  // (k_sum_stats leaves these three alone)
+        w[5] = (unsigned long long)ctx.t_begin;
+        w[6] = (unsigned long long)wv::realtime();
+        w[7] = (unsigned long long)wv::hw_id();
+        w[8] = (unsigned long long)ctx.g_n;
+        w[9] = (unsigned long long)ctx.g_max;
+        w[10] = (unsigned long long)ctx.g_last;
+        w[11] = (unsigned long long)ctx.g_prev;
+        w[12] = (unsigned long long)ctx.g_last_begin;
+    }
 #endif
 }
 

@@ -120,6 +120,11 @@ struct DevWork {
     const uint32_t *lane_groups;    // [2 * n]: lo, count
     const uint32_t *lane_n_groups;  // [1]
     uint32_t lane_groups_cap;       // groups `lane_groups` has room for (more would be a sizing bug: reported through CNT_ERROR)
+    // lane-per-item kernel, groups dealt dynamically (lane_tiles_persistent): the launch's ticket counter (zero at its start; NULL: fixed slots
+    // only), the counter of the context's NEXT launch (zeroed by this one's first wave), the rounds every wave takes by fixed slots first
+    uint32_t *lane_ticket;
+    uint32_t *lane_ticket_next;
+    uint32_t lane_static_rounds;
 };
 
 }  // namespace plo

@@ -18,6 +18,12 @@ namespace wv {
 
 PLO_DEV int lane() { return (int)__lane_id(); }
 PLO_DEV long long clock() { return (long long)__builtin_amdgcn_s_memtime(); }
+PLO_DEV long long realtime() { return (long long)__builtin_amdgcn_s_memrealtime(); }  // constant 100 MHz, the same on every XCD
+PLO_DEV unsigned hw_id() {  // HW_ID (wave / SIMD / CU / SH / SE) in the low half, XCC_ID in bits 16 ..
+    unsigned h, x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(h), "=s"(x));
+    return (h & 0xffffu) | (x << 16);
+}
 
 // LDS (or wave-private global scratch) hand-off between lanes of ONE wave: DS operations of a wave execute in
 // order, so all that is needed is to stop the compiler from moving memory accesses across this point.

@@ -282,6 +282,14 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
         }
         if (n_small) {  // k_lift_lanes: persistent waves over the groups of the two lane classes
             std::vector<uint32_t> llds((size_t)lane_capw + LANE_KVS_DWORDS + 16, 0xdeadbeefu);
+            // groups dealt by tickets behind 1 .. 3 rounds of fixed slots (runs with an order seed; the emulated waves run one after the
+            // other, so the first wave to get there takes every ticket: each group must still be lifted exactly once)
+            uint32_t ticket = 0, ticket_next = 0xffffffffu;
+            if (order_seed) {
+                wk.lane_ticket = &ticket;
+                wk.lane_ticket_next = &ticket_next;
+                wk.lane_static_rounds = 1u + (order_seed >> 2) % 3u;
+            }
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
