@@ -207,13 +207,16 @@ typedef struct plo_timing {
     uint32_t struct_size;
     float total_ms;      /* first kernel start -> last kernel end                                   */
     float enumerate_ms;  /* item enumeration + scans                                                */
-    float lift_ms;       /* the wave-cooperative tile kernel (longer CIGARs)                         */
+    float lift_ms;       /* the wave-cooperative tile kernels of the scan formulation (k_lift_tiles*: light items of batches the lane
+                            kernel does not take)                                                      */
     float big_ms;        /* one-wave-per-item kernel in global scratch (0 if not launched)          */
     uint32_t n_items;
     uint32_t n_big_items; /* items of that kernel */
     uint64_t n_in_ops;   /* input CIGAR ops over all items                                          */
     uint64_t n_out_ops;  /* output CIGAR ops                                                        */
-    uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device */
+    uint64_t algo_bytes; /* algorithmic bytes of the call, SURVEY.md 8(d) formula, counted on device.  The light-item kernel
+                            (k_lift_lanes) counts them only on a context with plo_ctx_set_stats(ctx, 1): its production
+                            instantiation is compiled without the counters (0 from its items otherwise)              */
     float lanes_ms;      /* the lane-per-item kernel (k_lift_lanes: items whose working region fits an LDS share)  */
     float retry_ms;      /* items of tiles that overflowed their LDS slice, re-run one per wave       */
     uint32_t n_lane_items;
@@ -225,11 +228,12 @@ typedef struct plo_timing {
     uint32_t tile_cap;     /* geometry of the tile kernel for this batch: elements per LDS slice (256: the variant with the
                               capacity compiled in, k_lift_tiles_c256) and window of item weights per tile        */
     uint32_t tile_window;
-    float heavy_lanes_ms;        /* the lane-per-item kernel over heavy items (k_lift_lanes_g: regions in global scratch
-                                    behind LDS windows); lift_ms / mid_ms are 0 then                                   */
+    float heavy_lanes_ms;        /* the heavy items' lane-per-item kernel, `heavy_kernel` says which (k_lift_lanes_g / _w3: regions in
+                                    global scratch behind LDS windows; k_lift_stream: teams of waves); lift_ms / mid_ms are 0 then */
     uint32_t n_heavy_lane_items;
     float lane_utilisation;      /* lane-per-item kernels: lanes at work / (64 x loop trips), summed over the liftover loop and the
-                                    shift stage's event rounds of all waves (0 when no such kernel ran)                      */
+                                    shift stage's event rounds of all waves (0 when no such kernel ran; the light-item kernel
+                                    counts only under plo_ctx_set_stats, as for algo_bytes)                                   */
     uint32_t heavy_kernel;       /* which kernel `heavy_lanes_ms` is the time of: 0 none, 1 k_lift_lanes_g, 2 k_lift_lanes_g_w3,
                                     3 k_lift_stream (teams of waves, stages chained through LDS rings)                       */
     uint32_t host_syncs;         /* host round trips of the call (stream synchronisations that returned counts to the host)  */
@@ -246,6 +250,9 @@ plo_status plo_index_segment_map(const plo_index *index, uint32_t global_seg, ui
 /* `hip_stream`: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one */
 plo_status plo_ctx_create(const plo_index *index, void *hip_stream, plo_ctx **out);
 void plo_ctx_destroy(plo_ctx *ctx);
+/* on != 0: the light-item kernel of this context's later calls counts plo_timing::algo_bytes and lane_utilisation (an instantiation with
+   the counters in its loops, a few per cent slower); default: off, or what the environment's PLO_LANE_STATS says at plo_ctx_create */
+plo_status plo_ctx_set_stats(plo_ctx *ctx, int on);
 
 /* Host buffers in, host (pinned, context-owned) buffers out; synchronous. */
 plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);

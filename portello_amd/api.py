@@ -80,6 +80,8 @@ def load_library(path: Optional[str] = None):
     L.plo_ctx_sync.argtypes = [vp]
     L.plo_ctx_download.restype = C.c_int
     L.plo_ctx_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.plo_ctx_set_stats.restype = C.c_int
+    L.plo_ctx_set_stats.argtypes = [vp, C.c_int]
     L.plo_api_version.restype = C.c_uint32
     L.plo_ctx_timing.restype = C.c_int
     L.plo_ctx_timing.argtypes = [vp, C.POINTER(abi.PloTiming)]
@@ -144,6 +146,12 @@ class Engine:
         if st != abi.PLO_OK:
             raise PortelloError(st, "plo_ctx_create failed")
         self.handle = h
+
+    def set_stats(self, on: bool = True):
+        """plo_ctx_set_stats: the light-item kernel counts timing().algo_bytes / lane_utilisation from the next call on (its production
+        instantiation is compiled without the counters)"""
+        self._check(self.lib.plo_ctx_set_stats(self.handle, 1 if on else 0), "plo_ctx_set_stats")
+        return self
 
     def _check(self, st: int, what: str):
         if st != abi.PLO_OK:

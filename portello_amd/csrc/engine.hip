@@ -937,7 +937,7 @@ constexpr int LANE_WAVES = 4;
 #define PLO_LANE_G_WPE 2  // k_lift_lanes_g: the windows' bookkeeping on top of 168 registers would spill; 12 KB of LDS per wave anyway
 #endif
 constexpr int LANE_G_WAVES = 4;
-template <bool SP, bool STATS>
+template <bool SP, bool STATS, bool H16>
 PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
@@ -953,34 +953,27 @@ PLO_DEV void lift_lanes_kernel(const DevIndex &ix, const DevBatch &bt, const Dev
     }
     // (the ticket counter of the context's next launch: not in use during this one)
     if (wk.lane_ticket_next && b == 0u && threadIdx.x == 0u) *wk.lane_ticket_next = 0u;
-    lane_tiles_persistent<SP, false, STATS>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + LANE_KVS_DWORDS), capw, ctx);
+    const int kvs_n = wk.lane_kvs ? (int)wk.lane_kvs : LANE_KVS;
+    lane_tiles_persistent<SP, false, STATS, H16>(ix, bt, wk, stages, wave, n_waves, n0, n1, gs, (uint32_t *)smem + (size_t)w * (size_t)(capw + 2 * kvs_n), capw, ctx, 0u, kvs_n);
     wave_ctx_flush(wk, ctx, wave);
 }
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                   uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
-    if (totals_dev) {  // (the one-round-trip path: the class counts are on the device only)
-        n0 = totals_dev[0];
-        n1 = totals_dev[1];
+#define PLO_LANE_KERNEL(name, SP_, STATS_, H16_)                                                                                                             \
+    __global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void name(                             \
+        DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0, uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {                   \
+        if (totals_dev) { /* (the one-round-trip path: the class counts are on the device only) */                                                             \
+            n0 = totals_dev[0];                                                                                                                                 \
+            n1 = totals_dev[1];                                                                                                                                 \
+        }                                                                                                                                                       \
+        lift_lanes_kernel<SP_, STATS_, H16_>(ix, bt, wk, stages, n0, n1, gs, capw);                                                                             \
     }
-    lift_lanes_kernel<false, false>(ix, bt, wk, stages, n0, n1, gs, capw);
-}
-// the same with the launch's statistics counted (plo_timing::algo_bytes, lane_utilisation): contexts created under PLO_LANE_STATS=1
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_stats(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                         uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
-    if (totals_dev) {
-        n0 = totals_dev[0];
-        n1 = totals_dev[1];
-    }
-    lift_lanes_kernel<false, true>(ix, bt, wk, stages, n0, n1, gs, capw);
-}
-__global__ __launch_bounds__(LANE_WAVES * 64) __attribute__((amdgpu_waves_per_eu(PLO_LANE_WPE_MIN, PLO_LANE_WPE))) void k_lift_lanes_sp(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, uint32_t n0,
-                                                                                                      uint32_t n1, uint32_t gs, int capw, const uint32_t *totals_dev) {
-    if (totals_dev) {
-        n0 = totals_dev[0];
-        n1 = totals_dev[1];
-    }
-    lift_lanes_kernel<true, false>(ix, bt, wk, stages, n0, n1, gs, capw);
-}
+PLO_LANE_KERNEL(k_lift_lanes, false, false, false)        // production: no statistics counters in the loops
+PLO_LANE_KERNEL(k_lift_lanes_stats, false, true, false)   // plo_ctx_set_stats / PLO_LANE_STATS=1: algo_bytes and lane_utilisation counted
+PLO_LANE_KERNEL(k_lift_lanes_sp, true, false, false)      // sparse read bases (PLO_SEQ_BAM4_SPARSE)
+// 16-bit ops in the regions (lane_core.hpp, H16; PLO_LANE_H16=1, stage sets with the liftover): measured in round 6, 5-10 % slower than the 32-bit
+// regions at every geometry tried (EXPERIMENTS 6.4) -- the conversions and the chunk tests cost more instructions than the halved LDS buys
+PLO_LANE_KERNEL(k_lift_lanes16, false, false, true)
+PLO_LANE_KERNEL(k_lift_lanes16_stats, false, true, true)
+#undef PLO_LANE_KERNEL
 
 // The same lane-per-item code for HEAVY items (too heavy for an LDS region: indel-dense or very long CIGARs), every lane's region in
 // wave-private global scratch and reached through per-lane LDS windows (lane_core.hpp, LaneWin); `per` items per wave.
@@ -1464,6 +1457,9 @@ struct plo_ctx {
     DevBuf lane_ticket;
     uint32_t lane_epoch = 0;
     int lane_static_rounds = 1;
+    int lane_tail_rounds = 1;  // PLO_LANE_TAIL: rounds' worth of cheap groups (no shift stage) dealt last (0: classes one to one)
+    int lane_kvs = LANE_KVS;  // block-map entries staged per wave (PLO_LANE_KVS: 64 .. LANE_KVS_MAX)
+    bool lane_h16 = false;    // PLO_LANE_H16=1: 16-bit regions (k_lift_lanes16; stage sets with the liftover)
     bool lane_stats = false;  // PLO_LANE_STATS=1: the light-item kernel that counts algorithmic bytes and lane utilisation (k_lift_lanes_stats)
     int lane_sort_window = LANE_SORT_WINDOW;
     // groups cut by LDS budget inside larger sort windows (k_chunk_sort, lane_groups_cut): on for batches whose groups are of 64
@@ -1723,10 +1719,16 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     (void)hipFuncSetAttribute((const void *)k_lift_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_lift_lanes_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lift_lanes16_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *e = getenv("PLO_LANE_MAX_W")) c->lane_max_w = atoi(e);
     if (const char *e = getenv("PLO_LANE_SORT")) c->lane_sort = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_STATIC")) c->lane_static_rounds = atoi(e);
     if (const char *e = getenv("PLO_LANE_STATS")) c->lane_stats = atoi(e) != 0;
+    if (const char *e = getenv("PLO_LANE_H16")) c->lane_h16 = atoi(e) != 0;
+    if (const char *e = getenv("PLO_LANE_TAIL")) c->lane_tail_rounds = std::max(0, atoi(e));
+    if (const char *e = getenv("PLO_LANE_KVS")) c->lane_kvs = std::min(LANE_KVS_MAX, std::max(64, atoi(e) & ~63));
+    if (!c->lane_h16) c->lane_kvs = std::min(c->lane_kvs, LANE_KVS);
     if (const char *e = getenv("PLO_LANE_SORT_WINDOW")) c->lane_sort_window = c->lane_budget_window = std::min(2048, std::max(64, atoi(e) & ~63));
     if (const char *e = getenv("PLO_LANE_BUDGET")) c->lane_budget = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_HEAVY_MIN")) c->lane_heavy_min = atoi(e);
@@ -1774,6 +1776,12 @@ void plo_ctx_destroy(plo_ctx *c) {
 
 const char *plo_last_error(const plo_ctx *c) { return c ? c->err.c_str() : g_index_err.c_str(); }
 
+plo_status plo_ctx_set_stats(plo_ctx *c, int on) {
+    if (!c) return PLO_ERR_INVALID_ARG;
+    c->lane_stats = on != 0;
+    return PLO_OK;
+}
+
 plo_status plo_ctx_sync(plo_ctx *c) {
     if (!c) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1783,6 +1791,14 @@ plo_status plo_ctx_sync(plo_ctx *c) {
 // debugging aid (timing builds, -DPLO_PHASE_TIMING): shader cycles spent per pipeline phase, summed over waves
 void plo_ctx_phase_cycles(plo_ctx *c, unsigned long long *out12) {
     for (int k = 0; k < 12; ++k) out12[k] = c ? c->phase_cycles[k] : 0;
+}
+// debugging aid: the item indices the last batch's lane kernels handed to the retry list (first `max_items` of them); returns how many were copied
+unsigned plo_ctx_debug_retry_list(plo_ctx *c, unsigned *out, unsigned max_items) {
+    if (!c || !out || !c->retry_list.p) return 0;
+    const unsigned n = (unsigned)std::min<size_t>(std::min<size_t>(max_items, c->timing.n_retry_items), c->retry_list.cap / 4);
+    if (hipSetDevice(c->ix->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    if (n && hipMemcpy(out, c->retry_list.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 // debugging aid (timing builds): the raw statistic slots of the last batch's lift waves, STAT_WORDS words each -- [5] / [6] the wave's first and
 // last tick of the constant 100 MHz clock, [7] its HW_ID | XCC_ID << 16 (tools/wave_timeline.py); returns the slots copied
@@ -1818,9 +1834,20 @@ static plo_status scan_u32(plo_ctx *c, const uint32_t *in, uint32_t n, uint32_t 
     return PLO_OK;
 }
 
+// which instantiation of the light-item kernel a call takes
+typedef void (*lane_kernel_t)(DevIndex, DevBatch, DevWork, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t *);
+static lane_kernel_t lane_kernel_of(const plo_ctx *c, uint32_t stages, bool sp) {
+    if (sp) return k_lift_lanes_sp;
+    const bool h16 = c->lane_h16 && (stages & PLO_STAGE_LIFTOVER) != 0u;  // (16-bit regions need LOAD's merged op codes)
+    if (h16) return c->lane_stats ? k_lift_lanes16_stats : k_lift_lanes16;
+    return c->lane_stats ? k_lift_lanes_stats : k_lift_lanes;
+}
+
 // The lane kernel's ticket counters (lane_tiles_persistent): this launch's -- zero, because the context's previous launch cleared it or the
 // allocation did -- and the next launch's, which this one clears.  Without them (PLO_LANE_STATIC < 0, or no memory) the waves keep to fixed slots.
 static void lane_ticket_arm(plo_ctx *c, DevWork &wk) {
+    wk.lane_kvs = (uint32_t)c->lane_kvs;
+    wk.lane_tail_rounds = (uint32_t)c->lane_tail_rounds;
     wk.lane_ticket = nullptr;
     wk.lane_ticket_next = nullptr;
     wk.lane_static_rounds = 0;
@@ -2169,7 +2196,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
 
     // launch geometry of the lane-per-item kernel (light items), needed here already: its waves own one output slab each from the start
     uint32_t lane_gs = 64, lane_nblk = 0;
-    const size_t lane_lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;  // slices + staged block-map entries
+    const size_t lane_lds = (size_t)(c->lane_capw + 2 * c->lane_kvs) * 4 * LANE_WAVES;  // slices + staged block-map entries
     if (n_small) {
         int occ = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sp ? (const void *)k_lift_lanes_sp : (const void *)k_lift_lanes, LANE_WAVES * 64, lane_lds) != hipSuccess || occ < 1)
@@ -2240,9 +2267,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
             lane_ticket_arm(c, wk);
-            if (sp) hipLaunchKernelGGL(k_lift_lanes_sp, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
-            else if (c->lane_stats) hipLaunchKernelGGL(k_lift_lanes_stats, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
-            else hipLaunchKernelGGL(k_lift_lanes, dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
+            hipLaunchKernelGGL(lane_kernel_of(c, stages, sp), dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(c->ev[4], st));
@@ -2517,7 +2542,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->fast_item_cap = n_items;
     c->fast_n0 = h_cls[0];
     c->fast_n1 = h_cls[1];
-    c->fast_light_only = n_items > 0 && n_items == n_small && n_retry == 0 && n_big == 0 && n_miss == 0;
+    // (items the lane kernel handed to the retry kernel are fine: the fast path runs that kernel too; items IT hands on are not)
+    c->fast_light_only = n_items > 0 && n_items == n_small && n_big == 0 && n_miss == 0;
     c->timing.n_retry_items = n_retry;
     if (c->adaptive && c->cap == TILE_CAP_SMALL && n_retry > n_items / 200) c->small_window_tight = true;
     c->timing.n_in_ops = hc[CNT_IN_OPS];
@@ -2598,7 +2624,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     // launch geometry from the last batch's class counts (a window of the same shape has the same): group size, persistent grid
     uint32_t lane_gs = 64, lane_nblk = 0;
-    const size_t lane_lds = (size_t)(c->lane_capw + LANE_KVS_DWORDS) * 4 * LANE_WAVES;
+    const size_t lane_lds = (size_t)(c->lane_capw + 2 * c->lane_kvs) * 4 * LANE_WAVES;
     {
         int occ = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_lift_lanes, LANE_WAVES * 64, lane_lds) != hipSuccess || occ < 1) occ = 1;
@@ -2630,8 +2656,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
         c->seq_pending = false;
     }
     lane_ticket_arm(c, wk);
-    if (c->lane_stats) hipLaunchKernelGGL(k_lift_lanes_stats, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
-    else hipLaunchKernelGGL(k_lift_lanes, dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
+    hipLaunchKernelGGL(lane_kernel_of(c, stages, false), dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
     {

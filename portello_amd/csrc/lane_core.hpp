@@ -74,18 +74,73 @@ struct LaneOut {
     bool seen_m = false;
     bool pairs = false;     // two neighbouring I / D ops were written: an indel cluster of more than one op
     bool ovf = false;       // a write would have passed `wlim`
+    // H16 (16-bit ops in the region, below): `no` counts HALFWORDS, `extra` those of them that continue an op longer than H16_MAX
+    // (counted where they are written, which is rare: the ops written are no - extra)
+    uint16_t *H = nullptr;
+    int extra = 0;
 };
 PLO_DEV int wrap_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 PLO_DEV bool b_is_match(int t) { return ((0x181u >> t) & 1u) != 0u; }   // M = X
 PLO_DEV bool b_is_indel(int t) { return (unsigned)(t - 1) < 2u; }        // I D
 PLO_DEV bool b_ref_cons(int t) { return ((0x18Du >> t) & 1u) != 0u; }   // M D N = X
 PLO_DEV bool b_read_cons(int t) { return ((0x1B3u >> t) & 1u) != 0u; }  // M I S H = X
+
+// -------------------------------------------------------------------------------------------------------------------
+// H16: the light-item kernel's regions hold 16-BIT ops (round 6; VERDICT r4 / r5 asked for the format itself instead of a proxy).
+// A halfword is (len << 3) | type with the BAM op codes 0 .. 6 (M I D N S H P) -- after LOAD has merged = / X / M runs into M, which it
+// does whenever the liftover runs (batches of other stage sets keep the 32-bit regions), no other code occurs -- and len <= H16_MAX = 8 191.
+// A longer op is stored as up to H16_CHUNKS neighbouring halfwords of its type (the first ones full): every stage treats equal
+// neighbours as the reference treats their sum -- the shift builder and the simplify stage add up the members of a cluster and the
+// match bases between clusters op by op, the liftover cuts ops into pieces anyway and its writer merges what comes of neighbouring
+// pieces -- and the output copy sums them up again.  Beyond H16_CHUNKS halfwords (65 528 bases in one op: no HiFi read's clip) the item takes the retry list.
+// In registers ops stay (len << 4) | type.  What it buys: a region of ~90 bytes instead of ~175, i.e. twice the items, or four times
+// the staged block-map entries and wider sort windows, in the same LDS slice.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int H16_MAX = 8191, H16_CHUNKS = 8;
+constexpr int H16_ALLOW = 4;  // halfwords a region has for the extra chunks of its long ops (more: the writer's / LOAD's overflow check -> retry list)
+PLO_DEV uint32_t h16_dec(uint32_t h) { return ((h >> 3) << 4) | (h & 7u); }
+PLO_DEV uint32_t h16_enc(int t, uint32_t len) { return (len << 3) | (uint32_t)t; }
+
+// the open run `o.acc` goes out for the lanes `flush` (H16: in chunks); `wlim`: first index that must not be written
+template <int ST, bool H16>
+PLO_DEV void lane_flush(LaneOut &o, bool flush, int wlim) {
+    const int at = (int)(o.acc & 15u);
+    if constexpr (!H16) {
+        const bool ok = o.no < wlim;
+        if (flush & ok) o.R[o.no * ST] = o.acc;
+        o.ovf = o.ovf | (flush & !ok);
+        o.no += flush ? 1 : 0;
+    } else {
+        static_assert(ST == 1, "H16 regions are lane-contiguous");
+        const uint32_t len = o.acc >> 4;
+        const bool ok = o.no < wlim;
+        if (flush & ok) o.H[o.no] = (uint16_t)h16_enc(at, len < (uint32_t)H16_MAX ? len : (uint32_t)H16_MAX);
+        o.ovf = o.ovf | (flush & !ok);
+        o.no += flush ? 1 : 0;
+        const bool big = flush & (len > (uint32_t)H16_MAX);
+        if (wv::ballot(big) != 0ull) {  // (three runs in a thousand)
+            uint32_t rest = big ? len - (uint32_t)H16_MAX : 0u;
+#pragma unroll
+            for (int c = 1; c < H16_CHUNKS; ++c) {
+                const bool more = rest > 0u;
+                const uint32_t part = rest < (uint32_t)H16_MAX ? rest : (uint32_t)H16_MAX;
+                const bool okc = o.no < wlim;
+                if (more & okc) o.H[o.no] = (uint16_t)h16_enc(at, part);
+                o.ovf = o.ovf | (more & !okc);
+                o.no += more ? 1 : 0;
+                o.extra += more ? 1 : 0;
+                rest -= part;
+            }
+            o.ovf = o.ovf | (rest > 0u);
+        }
+    }
+}
 // Flags are `bool`s combined with & | ^ (no short-circuit: the code must stay one basic block).
 // `wlim`: first index that must not be written (the reader's position when the region is used in place).  PAD: the stream may
 // hold Pad ops (absent from compress_cigar's summing pattern, :210-212: a Pad following a Pad adds nothing).
 // ST: distance of neighbouring ops in o.R (1; 64: the write window of a heavy item, whose writer stops for good at the first op
 // that does not fit -- its window indices mean nothing from there).
-template <bool PAD = true, int ST = 1>
+template <bool PAD = true, int ST = 1, bool H16 = false>
 PLO_DEV void lane_push(LaneOut &o, bool on, int t, int L, int wlim) {
     if constexpr (ST != 1) on = on & !o.ovf;
     const bool lead = on & !o.seen_m;
@@ -97,60 +152,90 @@ PLO_DEV void lane_push(LaneOut &o, bool on, int t, int L, int wlim) {
     const int at = (int)(o.acc & 15u);
     const bool same = live & (t == at);
     const bool flush = live & !same & (o.acc >= 16u);
-    const bool ok = o.no < wlim;
-    if (flush & ok) o.R[o.no * ST] = o.acc;
-    o.ovf = o.ovf | (flush & !ok);
     o.pairs = o.pairs | (flush & b_is_indel(at) & b_is_indel(t));
-    o.no += flush ? 1 : 0;
+    lane_flush<ST, H16>(o, flush, wlim);
     const uint32_t add = (PAD && t == OP_P) ? 0u : ((uint32_t)L << 4);
     o.acc = same ? o.acc + add : (live ? mk_op(t, L) : o.acc);
 }
 // wave-uniform call (the loops are bounded by ballots); `on`: lanes that own a writer
+template <bool H16 = false>
 PLO_DEV void lane_out_finish(LaneOut &o, bool on, int wlim) {
-    {
-        const bool flush = on & (o.acc >= 16u);
-        const bool ok = o.no < wlim;
-        if (flush & ok) o.R[o.no] = o.acc;
-        o.ovf = o.ovf | (flush & !ok);
-        o.no += flush ? 1 : 0;
-    }
+    lane_flush<1, H16>(o, on & (o.acc >= 16u), wlim);
     // trailing edge: the ops behind the last alignment match (if none was written, everything went through the leading rule
-    // already).  They are few: found by walking back from the end.
+    // already).  They are few.
     const bool fix0 = on & !o.ovf & o.seen_m;
-    int lm = o.no - 1;
-    {
-        bool look = fix0 & (lm >= 0);
-        while (wv::ballot(look) != 0ull) {
-            const uint32_t c = o.R[look ? lm : 0];
-            const bool hit = look & b_is_match(op_type(c));
-            look = look & !hit & (lm > 0);
-            lm -= (look) ? 1 : 0;
-            // (a lane leaves the loop on its last match, or at index 0 without one -- which seen_m rules out)
+    if constexpr (H16) {
+        // found by walking back from the end (the chunks of a long match are matches); the tail then goes through a second writer from
+        // there (edge rule: I -> S, D dropped; merging and chunking as everywhere): it shrinks or keeps the tail, so it never passes
+        // the position it reads at
+        int lm = o.no - 1;
+        {
+            bool look = fix0 & (lm >= 0);
+            while (wv::ballot(look) != 0ull) {
+                const uint32_t c = o.H[look ? lm : 0];
+                const bool hit = look & b_is_match((int)(c & 7u));
+                look = look & !hit & (lm > 0);
+                lm -= (look) ? 1 : 0;
+            }
         }
-    }
-    const bool fix = fix0 & (lm + 1 < o.no);
-    int i = lm + 1, w = lm + 1;
-    uint32_t run = 0;  // open run of the rewritten tail (0: none)
-    while (wv::ballot(fix & (i < o.no)) != 0ull) {
-        const bool act = fix & (i < o.no);
-        const uint32_t c = o.R[act ? i : 0];
-        int t = op_type(c);
-        const int L = op_len(c);
-        i += act ? 1 : 0;
-        const bool keep = act & (t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
-        t = (t == OP_I) ? (int)OP_S : t;
-        const bool same = keep & (run >= 16u) & (t == (int)(run & 15u));
-        const bool flush = keep & !same & (run >= 16u);
-        if (flush) o.R[w] = run;
-        w += flush ? 1 : 0;
-        const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
-        run = same ? run + add : (keep ? mk_op(t, L) : run);
-    }
-    {
-        const bool flush = fix & (run >= 16u);
-        if (flush) o.R[w] = run;
-        w += flush ? 1 : 0;
-        o.no = fix ? w : o.no;
+        const bool fix = fix0 & (lm + 1 < o.no);
+        LaneOut o2;
+        o2.H = o.H;
+        o2.no = lm + 1;
+        o2.seen_m = true;
+        int i = lm + 1, cont = 0, prev_t = -1;  // cont: halfwords of the old tail that continue an op
+        while (wv::ballot(fix & (i < o.no)) != 0ull) {
+            const bool act = fix & (i < o.no);
+            const uint32_t c = h16_dec(o.H[act ? i : 0]);
+            int t = op_type(c);
+            const int L = op_len(c);
+            i += act ? 1 : 0;
+            cont += (act & (t == prev_t)) ? 1 : 0;
+            prev_t = act ? t : prev_t;
+            const bool keep = act & (t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
+            t = (t == OP_I) ? (int)OP_S : t;
+            lane_push<true, 1, true>(o2, keep, t, L, i);
+        }
+        lane_flush<1, true>(o2, fix & (o2.acc >= 16u), o.no);
+        o.no = fix ? o2.no : o.no;
+        o.extra = fix ? o.extra - cont + o2.extra : o.extra;
+    } else {
+        // found by walking back from the end
+        int lm = o.no - 1;
+        {
+            bool look = fix0 & (lm >= 0);
+            while (wv::ballot(look) != 0ull) {
+                const uint32_t c = o.R[look ? lm : 0];
+                const bool hit = look & b_is_match(op_type(c));
+                look = look & !hit & (lm > 0);
+                lm -= (look) ? 1 : 0;
+                // (a lane leaves the loop on its last match, or at index 0 without one -- which seen_m rules out)
+            }
+        }
+        const bool fix = fix0 & (lm + 1 < o.no);
+        int i = lm + 1, w = lm + 1;
+        uint32_t run = 0;  // open run of the rewritten tail (0: none)
+        while (wv::ballot(fix & (i < o.no)) != 0ull) {
+            const bool act = fix & (i < o.no);
+            const uint32_t c = o.R[act ? i : 0];
+            int t = op_type(c);
+            const int L = op_len(c);
+            i += act ? 1 : 0;
+            const bool keep = act & (t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
+            t = (t == OP_I) ? (int)OP_S : t;
+            const bool same = keep & (run >= 16u) & (t == (int)(run & 15u));
+            const bool flush = keep & !same & (run >= 16u);
+            if (flush) o.R[w] = run;
+            w += flush ? 1 : 0;
+            const uint32_t add = (t == OP_P) ? 0u : ((uint32_t)L << 4);
+            run = same ? run + add : (keep ? mk_op(t, L) : run);
+        }
+        {
+            const bool flush = fix & (run >= 16u);
+            if (flush) o.R[w] = run;
+            w += flush ? 1 : 0;
+            o.no = fix ? w : o.no;
+        }
     }
 }
 
@@ -453,18 +538,24 @@ PLO_DEV void win_flush(LaneWin &w, bool on, int end) {
 // an L2 round trip in every iteration of every group.  Items whose window lies outside the staged range keep the global loads.
 constexpr int LANE_KVS = 128;                  // staged entries per wave
 constexpr int LANE_KVS_DWORDS = 2 * LANE_KVS;  // behind the wave's slice (lds + capw) / windows (lds + 64 * LANE_WIN_DWORDS)
+// The light-item kernel takes the number of staged entries from the launch (DevWork::lane_kvs, a multiple of 64 up to LANE_KVS_MAX): groups
+// of a sort window wider than 128 reads are every n-th read of a longer stretch of the contig, and their union of block-map entries grows
+// with the window (wgs30x, 4.8-fold coverage per haplotype: ~0.15 entries per kb, 64 neighbouring reads span 200 kb, 512 span 1.6 Mb).
+constexpr int LANE_KVS_MAX = 512;
 // NOSHIFT: an instantiation for groups of the class without the shift stage (forward-mapped contig segments), compiled without that
 // stage's code and state -- lanes that would need it are handed to the retry list (the class order keeps them away).
 // STATS: the launch counts its algorithmic bytes (SURVEY.md 8(d)'s B_item per item: plo_timing::algo_bytes) and the lanes at work per
 // loop trip (plo_timing::lane_utilisation).  The production instantiation of the light-item kernel is compiled WITHOUT them (the trip
 // counters sat in the two hot loops: an s_bcnt1 and two 64-bit adds per trip); a context asks for the counting kernel with
 // PLO_LANE_STATS=1 (bench.py's statistics pass, tools/, the tests of plo_timing).
-template <bool SP, bool WIN = false, bool NOSHIFT = false, bool STATS = true>
+// H16: 16-bit ops in the regions (above); only without WIN, and only for stage sets with the liftover (the caller's business).
+template <bool SP, bool WIN = false, bool NOSHIFT = false, bool STATS = true, bool H16 = false>
 PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t item_begin, int nit,
                        uint32_t *lds, int capw, int fixed_stride, WaveCtx &ctx, const uint32_t *list, bool have_g, uint32_t g_pre,
-                       uint32_t *greg = nullptr, uint32_t *kvs = nullptr) {
+                       uint32_t *greg = nullptr, uint32_t *kvs = nullptr, int kvs_n = LANE_KVS) {
     // WIN (heavy items): `lds` = 64 x LANE_WIN_DWORDS dwords of LDS for the lanes' windows, `greg` = 64 regions of fixed_stride dwords
     // in global memory; else: `lds` = the wave's slice of capw dwords, the regions themselves.
+    static_assert(!(H16 && WIN), "16-bit ops: LDS regions only");
     const int lane = wv::lane();
     const bool has = lane < nit;
     const uint32_t g = have_g ? g_pre : (has ? list[item_begin + (uint32_t)lane] : 0u);
@@ -514,29 +605,36 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
     const bool merges = do_shift || (stages & PLO_STAGE_LIFTOVER);
     const int n_ld = merges ? n_m : n_in;
     const int gap = has ? lane_region_gap(W0, W1) : 0;
-    const int W = n_ld + gap + LANE_SLACK;  // dwords
+    // (H16: in halfwords, with room for the extra chunks of long ops; the slice is shared out in dwords)
+    const int W = n_ld + gap + LANE_SLACK + (H16 ? H16_ALLOW : 0);  // dwords (H16: halfwords)
+    const int W_dw = H16 ? (W + 1) >> 1 : W;
 
     // ---- block-map entries of the group -> LDS (loads now; the stores follow the LOAD pass, whose round trip covers this one) ----
     int kvs_base = 0, kvs_cnt = 0;
     bool kv_lds = false, kvs_store = false;
-    KV kvs_e0 = {0, 0}, kvs_e1 = {0, 0};
+    constexpr int KVS_Q = H16 ? LANE_KVS_MAX / 64 : LANE_KVS / 64;  // loads per lane that stage the entries (32-bit regions: LANE_KVS entries at most)
+    if constexpr (!H16) kvs_n = kvs_n < LANE_KVS ? kvs_n : LANE_KVS;
+    KV kvs_e[KVS_Q];
+#pragma unroll
+    for (int q = 0; q < KVS_Q; ++q) kvs_e[q] = {0, 0};
     if (kvs != nullptr && (stages & PLO_STAGE_LIFTOVER)) {
         // the cursor of an item reads the entries [W0, min(kv1, W1 + 2)): its window and the look-ahead behind it
         const int need_hi = wv::imin(kv1, W1 + 2);
         kvs_base = -wv::reduce_max(has ? -W0 : -IMAX);
         const int top = wv::reduce_max(has ? need_hi : 0);
-        const int cnt = wv::imax(0, wv::imin(top - kvs_base, LANE_KVS));
+        const int cnt = wv::imax(0, wv::imin(top - kvs_base, kvs_n));
         kv_lds = has & (need_hi <= kvs_base + cnt);
         kvs_cnt = cnt;
-        if (lane < cnt) kvs_e0 = ix.kv[kvs_base + lane];
-        if (lane + 64 < cnt) kvs_e1 = ix.kv[kvs_base + lane + 64];
+#pragma unroll
+        for (int q = 0; q < KVS_Q; ++q)
+            if (64 * q < kvs_n && lane + 64 * q < cnt) kvs_e[q] = ix.kv[kvs_base + lane + 64 * q];
         kvs_store = true;
     }
 
     // items no region can hold (the class order keeps them away; tiny test capacities do not): the wave-cooperative path
     bool pending = has;
     {
-        const bool defer = has && (W > (WIN ? fixed_stride - LANE_REGION_PAD : capw) || (NOSHIFT && need_shift));
+        const bool defer = has && (W_dw > (WIN ? fixed_stride - LANE_REGION_PAD : capw) || (NOSHIFT && need_shift));
         const unsigned long long dm = wv::ballot(defer);
         if (dm != 0ull) {
             int slot = 0;
@@ -552,12 +650,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 
     // ---- rounds: the longest prefix of the pending items whose regions fit the slice (nearly always all of them) ----
     while (wv::ballot(pending) != 0ull) {
-        const int wv_ = pending ? W : 0;
+        const int wv_ = pending ? W_dw : 0;
         const int incl = WIN ? 0 : wv::scan_add(wv_);
         const bool act0 = pending && (WIN || incl <= capw);
         pending = pending && !act0;
         // R: where the stages read / write their ops by region index -- the region itself, or (WIN) re-pointed at a window
         uint32_t *R = WIN ? nullptr : lds + (act0 ? incl - wv_ : 0);
+        uint16_t *const R16 = (uint16_t *)R;  // (H16: the same region, indexed in halfwords)
         LaneWin win;
         if constexpr (WIN) {
             // (lanes without an item point at the wave's first region: the writer's clean-up reads o.R[0] unconditionally, and with fewer
@@ -580,10 +679,12 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         bool ovf = false, panic = false;
         unsigned algo = 0;
         int cur_off = 0, n = 0;  // the item's current CIGAR: R[cur_off .. cur_off + n)
+        int nops = 0;            // H16: its ops (n counts halfwords; an op longer than H16_MAX has several)
         constexpr int ST = WIN ? 64 : 1;
         // the op at R[cur_off + k] (lanes without one: some readable word)
         auto rd_at = [&](int k, bool ok) -> uint32_t {
             if constexpr (WIN) return win.rw[ok ? (cur_off + k - win.rbase) * 64 : 0];
+            else if constexpr (H16) return h16_dec(R16[cur_off + (ok ? k : 0)]);
             else return R[cur_off + (ok ? k : 0)];
         };
         // WIN, stages with the liftover: the first stage of an item -- the shift or the liftover, which take =, X and M ops alike --
@@ -612,6 +713,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
             if constexpr (WIN) {
                 win.wbase = base;
                 o.R = win.ww;
+            } else if constexpr (H16) {
+                o.H = R16 + base;
             } else {
                 o.R = R + base;
             }
@@ -631,7 +734,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                 win_flush(win, on & !o.ovf, base + o.no);
                 o.R = win.G + base;
             }
-            lane_out_finish(o, on, wlim);
+            lane_out_finish<H16>(o, on, wlim);
         };
         int pos = pos1;
         ReadSeq rd = item_read_seq<SP>(bt, seq_off, seq_len, flip ? 1 : 0);
@@ -650,18 +753,47 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         } else {
             const bool ld = act0;
             const bool merge = ld & merges;
-            const int inb = shift_on ? W - n_ld : gap;
+            const int inb = shift_on ? W - n_ld - (H16 ? H16_ALLOW : 0) : gap;
             const int nmax = wv::reduce_max(ld ? n_in : 0);
             const int n_cig = (int)bt.seg_cigar_off[bt.n_segs];  // ops in the batch's CIGAR buffer (wave-uniform)
             uint32_t run = 0;
             bool has_run = false;
             int w = 0;
             if constexpr (WIN) win.wbase = inb;
+            bool ld_ovf = false;  // H16: more chunks than the region allows
             auto put = [&](bool on, uint32_t v) {
                 if constexpr (WIN) {
                     if (on) win.ww[(inb + w - win.wbase) * 64] = v;
+                } else if constexpr (H16) {
+                    // (chunks: the first here, the others -- three runs in a thousand -- behind a wave-uniform test; `w` moves in put_more)
+                    // (a lone = or X is an M to the stages that follow, like the runs merged above: the format has codes 0 .. 6)
+                    const uint32_t len = v >> 4;
+                    const int vt = b_is_match((int)(v & 15u)) ? (int)OP_M : (int)(v & 15u);
+                    const bool ok = inb + w < W;
+                    if (on & ok) R16[inb + w] = (uint16_t)h16_enc(vt, len < (uint32_t)H16_MAX ? len : (uint32_t)H16_MAX);
+                    ld_ovf = ld_ovf | (on & !ok);
                 } else {
                     if (on) R[inb + w] = v;
+                }
+            };
+            auto put_more = [&](bool on, uint32_t v) {  // H16: the chunks after the first
+                if constexpr (H16) {
+                    const uint32_t len = v >> 4;
+                    const bool big = on & (len > (uint32_t)H16_MAX);
+                    if (wv::ballot(big) != 0ull) {
+                        uint32_t rest = big ? len - (uint32_t)H16_MAX : 0u;
+#pragma unroll
+                        for (int c = 1; c < H16_CHUNKS; ++c) {
+                            const bool more = rest > 0u;
+                            const uint32_t part = rest < (uint32_t)H16_MAX ? rest : (uint32_t)H16_MAX;
+                            const bool ok = inb + w < W;
+                            if (more & ok) R16[inb + w] = (uint16_t)h16_enc(b_is_match((int)(v & 15u)) ? (int)OP_M : (int)(v & 15u), part);
+                            ld_ovf = ld_ovf | (more & !ok);
+                            w += more ? 1 : 0;
+                            rest -= part;
+                        }
+                        ld_ovf = ld_ovf | (rest > 0u);
+                    }
                 }
             };
             // LB ops per round trip: LB / 4 loads of 16 bytes per lane (every lane reads its own CIGAR), ALL of them in flight together.
@@ -713,21 +845,26 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     const bool flush = have & has_run & !join;
                     put(flush, run);
                     w += flush ? 1 : 0;
+                    put_more(flush, run);
                     run = join ? ((run & ~15u) + (c & ~15u)) | (uint32_t)OP_M : (have ? c : run);
                     has_run = has_run | have;
                 }
             }
             put(ld & has_run, run);
             w += (ld & has_run) ? 1 : 0;
+            put_more(ld & has_run, run);
             if constexpr (WIN) win_flush(win, ld, inb + w);
             n = ld ? w : 0;
             cur_off = ld ? inb : 0;
+            if constexpr (H16) ovf = ovf | (ld & ld_ovf);
         }
         if (kvs_store) {  // (wave-uniform; once per group)
-            kvs[2 * lane] = (uint32_t)kvs_e0.key;
-            kvs[2 * lane + 1] = (uint32_t)kvs_e0.val;
-            kvs[2 * (lane + 64)] = (uint32_t)kvs_e1.key;
-            kvs[2 * (lane + 64) + 1] = (uint32_t)kvs_e1.val;
+#pragma unroll
+            for (int q = 0; q < KVS_Q; ++q)
+                if (64 * q < kvs_n) {  // (wave-uniform)
+                    kvs[2 * (lane + 64 * q)] = (uint32_t)kvs_e[q].key;
+                    kvs[2 * (lane + 64 * q) + 1] = (uint32_t)kvs_e[q].val;
+                }
             kvs_store = false;
         }
         wv::sync();
@@ -808,9 +945,9 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     int h = lane_probe_finish(pr, on, sref, shift_ref_len, rd, probes);
                     h = rd.miss ? 0 : h;
                     const int sh = wv::imin(p_match, h);  // actual_shift_len (:132)
-                    lane_push<false, ST>(o, on & (p_match - sh > 0), OP_M, p_match - sh, wl);
-                    lane_push<false, ST>(o, on & (p_ins > 0), OP_I, p_ins, wl);
-                    lane_push<false, ST>(o, on & (p_del > 0), OP_D, p_del, wl);
+                    lane_push<false, ST, H16>(o, on & (p_match - sh > 0), OP_M, p_match - sh, wl);
+                    lane_push<false, ST, H16>(o, on & (p_ins > 0), OP_I, p_ins, wl);
+                    lane_push<false, ST, H16>(o, on & (p_del > 0), OP_D, p_del, wl);
                     match = on ? sh + msince : match;
                     msince = on ? 0 : msince;
                     pend = pend & !on;
@@ -840,10 +977,10 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if (wv::ballot(flushing & pend) == 0ull) break;
                 }
                 if (wv::ballot(flushing) != 0ull) {  // add_other (:155-165); at the end: get_cigar()'s add_other(None) (:54-60)
-                    lane_push<false, ST>(o, flushing & (match > 0), OP_M, match, wl);
+                    lane_push<false, ST, H16>(o, flushing & (match > 0), OP_M, match, wl);
                     match = flushing ? 0 : match;
                     const bool oth = flushing & ev_other;
-                    lane_push<true, ST>(o, oth, ev_t, ev_L, wl + 1);
+                    lane_push<true, ST, H16>(o, oth, ev_t, ev_L, wl + 1);
                     read_head += (oth & b_read_cons(ev_t)) ? ev_L : 0;
                     ref_head += (oth & b_ref_cons(ev_t)) ? ev_L : 0;
                     k += oth ? 1 : 0;
@@ -984,7 +1121,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     in_op = in_op & !done;
                     seg_start = done ? seg_end : seg_start;
                     const int wl = ext ? W : cur_off + k;  // ops below R[cur_off + k] have been read
-                    lane_push<false, ST>(o, e0 | copy | e1p, e0 ? (int)OP_D : (copy ? tf : t1p), e0 ? d : (copy ? Lf : plen), wl);
+                    lane_push<false, ST, H16>(o, e0 | copy | e1p, e0 ? (int)OP_D : (copy ? tf : t1p), e0 ? d : (copy ? Lf : plen), wl);
                     kf = adv ? fk : kf;  // the entry after next (kv_fetch above)
                     vf = adv ? fv : vf;
                 }
@@ -1001,6 +1138,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     alive = false;
                 } else {
                     n = o.no;
+                    nops = o.no - o.extra;
                     cur_off = 0;
                     ext = false;
                     pos = r2s + o.lead_shift;  // :221
@@ -1082,13 +1220,13 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                         // kind only where some lane has them
                         const bool emit_id = endc & !one_one;
                         const bool both = wv::ballot(endc & !single) != 0ull;
-                        if (both) lane_push<false, ST>(o, endc & (pre > 0), OP_M, pre, wl);
+                        if (both) lane_push<false, ST, H16>(o, endc & (pre > 0), OP_M, pre, wl);
                         {
                             const bool first_d = emit_id & (ins == 0);  // (then the one op is the D, if anything)
-                            lane_push<false, ST>(o, emit_id & ((first_d ? del : ins) > 0), first_d ? (int)OP_D : (int)OP_I, first_d ? del : ins, wl);
+                            lane_push<false, ST, H16>(o, emit_id & ((first_d ? del : ins) > 0), first_d ? (int)OP_D : (int)OP_I, first_d ? del : ins, wl);
                             if (both) {
-                                lane_push<false, ST>(o, emit_id & !first_d & (del > 0), OP_D, del, wl);
-                                lane_push<false, ST>(o, endc & (post > 0), OP_M, post, wl);
+                                lane_push<false, ST, H16>(o, emit_id & !first_d & (del > 0), OP_D, del, wl);
+                                lane_push<false, ST, H16>(o, endc & (post > 0), OP_M, post, wl);
                             }
                         }
                         del = endc ? 0 : del;
@@ -1103,7 +1241,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     ins += (indel & (t == OP_I)) ? L : 0;
                     const bool cp = valid & !indel;
                     zero_m = zero_m | (cp & b_is_match(t) & (L == 0));  // an edge mark the writer would not see (LaneOut)
-                    lane_push<true, ST>(o, cp, t, L, wl);  // :144-147
+                    lane_push<true, ST, H16>(o, cp, t, L, wl);  // :144-147
                     read_head += (valid & b_read_cons(t)) ? L : 0;
                     ref_head += (valid & b_ref_cons(t)) ? L : 0;
                 }
@@ -1112,6 +1250,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     if constexpr (STATS) algo += 2u * (unsigned)cmp;
                     ovf = ovf | o.ovf | zero_m;
                     n = o.no;
+                    nops = o.no - o.extra;
                     cur_off = 0;
                     pos += o.lead_shift;  // :155
                     if (rd.miss || spanic) {
@@ -1140,7 +1279,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         }
         const bool done = act0 && !ovf;
         const bool emit_cigar = done && (status == PLO_ITEM_LIFTED || status == PLO_ITEM_LEN_MISMATCH);
-        const int oc = emit_cigar ? n : 0;
+        const int oc = emit_cigar ? (H16 ? nops : n) : 0;
         const int inco = wv::scan_add(oc);
         const int oS = inco - oc;
         const int total = wv::bcast_last(inco);
@@ -1156,7 +1295,43 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
         ctx.slab_left -= (unsigned long long)total;
         const bool fits = gbase + (unsigned long long)total <= wk.out_cap;
         if (!fits && lane == 0) wv::atomic_add_global(&wk.counters[CNT_OVERFLOW], 1ull);
-        {
+        if constexpr (H16) {
+            // halfwords -> 32-bit ops.  No op of the group in chunks (three groups in four): four halfwords, one 16-byte store; else
+            // equal neighbours -- the writer leaves no others than the chunks of one op -- are summed on the way
+            const int nh = (emit_cigar && fits) ? n : 0;
+            const int nhmax = wv::reduce_max(nh);
+            uint32_t *const dst = wk.out_cigar + gbase + (unsigned long long)oS;
+            const uint16_t *const srcp = R16 + cur_off;
+            if (wv::ballot(nh != (fits ? oc : 0)) == 0ull) {
+                for (int k = 0; k < nhmax; k += 4) {
+                    if (k + 3 < nh) {
+                        Ops4 v;
+                        v.x = h16_dec(srcp[k]);
+                        v.y = h16_dec(srcp[k + 1]);
+                        v.z = h16_dec(srcp[k + 2]);
+                        v.w = h16_dec(srcp[k + 3]);
+                        *(PLO_GLOBAL Ops4 *)(dst + k) = v;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < nh) dst[k + j] = h16_dec(srcp[k + j]);
+                    }
+                }
+            } else {
+                uint32_t run = 0;
+                int w = 0;
+                for (int k = 0; k < nhmax; ++k) {
+                    const bool act = k < nh;
+                    const uint32_t c = h16_dec(srcp[act ? k : 0]);
+                    const bool same = act & (run >= 16u) & (((c ^ run) & 15u) == 0u);
+                    const bool fl = act & !same & (run >= 16u);
+                    if (fl) dst[w] = run;
+                    w += fl ? 1 : 0;
+                    run = same ? run + (c & ~15u) : (act ? c : run);
+                }
+                if ((nh > 0) & (run >= 16u)) dst[w] = run;
+            }
+        } else {
             const int ocmax = wv::reduce_max(fits ? oc : 0);
             uint32_t *const dst = wk.out_cigar + gbase + (unsigned long long)oS;
             const uint32_t *const srcp = (WIN ? win.G : R) + cur_off;
@@ -1209,9 +1384,9 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
 // stage and take half as long; the last round is a partial one).  The earlier attempt with one queue per XCD (round 4) kept the XCDs' unequal
 // shares; one counter for the chip levels them too.
 // `base`: class-order position of the first item (0; a launch over one class only starts at that class)
-template <bool SP, bool NOSHIFT = false, bool STATS = true>
+template <bool SP, bool NOSHIFT = false, bool STATS = true, bool H16 = false>
 PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t stages, uint32_t first, uint32_t stride,
-                                   uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx, uint32_t base = 0) {
+                                   uint32_t n0, uint32_t n1, uint32_t gs, uint32_t *lds, int capw, WaveCtx &ctx, uint32_t base = 0, int kvs_n = LANE_KVS) {
     const uint32_t lane = (uint32_t)wv::lane();
     // groups: cut by LDS budget (k_chunk_sort's list, wk.lane_groups) or fixed: `gs` items each from the start of either class
     const bool listed = wk.lane_groups != nullptr;
@@ -1229,9 +1404,28 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
             // the two classes interleaved (group 0 of the first, group 0 of the second, group 1 of the first, ...; the longer class's rest
             // behind): the groups with the shift stage are the ones whose probes load the memory system, and a kernel that runs all the
             // others first and all of them last has every wave probing at the same time
-            const uint32_t m = t0 < t1 ? t0 : t1;
-            const bool second = t < 2u * m ? (t & 1u) != 0u : t1 > t0;
-            const uint32_t idx = t < 2u * m ? t >> 1 : t - m;
+            bool second;
+            uint32_t idx;
+            if (wk.lane_tail_rounds) {
+                // (round 6) the last groups dealt are groups WITHOUT the shift stage -- half as long as the others: what the waves still have to
+                // do when the tickets run out is what the launch waits for (tools/group_log.py: with the longer class's surplus at the end the
+                // last 1 800 groups of wgs30x were all of the expensive kind and took 120-160 us each) -- and the classes are mixed in
+                // proportion in front of them instead of one to one with the longer one's rest behind
+                const uint32_t keep = wk.lane_tail_rounds * stride, tail = t0 < keep ? t0 : keep;
+                const uint32_t head0 = t0 - tail, head = head0 + t1;
+                if (t >= head) {
+                    second = false;
+                    idx = head0 + (t - head);
+                } else {
+                    const uint32_t r0 = (uint32_t)(((unsigned long long)t * t1) / head), r1 = (uint32_t)(((unsigned long long)(t + 1u) * t1) / head);
+                    second = r1 > r0;  // (r0 groups of the second class lie in front of t)
+                    idx = second ? r0 : t - r0;
+                }
+            } else {
+                const uint32_t m = t0 < t1 ? t0 : t1;
+                second = t < 2u * m ? (t & 1u) != 0u : t1 > t0;
+                idx = t < 2u * m ? t >> 1 : t - m;
+            }
             if (!second) {
                 lo = idx * gs;
                 hi = lo + gs < n0 ? lo + gs : n0;
@@ -1273,7 +1467,7 @@ PLO_DEV void lane_tiles_persistent(const DevIndex &ix, const DevBatch &bt, const
 #ifdef PLO_PHASE_TIMING
         const long long tg0 = wv::realtime(), lt0 = ctx.tph[7], sr0 = ctx.tph[8], sc0 = ctx.tph[9], rd0 = ctx.tph[11];
 #endif
-        lane_tile<SP, false, NOSHIFT, STATS>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw);
+        lane_tile<SP, false, NOSHIFT, STATS, H16>(ix, bt, wk, stages, lo, (int)(hi - lo), lds, capw, 0, ctx, wk.perm, true, g, nullptr, lds + capw, kvs_n);
         wv::sync();
 #ifdef PLO_PHASE_TIMING
         {

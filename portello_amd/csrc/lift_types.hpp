@@ -125,6 +125,8 @@ struct DevWork {
     uint32_t *lane_ticket;
     uint32_t *lane_ticket_next;
     uint32_t lane_static_rounds;
+    uint32_t lane_tail_rounds;  // rounds' worth of groups without the shift stage kept for the end of the launch (0: the classes one to one, the longer one's rest last)
+    uint32_t lane_kvs;  // block-map entries a wave of the light-item kernel stages in LDS (0: LANE_KVS; a multiple of 64 up to LANE_KVS_MAX)
 };
 
 }  // namespace plo

@@ -289,13 +289,18 @@ extern "C" int emu_liftover_batch(const plo_index_desc *ixd, const plo_batch_in 
                 wk.lane_ticket = &ticket;
                 wk.lane_ticket_next = &ticket_next;
                 wk.lane_static_rounds = 1u + (order_seed >> 2) % 3u;
+                wk.lane_tail_rounds = (order_seed >> 4) % 3u;
             }
             for (uint32_t wv_id = 0; wv_id < n_waves; ++wv_id) {
                 wv::EmuWave w;
                 w.order_seed = order_seed ? order_seed + 31 + wv_id : 0;
                 w.run([&]() {
                     WaveCtx ctx;
-                    if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
+                    // (PLO_EMU_H16=1: 16-bit regions for the stage sets with the liftover, as the engine routes them under PLO_LANE_H16=1)
+                    const bool h16 = (stages & PLO_STAGE_LIFTOVER) != 0u && getenv("PLO_EMU_H16") && atoi(getenv("PLO_EMU_H16")) != 0;
+                    if (sp && h16) lane_tiles_persistent<true, false, true, true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
+                    else if (sp) lane_tiles_persistent<true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
+                    else if (h16) lane_tiles_persistent<false, false, true, true>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
                     else lane_tiles_persistent<false>(ix, bt, wk, stages, wv_id, n_waves, r0[n_items], r1[n_items], lane_group, llds.data(), lane_capw, ctx);
                     wave_ctx_flush(wk, ctx, 0);
                 });

@@ -152,19 +152,25 @@ def test_lane_path_golden_vectors(golden):
     check_golden(golden, emu_backend(lane_max_w=4096, lane_capw=8192))
 
 
+@pytest.mark.parametrize("h16", ["0", "1"])
 @pytest.mark.parametrize("stages", [abi.STAGES_ALL, abi.STAGES_ALL & ~abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LIFTOVER,
                                     abi.STAGE_LSHIFT, abi.STAGE_SIMPLIFY, abi.STAGE_STRAND | abi.STAGE_LSHIFT])
-def test_lane_path_synthetic_tiny(oracle, stages):
+def test_lane_path_synthetic_tiny(oracle, stages, h16, monkeypatch):
+    if h16 == "1" and not (stages & abi.STAGE_LIFTOVER):
+        pytest.skip("16-bit regions: stage sets with the liftover only")
+    monkeypatch.setenv("PLO_EMU_H16", h16)
     w = synth.generate(synth.config("tiny", n_reads=150, split_read_frac=0.2, seed=131))
     ix, b = w.index_data(), w.batch_data()
     rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=400, lane_capw=3072)
-    assert rc == 0
+    assert rc == 0 and cnt[7] == 0  # (no item handed on: a lane path that overflows everything would still give right results)
     _assert_same(oracle.liftover_batch(ix, b, stages, 1), res)
 
 
-def test_lane_path_small_slices_rounds_and_overflow(oracle):
+@pytest.mark.parametrize("h16", ["0", "1"])
+def test_lane_path_small_slices_rounds_and_overflow(oracle, h16, monkeypatch):
     """slices too small for 64 regions (several rounds per group), for some items (-> retry list), shuffled lane order; a weight
     limit that splits the items between the lane path and the wave-cooperative one"""
+    monkeypatch.setenv("PLO_EMU_H16", h16)
     w = synth.generate(synth.config("tiny", n_reads=120, seed=132, split_read_frac=0.2, read_len_mean=2500, read_len_sd=900))
     ix, b = w.index_data(), w.batch_data()
     ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, 1)
@@ -344,3 +350,30 @@ def test_block_map_built_by_a_wave_equals_the_sequential_builder():
         keys = [e[0] for e in seq[1]]
         n_merge += sum(1 for a, b in zip(seq[1], seq[1][1:]) if a[1] != -(2 ** 31) and b[1] != -(2 ** 31))
     assert n_merge > 20  # (deletions right behind a block: consecutive Some entries -- the merged form -- were exercised)
+
+
+@pytest.mark.parametrize("h16", ["1", "0"])
+def test_lane_path_ops_longer_than_a_halfword_holds(oracle, monkeypatch, h16):
+    """16-bit regions (lane_core.hpp, H16): ops longer than 8 191 bases are kept as chunks -- by LOAD, by every stage's writer, by the
+    trailing-edge rule -- and summed up again on the way out; an op beyond eight chunks, or more extra chunks than a region has room for, sends its item to the retry list.  Reads of 30 kb
+    with few edits: match runs of 5 .. 40 kb, clips of several kb; block maps with few, long blocks.  The same through the 32-bit regions."""
+    monkeypatch.setenv("PLO_EMU_H16", h16)
+    cfg = synth.config("tiny", n_reads=90, seed=136, chrom_lens=(400_000,), read_len_mean=30_000, read_len_sd=9_000, split_read_frac=0.3, clip_read_frac=0.5,
+                       read_rates=synth.EditRates(mismatch=4e-5, ins=4e-5, dele=4e-5, hpol_frac=0.7),
+                       contig_rates=synth.EditRates(mismatch=1e-4, ins=3e-5, dele=3e-5, hpol_frac=0.3, big_indel_prob=0.3))
+    w = synth.generate(cfg)
+    ix, b = w.index_data(), w.batch_data()
+    lens = b.cigar >> 4
+    assert (lens > 8191).sum() > 20 and (lens > 4 * 8191).sum() > 0
+    seg_of_op = np.repeat(np.arange(len(b.seg_cigar_off) - 1), np.diff(b.seg_cigar_off))
+    huge_segs = set(seg_of_op[lens > 8 * 8191].tolist())
+    for stages in (abi.STAGES_ALL, abi.STAGE_STRAND | abi.STAGE_LIFTOVER, abi.STAGES_ALL & ~abi.STAGE_SIMPLIFY):
+        ref = oracle.liftover_batch(ix, b, stages, 1)
+        n_huge = int(np.isin(ref.item_seg, list(huge_segs)).sum())
+        for capw, seed in ((3072, 0), (3072, 4713), (160, 5)):
+            rc, res, cnt = emu_lib.liftover_batch(ix, b, stages=stages, lane_max_w=4096, lane_capw=capw, order_seed=seed)
+            assert rc == 0
+            _assert_same(ref, res)
+            if capw == 3072:  # handed on: the items with an op (or a merged run) of more than three chunks or more extra chunks than a region allows
+                assert (n_huge <= cnt[7] < res.n_items // 3) if h16 == "1" else cnt[7] == 0, (cnt[7], n_huge, res.n_items)
+    assert (ref.item_cigar_len > 0).sum() > 40

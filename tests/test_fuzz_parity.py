@@ -22,7 +22,7 @@ def _diff(ref, got, b, tag):
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_fuzz_emulated_device_algorithm(oracle, seed):
+def test_fuzz_emulated_device_algorithm(oracle, seed, monkeypatch):
     for alpha in (b"ACGT", b"AC", b"A"):
         ix, b = fuzz_cases.make(100 + seed, alphabet=alpha, explicit=(seed % 3 == 0),
                                 seq_fmt=(abi.SEQ_BAM4 if seed % 4 == 1 else abi.SEQ_ASCII))
@@ -36,6 +36,13 @@ def test_fuzz_emulated_device_algorithm(oracle, seed):
                                                   lane_capw=1024 if seed % 2 else 160)
             assert rc == 0 and cnt[23] > 0
             _diff(ref, got, b, f"lane path: seed {seed} alpha {alpha} stages {stages}")
+            if stages & abi.STAGE_LIFTOVER:  # ... with 16-bit ops in the regions (the experiment kernel k_lift_lanes16)
+                monkeypatch.setenv("PLO_EMU_H16", "1")
+                rc, got, cnt = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096, lane_max_w=60,
+                                                      lane_capw=1024 if seed % 2 else 160, order_seed=(0, 21 + seed)[seed % 2])
+                monkeypatch.delenv("PLO_EMU_H16")
+                assert rc == 0 and cnt[23] > 0
+                _diff(ref, got, b, f"lane path, 16-bit regions: seed {seed} alpha {alpha} stages {stages}")
             # ... and with nearly every item in the heavy classes: regions in global scratch behind LDS windows (k_lift_lanes_g)
             rc, got, cnt = emu_lib.liftover_batch(ix, b, stages=stages, cap=256, window=48, big_thresh=10, big_cap=4096, lane_max_w=12,
                                                   lane_capw=1024, lane_heavy_per=(64, 5)[seed % 2])
@@ -52,7 +59,9 @@ def test_fuzz_emulated_device_algorithm(oracle, seed):
 
 
 @pytest.mark.gpu
-def test_fuzz_hip(oracle):
+@pytest.mark.parametrize("h16", ["0", "1"])
+def test_fuzz_hip(oracle, h16, monkeypatch):
+    monkeypatch.setenv("PLO_LANE_H16", h16)  # (1: the light items of stage sets with the liftover through k_lift_lanes16)
     for seed in range(40):
         alpha = (b"ACGT", b"AC", b"A")[seed % 3]
         ix, b = fuzz_cases.make(1000 + seed, alphabet=alpha, n_reads=120, explicit=(seed % 3 == 0),

@@ -88,7 +88,7 @@ def test_synthetic_plumbing_config(oracle):
     w = synth.generate(synth.config("plumbing"))
     ix, b = w.index_data(), w.batch_data()
     eng_ix = api.Index(ix)
-    eng = api.Engine(eng_ix)
+    eng = api.Engine(eng_ix).set_stats()  # (algo_bytes: the light-item kernel's counting instantiation)
     got = eng.liftover_batch(b)
     _assert_same(oracle.liftover_batch(ix, b, abi.STAGES_ALL, 4), got, "plumbing")
     t = eng.timing()
