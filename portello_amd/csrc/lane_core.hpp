@@ -1080,7 +1080,8 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     const int tf = op_type(c), Lf = op_len(c);
                     const bool copy = fetch & (((0x32u >> tf) & 1u) != 0u);  // I S H: :157-160 copied through; Pad (:213) emits nothing
                     const bool start = fetch & b_ref_cons(tf) & (Lf > 0);
-                    t = start ? tf : t;
+                    // (t: what a piece of this op in a mapped block is written as, :102-109 -- D and N as themselves, the matches as M)
+                    t = start ? ((unsigned)(tf - (int)OP_D) < 2u ? tf : (int)OP_M) : t;
                     ism = start ? b_is_match(tf) : ism;
                     seg_end = start ? seg_start + Lf : seg_end;
                     block_pos = start ? seg_start : block_pos;
@@ -1115,7 +1116,7 @@ PLO_DEV void lane_tile(const DevIndex &ix, const DevBatch &bt, const DevWork &wk
                     r2e = mp ? wrap_add(vb, e0 ? 0 : pend - kb) : r2e;  // :98-100
                     // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
                     const bool e1p = go & (mapped ? (ism | has_start) : ism);
-                    const int t1p = mapped ? (t == OP_D ? (int)OP_D : (t == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
+                    const int t1p = mapped ? t : (bvalid ? (int)OP_I : (int)OP_S);
                     block_pos = go ? pend : block_pos;
                     const bool done = go & (pend >= seg_end);
                     in_op = in_op & !done;
