@@ -57,7 +57,7 @@ def ref_names(w) -> List[str]:
 
 
 def write_read_bam(w, path: str, lo: int = 0, hi: Optional[int] = None, level: int = 1, seed: int = 11, n_unmapped: int = 5,
-                   n_threads: int = 8) -> dict:
+                   n_threads: int = 8, odd_names: bool = False) -> dict:
     """reads [lo, hi) of the workload as a read->contig BAM.  Returns what a checker needs: per-read qnames / quals / aux."""
     hi = w.n_reads if hi is None else hi
     rng = np.random.default_rng(seed)
@@ -90,6 +90,8 @@ def write_read_bam(w, path: str, lo: int = 0, hi: Optional[int] = None, level: i
         cig = b.cigar[int(b.seg_cigar_off[s0]): int(b.seg_cigar_off[s0 + 1])]
         flag = 0x10 if b.read_is_reverse[r] else 0
         qname = f"m84011_{lo + r:09d}/ccs".encode()
+        if odd_names and r % 3 == 0:  # names a strict record test would not take: a blank, a byte beyond ASCII
+            qname = b"m84011 " + bytes([0xC3, 0xA9]) + f"{lo + r:09d}".encode()
         # aux: a mix of kept and removed tags in varying order
         aux = b"rqf" + struct.pack("<f", 0.999) + b"npi" + struct.pack("<i", int(rng.integers(3, 40)))
         style = int(rng.integers(0, 5))

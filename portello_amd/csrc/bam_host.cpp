@@ -2,6 +2,7 @@
 // (get_seq_order_read_split_segments), BAM record bytes of the lifted alignments, BGZF output.  Plain C++17 + zlib;
 // no GPU code.  Citations are relative to /root/reference; rust-htslib / htslib semantics are restated from their
 // published behaviour (third party, absent from the reference tree).
+#include <errno.h>
 #include <chrono>
 #include <sys/uio.h>
 
@@ -16,6 +17,7 @@ void plo_bam_set_error(const std::string &msg) { g_bam_err = msg; }
 // objects
 // ---------------------------------------------------------------------------------------------------------------------
 struct plo_bam_reader {
+    uint64_t hdr_bytes = 0;  // inflated size of the BAM header (magic .. last reference length)
     BgzfIn in;
     std::string text;
     std::vector<std::string> names;
@@ -79,9 +81,11 @@ plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_
     uint8_t w[4];
     if ((st = r->in.read(w, 4)) != PLO_OK) return bail(st);
     uint32_t n_ref = rd32(w);
+    r->hdr_bytes = 12 + (uint64_t)l_text;  // inflated bytes of the header as the file has them (plo_bam_open_range skips exactly these)
     for (uint32_t i = 0; i < n_ref; ++i) {
         if ((st = r->in.read(w, 4)) != PLO_OK) return bail(st);
         uint32_t l_name = rd32(w);
+        r->hdr_bytes += 8 + (uint64_t)l_name;
         std::string name(l_name, '\0');
         if (l_name && (st = r->in.read(&name[0], l_name)) != PLO_OK) return bail(st);
         while (!name.empty() && name.back() == '\0') name.pop_back();
@@ -100,23 +104,23 @@ plo_status plo_bam_open_device(const char *path, int n_threads, int device, plo_
 // src/worker_thread_data.rs:21-30, src/read_alignment_scanner.rs:382; here the split needs no index): the compressed file is cut at
 // size x part / n_parts, a part owns the records whose first byte lies in a BGZF block that STARTS inside its stretch, and reads on
 // past its end to finish the last of them.  A part behind the first finds its first block (BgzfIn::seek_block) and then its first
-// record: the offset in the inflated stream from which a chain of records parses -- sane block_size, reference ids inside the header's
-// list, a NUL-terminated printable name, CIGAR op codes, fixed fields + name + CIGAR + bases + qualities within block_size -- eight
-// times in a row (or to the end of the data).
+// record: the offset in the inflated stream from which a chain of records parses, eight times in a row (or to the end of the data).
+// The test asks for what plo_bam_read_window itself insists on (block_size >= 32, fixed fields + name + CIGAR + bases + qualities within
+// block_size) and for what every BAM record has by the format's definition (reference ids inside the header's list, a NUL-terminated
+// name, CIGAR op codes 0 .. 8) -- and for nothing else (a test stricter than the reader's -- printable names, positions >= -1, a
+// size bound -- let a record the reader lifts break every chain through it, and the records in front of the start found behind it were
+// read by no part).
 static bool plausible_record(const uint8_t *p, size_t left, uint32_t n_ref, size_t *len) {
     if (left < 4 + 32) return false;
     const uint32_t bs = rd32(p);
-    if (bs < 32 + 2 || bs > (1u << 28) || 4 + (size_t)bs > left) return false;
+    if (bs < 32 || 4 + (size_t)bs > left) return false;
     Rec rec{p + 4, bs};
     const int32_t tid = rec.tid(), mtid = (int32_t)rd32(p + 4 + 20);
     if (tid < -1 || tid >= (int32_t)n_ref || mtid < -1 || mtid >= (int32_t)n_ref) return false;
-    if ((int32_t)rd32(p + 4 + 4) < -1 || (int32_t)rd32(p + 4 + 24) < -1) return false;
     const uint32_t l_name = rec.l_qname();
-    if (l_name < 2 || !rec.layout_ok()) return false;
+    if (l_name < 1 || !rec.layout_ok()) return false;
     const uint8_t *name = p + 4 + 32;
     if (name[l_name - 1] != 0) return false;
-    for (uint32_t i = 0; i + 1 < l_name; ++i)
-        if (name[i] < 33 || name[i] > 126) return false;
     const uint32_t n_cig = rec.n_cigar();
     const uint8_t *cg = name + l_name;
     for (uint32_t i = 0; i < n_cig; ++i)
@@ -142,8 +146,7 @@ plo_status plo_bam_open_range(const char *path, int n_threads, int device, uint3
     // it look for their first block and their first record.
     in.ranged = true;
     in.range_end = part + 1 == n_parts ? (size_t)-1 : hi;
-    size_t hdr_bytes = 12 + r->text.size();
-    for (size_t i = 0; i < r->names.size(); ++i) hdr_bytes += 8 + r->names[i].size() + 1;
+    const size_t hdr_bytes = (size_t)r->hdr_bytes;  // (from the l_name fields as read: a name without its NUL, or padded, must not move the start)
     size_t c = 0, u = 0;  // walk the blocks from the file's start until the inflated offset passes the header
     while (c < in.size) {
         const uint32_t bsz = BgzfIn::bgzf_block_at(in.map + c, in.size - c);
@@ -184,7 +187,7 @@ plo_status plo_bam_open_range(const char *path, int n_threads, int device, uint3
             while (ok < 8) {
                 if (q == have && in.eof) break;
                 if (!plausible_record(b + q, have - q, n_ref, &len)) {
-                    ran_out = q + 36 > have || (q + 4 <= have && 4 + (size_t)rd32(b + q) > have - q && rd32(b + q) <= (1u << 28) && rd32(b + q) >= 34);
+                    ran_out = q + 36 > have || (q + 4 <= have && 4 + (size_t)rd32(b + q) > have - q && rd32(b + q) >= 32);
                     break;
                 }
                 q += len;
@@ -199,7 +202,11 @@ plo_status plo_bam_open_range(const char *path, int n_threads, int device, uint3
         }
         if (in.eof || want > ((size_t)1 << 32)) break;
     }
-    // no record boundary in the rest of the file: the stretch holds the tail of one record only
+    // No record boundary behind this part's first block.  The tail of one record that began in an earlier part's block is all there is
+    // when little data is left; megabytes without a boundary are not a record's tail -- the part would come back empty and the parts'
+    // union incomplete with status 0, so that is an error.
+    if (have > ((size_t)64 << 20) || !in.eof)
+        return bail(fail(PLO_ERR_DATA, "plo_bam_open_range: no BAM record boundary found behind the part's first BGZF block"));
     in.restart_at(in.size);
     return PLO_OK;
 }
@@ -1196,6 +1203,7 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
             while (first < iov.size()) {
                 const int cnt = (int)std::min<size_t>(iov.size() - first, 1024);
                 ssize_t k = pwritev(fd, iov.data() + first, cnt, (off_t)off);
+                if (k < 0 && errno == EINTR) continue;  // (a signal -- a watchdog, a profiler's timer -- is not a failed write)
                 if (k <= 0) {
                     wbad = 1;
                     return;
@@ -1291,6 +1299,7 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
                 uint64_t off = file_off + at[b];
                 while (left) {
                     ssize_t k = pwrite(fd, p, left, (off_t)off);
+                    if (k < 0 && errno == EINTR) continue;
                     if (k <= 0) {
                         bad = 1;
                         return;
@@ -1309,6 +1318,7 @@ plo_status plo_bam_writer::emit(const uint8_t *src, size_t n) {
             size_t left = olen[b];
             while (left) {
                 ssize_t k = ::write(fd, p, left);
+                if (k < 0 && errno == EINTR) continue;
                 if (k <= 0) return fail(PLO_ERR_IO, "write failed");
                 p += k;
                 left -= (size_t)k;
@@ -1391,11 +1401,15 @@ extern "C" plo_status plo_bam_writer_close(plo_bam_writer *w) {
     if (!w) return PLO_ERR_INVALID_ARG;
     plo_status st = w->pend.empty() ? PLO_OK : w->emit(w->pend.data(), w->pend.size());
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t end = w->file_off;  // bytes actually written: the EOF block counts only when it went out
     if (st == PLO_OK) {
-        ssize_t k = w->seekable ? pwrite(w->fd, eof_block, 28, (off_t)w->file_off) : ::write(w->fd, eof_block, 28);
+        ssize_t k;
+        do k = w->seekable ? pwrite(w->fd, eof_block, 28, (off_t)w->file_off) : ::write(w->fd, eof_block, 28);
+        while (k < 0 && errno == EINTR);
         if (k != 28) st = fail(PLO_ERR_IO, "write failed");
+        else end += 28;
     }
-    if (w->seekable && w->reserved > w->file_off + 28 && ftruncate(w->fd, (off_t)(w->file_off + 28)) != 0 && st == PLO_OK)  // reserved blocks behind the end go back
+    if (w->seekable && w->reserved > end && ftruncate(w->fd, (off_t)end) != 0 && st == PLO_OK)  // reserved blocks behind the end go back
         st = fail(PLO_ERR_IO, "ftruncate failed");
     ::close(w->fd);
     delete w;

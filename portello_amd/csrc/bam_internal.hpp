@@ -1,6 +1,7 @@
 // bam_internal.hpp -- shared internals of the host-side BAM code (bam_host.cpp, phase1.cpp): BGZF input, record access, aux
 // walking, CIGAR helpers.  Everything sits in an unnamed namespace (one private copy per translation unit).
 #pragma once
+#include <errno.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -722,6 +723,7 @@ bool parallel_pread(int fd, uint8_t *dst, size_t off, size_t n, int threads) {
         size_t o = i * piece, left = std::min(piece, n - o);
         while (left) {
             const ssize_t k = pread(fd, dst + o, left, (off_t)(off + o));
+            if (k < 0 && errno == EINTR) continue;
             if (k <= 0) {
                 bad = 1;
                 return;

@@ -1470,6 +1470,8 @@ struct plo_ctx {
     // class counts, whether it had heavy items (a context that sees windows of one shape lifts them without asking the device for counts)
     bool fast = true;
     uint32_t fast_ns_cap = 0, fast_item_cap = 0, fast_n0 = 0, fast_n1 = 0;
+    uint32_t item_cap_now = 0;   // items the per-item arrays hold
+    uint32_t fast_extra_syncs = 0;  // a fast attempt that fell back: its round trip counts in the call's host_syncs
     bool fast_light_only = false;
     uint32_t lane_groups_cap = 0;  // groups the list of the budget-cut groups has room for (set with the list, attempt 0 of a batch)
     // k_lift_lanes_g (heavy items through the lane-per-item code, regions in global scratch behind LDS windows): lane_heavy_min >= 0 = for
@@ -1958,6 +1960,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
         plo_status fs = liftover_fast(c, in, stages, out, bt, fallback);
         if (!fallback) return fs;
         c->fast_light_only = false;
+        c->fast_extra_syncs = 1;
         memset(out, 0, sizeof(*out));
         memset(&c->timing, 0, sizeof(c->timing));
     }
@@ -2030,6 +2033,19 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     HIP_TRY(c, c->big_list.ensure(ni * 4));
     if (in->seq_fmt == PLO_SEQ_BAM4_SPARSE) HIP_TRY(c, c->miss_list.ensure(ni * 4));
     HIP_TRY(c, c->counters.ensure(CNT_N * 8));
+    {   // items the per-item arrays hold (they grow with head-room): the one-round-trip path's capacity (the last batch's item
+        // count refused a window with one item more and cost it two passes)
+        size_t cap_items = (size_t)0xffffffffu;
+        const struct { const DevBuf *b; size_t el; } arrs[] = {
+            {&c->item_seg, 4}, {&c->item_cseg, 4}, {&c->item_nin, 4}, {&c->item_cls, 4}, {&c->retry_list, 4}, {&c->perm, 4}, {&c->nin_p, 4},
+            {&c->d_in_off, 4}, {&c->d_n_in, 4}, {&c->d_n_m, 4}, {&c->d_pos1, 4}, {&c->d_w0, 4}, {&c->d_w1, 4}, {&c->d_kv0, 4}, {&c->d_kv1, 4},
+            {&c->d_flags, 4}, {&c->d_contig, 4}, {&c->d_seq_len, 4}, {&c->d_seq_off, 8}, {&c->d_shift_ref, 8}, {&c->d_shift_ref_len, 4},
+            {&c->d_chrom_ref, 8}, {&c->d_chrom_ref_len, 4}, {&c->d_read_len, 4}, {&c->o_status, 1}, {&c->o_flip, 1}, {&c->o_mapq, 1},
+            {&c->o_chrom, 4}, {&c->o_pos, 8}, {&c->o_coff, 8}, {&c->o_clen, 4}, {&c->big_list, 4}};
+        for (const auto &a : arrs) cap_items = std::min(cap_items, a.b->cap / a.el);
+        cap_items = std::min(cap_items, c->op_prefix.cap / 4 ? c->op_prefix.cap / 4 - 1 : 0);
+        c->item_cap_now = (uint32_t)std::min<size_t>(cap_items, 0x7fffffffu);
+    }
     DevWork wk;
     fill_work(c, wk, n_items);
     {   // statistic slots of the lift kernels' waves: zeroed once, cleared again by every k_sum_stats
@@ -2537,9 +2553,11 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->timing.n_lane_items = n_small;
     c->timing.n_heavy_lane_items = heavy_lanes ? n_items - n_small : 0u;
     c->timing.heavy_kernel = heavy_kernel;
-    c->timing.host_syncs = n_syncs;
+    c->timing.host_syncs = n_syncs + c->fast_extra_syncs;
+    c->fast_extra_syncs = 0;
     c->fast_ns_cap = ns;
-    c->fast_item_cap = n_items;
+    // (PLO_FAST_CAP_EXACT=1, tests: the last batch's item count, so that a window with a few items more exercises the VERR_CAP fallback)
+    c->fast_item_cap = getenv("PLO_FAST_CAP_EXACT") ? n_items : std::max(n_items, c->item_cap_now);
     c->fast_n0 = h_cls[0];
     c->fast_n1 = h_cls[1];
     // (items the lane kernel handed to the retry kernel are fine: the fast path runs that kernel too; items IT hands on are not)

@@ -751,6 +751,7 @@ def test_one_host_round_trip_path(oracle, monkeypatch):
         shapes[(lo, hi)] = (int(len(b.seg_read)), int(len(oracle.liftover_batch(ix, b, abi.STAGES_ALL, os.cpu_count() or 8).item_seg)))
     pairs = [(a, b) for a in cand for b in cand if shapes[b][0] <= shapes[a][0] and shapes[b][1] > shapes[a][1]]
     assert pairs, shapes  # (windows of 8 000 reads differ by tens of segments and items either way)
+    monkeypatch.setenv("PLO_FAST_CAP_EXACT", "1")  # (the arrays' head-room would hold the few items more; the capacity check is what is tested)
     for a, b in pairs[:3]:
         eng3 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
         syncs3 = []
@@ -762,8 +763,19 @@ def test_one_host_round_trip_path(oracle, monkeypatch):
             ref = oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8)
             assert int(eng3.timing().n_items) == shapes[(lo, hi)][1]
             assert got.canonical() == ref.canonical(), f"reads [{lo}, {hi})"
-        assert syncs3[1] == 1 and syncs3[2] >= 3 and syncs3[3] == 1, (syncs3, shapes[a], shapes[b])
+        assert syncs3[1] == 1 and syncs3[2] >= 4 and syncs3[3] == 1, (syncs3, shapes[a], shapes[b])  # (4: the refused attempt's round trip counts)
         eng3.close()
+    monkeypatch.delenv("PLO_FAST_CAP_EXACT")
+    # ... and without the switch the arrays' head-room takes the few items more in one round trip
+    a, b = pairs[0]
+    eng5 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
+    for lo, hi in (a, a, b):
+        db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+        torch.cuda.synchronize()
+        got = devbatch.run_and_download(eng5, db)
+        assert got.canonical() == oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8).canonical()
+    assert int(eng5.timing().host_syncs) == 1
+    eng5.close()
     # the one-launch scan of the segments' item offsets (k_scan_chain, an experiment that stays switched off) gives the same results
     monkeypatch.setenv("PLO_SCAN_CHAIN", "1")
     eng4 = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream)
