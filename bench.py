@@ -97,6 +97,7 @@ def cpu_baseline(w, got, budget_s: float = 12.0, ixd=None):
     pyoracle.liftover_batch(ixd, w.batch_data(0, probe), abi.STAGES_ALL, 1)
     rate1 = probe / max(1e-4, time.perf_counter() - t0)
     return {"value": n_done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "block_map": "array-based (sorted key / value arrays + bisection): faster than the reference's BTreeMap -- the baseline errs on the conservative side",
             "sample": f"{n_blocks} blocks of {block} consecutive reads spread evenly over the read set ({n_done} reads), "
                       f"oracle/liboracle.so = C restatement of the reference algorithm, not the reference binary (sorted-array block "
                       f"maps with bisection where the reference has a BTreeMap; segments split evenly over {cores} pthreads where the "
@@ -497,6 +498,8 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
         agg["big_items"] += int(tm.n_big_items)
         agg["lane_items"] += int(tm.n_lane_items)
         agg["retry_items"] += int(tm.n_retry_items)
+        if int(tm.heavy_kernel):
+            agg["heavy_kernel"] = int(tm.heavy_kernel)
 
     # algorithmic bytes: one pass of the counting kernels outside the timed region (the production light-item kernel carries no counters)
     cnt_run = stream.StreamRunner(index, dev, 1)
@@ -530,7 +533,8 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
     share = dom_ms / max(1e-9, sum(kms.values()))
     algo_per_call = agg["algo"] / len(descs)
     achieved = (algo_per_call * share) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    dom_name = {"k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
+    heavy_name = {2: "k_lift_lanes_g_w3", 3: "k_lift_stream"}.get(agg.get("heavy_kernel", 0), "k_lift_lanes_g")  # (the batches' last heavy-item kernel)
+    dom_name = {"k_lift_mid": "k_lift_mid<16>", "k_lift_lanes_g": heavy_name}.get(dominant, dominant)
     result = {
         "metric": "lifted HiFi reads/sec (whole node)", "value": total_reads * args.steps / dt, "unit": "reads/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -546,7 +550,7 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
                      "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(algo_per_call * share),
                      "kernel_ms": dom_ms, "launches_per_step": len(descs), "enumerate_ms": float(np.sum(times["enum"])) / n_calls,
                      "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"], "lift_big_ms": kms["k_lift_big"],
-                     "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_lanes_ms": kms["k_lift_lanes_g"]},
+                     "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms["k_lift_lanes_g"], "heavy_kernel": heavy_name},
     }
     one.close()
     if args.overlap_workers > 1:
@@ -863,13 +867,14 @@ def main():
 
     def make_result(dt_, gather_desc):
         tm = eng.timing()
+        # the heavy items' kernel under its own name (plo_timing::heavy_kernel says which one `heavy_lanes_ms` is the time of)
+        heavy_name = {2: "k_lift_lanes_g_w3", 3: "k_lift_stream"}.get(int(tm.heavy_kernel), "k_lift_lanes_g")
         kms = {"k_lift_lanes": float(np.mean(times["lanes"])), "k_lift_mid": float(np.mean(times["mid"])), "k_lift_tiles": float(np.mean(times["lift"])),
-               "k_lift_big": float(np.mean(times["big"])), "k_lift_retry": float(np.mean(times["retry"])), "k_lift_lanes_g": float(np.mean(times["heavy"]))}
+               "k_lift_big": float(np.mean(times["big"])), "k_lift_retry": float(np.mean(times["retry"])), heavy_name: float(np.mean(times["heavy"]))}
         dominant = max(kms, key=kms.get)
         dom_ms = kms[dominant]
         # the name rocprofv3 lists it under: the tile kernel of batches without heavy items has its slice capacity compiled in
-        dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>",
-                    "k_lift_lanes_g": {2: "k_lift_lanes_g_w3", 3: "k_lift_stream"}.get(int(tm.heavy_kernel), "k_lift_lanes_g")}.get(dominant, dominant)
+        dom_name = {"k_lift_tiles": "k_lift_tiles_c256" if int(tm.tile_cap) == 256 else "k_lift_tiles", "k_lift_mid": "k_lift_mid<16>"}.get(dominant, dominant)
         # algorithmic bytes are counted by the kernels themselves (SURVEY.md 8(d) formula), summed over all lift kernels;
         # attribute them to the dominant kernel in proportion to its share of the lift time
         share = dom_ms / max(1e-9, sum(kms.values()))
@@ -939,7 +944,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(algo_bytes * share), "kernel_ms": dom_ms,
                          "enumerate_ms": float(np.mean(times["enum"])), "enumerate_pass": enum_obj, "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"],
-                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_lanes_ms": kms["k_lift_lanes_g"],
+                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms[heavy_name], "heavy_kernel": heavy_name,
                          "lane_utilisation": stats["lane_utilisation"],  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
                          "statistics_from": "one call of the counting kernel outside the timed region (plo_ctx_set_stats); the timed kernel carries no counters",
                          "lanes_ms_counting_kernel": stats["lanes_ms_counting_kernel"],

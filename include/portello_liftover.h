@@ -156,7 +156,7 @@ typedef struct plo_batch_in {
     const uint64_t *read_seq_off;    /* [n_reads] byte offset of the read's bases inside `seq` */
     const uint8_t *seq;              /* all read bases, encoding `seq_fmt`                      */
     uint64_t seq_bytes;              /* size of `seq` in bytes                                  */
-    int32_t seq_fmt;                 /* PLO_SEQ_BAM4 / PLO_SEQ_ASCII                            */
+    int32_t seq_fmt;                 /* PLO_SEQ_BAM4 / PLO_SEQ_ASCII / PLO_SEQ_BAM4_SPARSE      */
 
     /* read split segments (SeqOrderSplitReadSegment) */
     uint32_t n_segs;

@@ -61,7 +61,7 @@ def strided_blocks(n_reads, n_blocks, block):
     return [(i * stride, i * stride + block) for i in range(n_blocks)]
 
 
-def check_strided_parity(w, res, oracle, n_blocks=40, block=400, threads=8, ix=None):
+def check_strided_parity(w, res, oracle, n_blocks=40, block=400, threads=8, ix=None, blocks=None):
     """oracle parity of `n_blocks` blocks of `block` consecutive reads spread evenly over the read set; returns the number of
     items compared, how many sat on reverse-mapped contig segments, and the distinct contigs touched"""
     import torch
@@ -70,7 +70,7 @@ def check_strided_parity(w, res, oracle, n_blocks=40, block=400, threads=8, ix=N
     n_cmp = 0
     contigs = set()
     n_flip = 0
-    for lo, hi in strided_blocks(w.n_reads, n_blocks, block):
+    for lo, hi in (blocks if blocks is not None else strided_blocks(w.n_reads, n_blocks, block)):  # (blocks: explicit read ranges, e.g. a tiling of the whole set)
         b = w.batch_data(lo, hi)
         ref = oracle.liftover_batch(ix, b, abi.STAGES_ALL, threads)
         seg_lo = int(torch.searchsorted(w.seg_read, torch.tensor(lo, device=w.device)).item())

@@ -330,6 +330,30 @@ def test_full_size_wgs30x(oracle):
     _full_size("wgs30x", oracle, 250, 1000, threads=os.cpu_count() or 8)
 
 
+def test_every_item_of_wgs30x(oracle):
+    """the headline configuration once in full -- every one of the ~2.07 M items of BASELINE configs[2] compared with the
+    oracle (blocks of 10 000 reads tiling the whole read set, all host cores; the other full-size test and the bench keep their eighth)"""
+    import torch
+
+    import fullsize
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("wgs30x"), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    db = devbatch.DeviceBatch.from_workload(w)
+    devbatch.run_and_download(eng, db)
+    res = devbatch.run_and_download(eng, db)  # (the second call: the one-round-trip path)
+    assert int(eng.timing().host_syncs) == 1
+    blocks = [(lo, min(lo + 10_000, w.n_reads)) for lo in range(0, w.n_reads, 10_000)]
+    n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, threads=os.cpu_count() or 8, blocks=blocks)
+    _dump("every_item_wgs30x.json", {"reads": w.n_reads, "items": int(res.n_items), "items_compared_with_oracle": n_cmp, "of_them_flipped": n_flip,
+                                     "contigs_in_sample": n_contigs, "blocks": len(blocks)})
+    assert n_cmp == res.n_items and n_flip > 0
+    eng.close()
+    eng_ix.close()
+
+
 def test_full_size_stress(oracle):
     """BASELINE configs[4] read profile (20 kb, 5 % indel-dense, ~2 000 ops per read) on the wgs30x contigs: every item is far heavier than a
     shared tile holds; 60 k reads are a reference-sized window task (src/read_alignment_scanner.rs:508-534) -- since round 5 routed to the

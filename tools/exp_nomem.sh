@@ -14,7 +14,7 @@ import json, sys
 try:
     r = json.loads(open('/tmp/exp.json').read().strip().splitlines()[-1])
     ro = r['roofline']
-    print(f"{sys.argv[1]:40s} step {r['ms_per_step']:7.2f} ms  heavy {ro['lift_heavy_lanes_ms']:7.2f}  util {ro['lane_utilisation']:.2f}")
+    print(f"{sys.argv[1]:40s} step {r['ms_per_step']:7.2f} ms  heavy {ro.get('lift_heavy_ms', ro.get('lift_heavy_lanes_ms', 0.0)):7.2f}  util {ro['lane_utilisation']:.2f}")
 except Exception as e:
     print(sys.argv[1], 'ERR', e, open('/tmp/exp.err').read()[-400:])
 PY

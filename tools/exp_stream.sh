@@ -14,7 +14,7 @@ import json, sys
 try:
     r = json.loads(open('/tmp/exp.json').read().strip().splitlines()[-1])
     ro = r['roofline']
-    print(f"{sys.argv[1]:34s} {r['value']/1e6:7.2f} M reads/s  step {r['ms_per_step']:7.2f} ms  heavy {ro['lift_heavy_lanes_ms']:7.2f}  mid {ro['lift_mid_ms']:6.2f}  retry {ro['lift_retry_ms']:5.2f} ({r['config']['retry_items_per_gpu']})  util {ro['lane_utilisation']:.2f}")
+    print(f"{sys.argv[1]:34s} {r['value']/1e6:7.2f} M reads/s  step {r['ms_per_step']:7.2f} ms  heavy {ro.get('lift_heavy_ms', ro.get('lift_heavy_lanes_ms', 0.0)):7.2f}  mid {ro['lift_mid_ms']:6.2f}  retry {ro['lift_retry_ms']:5.2f} ({r['config']['retry_items_per_gpu']})  util {ro['lane_utilisation']:.2f}")
 except Exception as e:
     print(sys.argv[1], 'ERR', e, open('/tmp/exp.err').read()[-400:])
 PY
