@@ -687,6 +687,9 @@ def main():
                     help="primary records per window of the end-to-end run (a 60 k-read sample is 8 windows: with fewer, larger ones the "
                          "pipeline spends most of the run filling and draining; the default sample of 180 k reads is 24)")
     ap.add_argument("--e2e-workers", type=int, default=2, help="lift worker threads (contexts) of the end-to-end run")
+    ap.add_argument("--pipeline-batches", type=int, default=int(os.environ.get("PLO_BENCH_PIPELINE_BATCHES", "4")),
+                    help="N > 1, strong scaling: every rank also lifts its windows as this many batches on two contexts, the record gather of "
+                         "batch i under the compute of batch i + 1 (`gather_modes.window_pipeline`; 1: off)")
     ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip rank 0's comparison of the gathered records "
                                                              "with its own single-GPU result (after the timed region)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("PLO_BENCH_WORKERS", "1")),
@@ -1057,6 +1060,66 @@ def main():
                 return d_
 
             dt_async = guarded(async_run)
+        # (c) the reference's window loop on every rank (src/read_alignment_scanner.rs:508-534: window tasks one after the other, one locked
+        # writer behind them): the rank's windows as k batches on two contexts, the exchange of batch i under the compute of batch i + 1 --
+        # across the steps' boundaries too; only the last batch's exchange of the last step is waited for with nothing to hide it under.
+        # (gloo with host copies has no asynchronous form here: the batches and their exchanges then simply follow each other.)
+        dt_pipe = None
+        pipe_parts = None  # rank 0: the gathered parts of one pass, batch by batch (verification)
+        k_pipe = max(1, args.pipeline_batches)
+        if strong and k_pipe > 1 and n_workers == 1 and dt_sync is not None:
+            pipe_groups = [shard.pipeline_batches(wins, deal, r, k_pipe) for r in range(world)]
+            sub_dbs = [devbatch.DeviceBatch.from_read_ranges(w, g) for g in pipe_groups[rank]]
+            sub_descs = [d_.desc() for d_ in sub_dbs]
+
+            def pipe_run_outer():
+                s2 = torch.cuda.Stream(device=dev)
+                p_streams = [streams[0], s2]
+                p_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
+
+                def pipe_run(n_steps, keep=None):
+                    pending = [None, None]
+                    for i in range(n_steps * k_pipe):
+                        j, c_ = i % k_pipe, i & 1
+                        if pending[c_] is not None:
+                            with torch.cuda.stream(p_streams[c_]):
+                                got_ = pending[c_][1].wait()
+                            if keep is not None:
+                                keep[pending[c_][0]] = got_
+                            pending[c_] = None
+                        out_j = p_engs[c_].liftover_batch_dev(sub_descs[j])
+                        p_engs[c_].compact_output_dev(out_j)
+                        with torch.cuda.stream(p_streams[c_]):
+                            if host_comm:
+                                mine = {k_: v.cpu() for k_, v in plo_gather.tensors_from_out(out_j, dev).items()}
+                                got_ = plo_gather.gather_payloads(mine, dist, rank, world)
+                                if keep is not None:
+                                    keep[j] = got_
+                            else:
+                                pending[c_] = (j, plo_gather.gather_results_async(out_j, dev, dist, rank, world))
+                    for c_ in (0, 1):
+                        if pending[c_] is not None:
+                            with torch.cuda.stream(p_streams[c_]):
+                                got_ = pending[c_][1].wait()
+                            if keep is not None:
+                                keep[pending[c_][0]] = got_
+
+                pipe_run(1)  # (sizes the second context's buffers)
+                d_ = timed(pipe_run, args.steps)
+                kept = {}
+                pipe_run(1, kept)  # one more pass whose gathered parts rank 0 keeps (cloned: the contexts' buffers are reused)
+                torch.cuda.synchronize()
+                parts_ = None
+                if rank == 0:
+                    parts_ = [[{k_: v.clone() for k_, v in t_.items()} for t_ in kept[j]] for j in range(k_pipe)]
+                p_engs[1].close()
+                engs[0].liftover_batch_dev(desc)  # (this rank's own whole-share result back in the first context)
+                engs[0].sync()
+                return d_, parts_
+
+            got_pipe = guarded(pipe_run_outer)
+            if got_pipe is not None:
+                dt_pipe, pipe_parts = got_pipe
         gather_modes = {}  # reads/s of the whole job with the records of every step on rank 0 when the clock stops
         if dt_sync is not None:
             gather_modes["after_every_step"] = {"value": total_reads * args.steps / dt_sync, "unit": "reads/s", "ms_per_step": dt_sync / args.steps * 1e3}
@@ -1066,6 +1129,14 @@ def main():
             if dt_async < dt_sync:  # the headline is the faster complete pipeline: K steps, all K record sets on rank 0 when the clock stops
                 result = make_result(dt_async, "rccl send/recv to rank 0, the exchange of batch i overlapped with the compute of batch i+1 "
                                                "(two contexts alternate)")
+        if dt_pipe is not None:
+            gather_modes["window_pipeline"] = {"value": total_reads * args.steps / dt_pipe, "unit": "reads/s", "ms_per_step": dt_pipe / args.steps * 1e3,
+                                               "batches_per_rank_and_step": k_pipe, "reads_per_batch_this_rank": [int(d_.n_reads) for d_ in sub_dbs],
+                                               "note": "every rank lifts its windows as consecutive batches on two contexts, the gather of batch i under the compute "
+                                                       "of batch i+1 (the reference's window loop, read_alignment_scanner.rs:508-534)"}
+            if dt_pipe < min(x for x in (dt_sync, dt_async) if x is not None):
+                result = make_result(dt_pipe, ("gloo send/recv of host copies" if host_comm else "rccl send/recv") + f" to rank 0, every rank's windows as {k_pipe} "
+                                     "batches per step on two contexts, the exchange of batch i under the compute of batch i+1")
 
     overlap = None
     if dist is None and n_workers == 1 and args.overlap_workers > 1:
@@ -1156,8 +1227,20 @@ def main():
                     eng.sync()
                     whole = {k_: v.to(comm_dev) for k_, v in plo_gather.tensors_from_out(whole_out, dev).items()}
                     same = plo_gather.same_records(got_all, whole)
+                    whole_ms = float(eng.timing().total_ms)  # device time of the WHOLE read set on this one GPU
                     verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
-                              "reads": int(w.n_reads)}
+                              "reads": int(w.n_reads), "single_gpu_device_ms": whole_ms,
+                              "this_rank": {"reads": int(my_reads), "ms_per_step_no_gather": dt_ng / args.steps * 1e3,
+                                            "single_gpu_pro_rata_ms": whole_ms * my_reads / max(1.0, total_reads)}}
+                    if pipe_parts is not None:  # the window pipeline's batches, every one mapped back to the unsharded numbering
+                        per_batch = []
+                        for j in range(k_pipe):
+                            maps_j = [plo_gather.local_to_global_segments(w, pipe_groups[r][j]).to(comm_dev) for r in range(world)]
+                            per_batch.append(plo_gather.combine([{k_: v.to(comm_dev) for k_, v in t_.items()} for t_ in pipe_parts[j]], maps_j))
+                        same_p = plo_gather.same_records(plo_gather.combine(per_batch), whole)
+                        verify["window_pipeline_equals_single_gpu_result"] = bool(same_p)
+                        same = same and same_p
+                        verify["gathered_equals_single_gpu_result"] = bool(same)
                     if not same:
                         log("[bench] VERIFY FAILURE: gathered records differ from the single-GPU result")
                     step(0, gather=False)  # restore this rank's own result in the context (read by the roofline object below)

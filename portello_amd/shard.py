@@ -101,6 +101,25 @@ def rank_read_ranges(windows: Sequence[Window], deal: List[List[int]], rank: int
     return out
 
 
+def pipeline_batches(windows: Sequence[Window], deal: List[List[int]], rank: int, k: int) -> List[List[Tuple[int, int]]]:
+    """The rank's windows, in input order, cut into `k` consecutive runs of about equal weight -- the batches a rank lifts one after
+    the other the way the reference walks its window tasks (src/read_alignment_scanner.rs:508-534), so that the exchange of one batch
+    runs under the compute of the next.  Every run as read ranges (neighbouring windows merged); runs may be empty."""
+    mine = list(deal[rank])
+    total = sum(windows[i].weight for i in mine)
+    out: List[List[Tuple[int, int]]] = [[] for _ in range(max(1, k))]
+    acc = 0
+    for i in mine:
+        w = windows[i]
+        j = min(len(out) - 1, (acc * len(out)) // total) if total else 0  # the run the window's first op falls into
+        if out[j] and out[j][-1][1] == w.read_lo:
+            out[j][-1] = (out[j][-1][0], w.read_hi)
+        else:
+            out[j].append((w.read_lo, w.read_hi))
+        acc += w.weight
+    return out
+
+
 def workload_windows(w, segment_size: int = SEGMENT_SIZE) -> List[Window]:
     """windows of a synth.Workload (its first split segment is the primary alignment of a read)"""
     import torch

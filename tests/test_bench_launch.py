@@ -65,3 +65,22 @@ def test_bench_starts_two_ranks_by_itself():
     sh = r["end_to_end_sharded"]
     assert sh["ranks"] == 2 and sh["reads"] == 4000 and all(n > 0 for n in sh["reads_per_rank"]) and sh["value"] > 0
     assert sh["records_verified"] >= 300 and sh["verification"]["ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_lift_wgs30x_as_a_window_pipeline():
+    """BASELINE configs[3] at its own size on the one GPU of the box: bench.py --gpus 2 --workload wgs30x -- 2 M reads,
+    the reference's 20 Mb windows dealt to two ranks, each rank's windows also lifted as four batches per step on two contexts with the
+    record gather of batch i behind the compute of batch i+1; rank 0 checks both gathered record sets against its single-GPU result"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PLO_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "wgs30x", "--steps", "2", "--warmup", "1",
+                        "--e2e-reads", "0", "--pipeline-batches", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=2400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert r["n_gpus"] == 2 and r["config"]["workload"] == "wgs30x" and r["config"]["reads_total"] == 2_000_000 and r["value"] > 0
+    v = r["verify"]
+    assert v["gathered_equals_single_gpu_result"] is True and v["window_pipeline_equals_single_gpu_result"] is True and v["items"] > 2_000_000
+    wp = r["gather_modes"]["window_pipeline"]
+    assert wp["batches_per_rank_and_step"] == 4 and len(wp["reads_per_batch_this_rank"]) == 4 and wp["value"] > 0
+    assert v["this_rank"]["single_gpu_pro_rata_ms"] > 0 and v["this_rank"]["ms_per_step_no_gather"] > 0

@@ -133,3 +133,67 @@ def test_async_gather_world_size_2():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_async, args=(2, _free_port(), d), nprocs=2, join=True)
         assert os.path.exists(os.path.join(d, "ok"))
+
+
+def _worker_pipeline8(rank, world, port, outdir):
+    """BASELINE configs[3] / [4] name eight ranks: the deal for world size 8, every rank's windows as three consecutive batches
+    (shard.pipeline_batches: the reference's window loop, src/read_alignment_scanner.rs:508-534), the exchange of a batch posted while the
+    next one is lifted, rank 0 maps every batch of every rank back to the unsharded numbering.  The oracle stands in for the engine."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+    from portello_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = 3
+    w = synth.generate(synth.config("tiny", n_reads=400, seed=303, split_read_frac=0.2, sorted_reads=True))
+    ix = w.index_data()
+    wins = shard.workload_windows(w, segment_size=6_000)
+    deal = shard.deal_windows(wins, world)
+    assert len(wins) >= 3 * world and all(len(d) > 0 for d in deal)
+    groups = [shard.pipeline_batches(wins, deal, r, k) for r in range(world)]
+    # a rank's batches tile its read ranges exactly
+    for r in range(world):
+        flat = sorted(x for g in groups[r] for x in g)
+        merged = []
+        for lo, hi in flat:
+            if merged and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        assert merged == shard.rank_read_ranges(wins, deal, r)
+    pend = []
+    for j in range(k):
+        parts, seg_base = [], 0
+        for lo, hi in groups[rank][j]:
+            b = w.batch_data(lo, hi)
+            t = gather.tensors_from_result(pyoracle.liftover_batch(ix, b, abi.STAGES_ALL, 1))
+            t["item_seg"] = t["item_seg"] + seg_base
+            seg_base += b.n_segs
+            parts.append(t)
+        mine = gather.combine(parts) if parts else gather.tensors_from_result(pyoracle.liftover_batch(ix, w.batch_data(0, 0), abi.STAGES_ALL, 1))
+        if len(pend) == 2:  # two contexts' worth of buffers: the exchange posted two batches ago must be through
+            pend[-2][1].wait()
+        pend.append((j, gather.gather_payloads_async(mine, dist, rank, world)))
+    got = {j: p_.wait() for j, p_ in pend}
+    if rank == 0:
+        whole = gather.tensors_from_result(pyoracle.liftover_batch(ix, w.batch_data(), abi.STAGES_ALL, 1))
+        per_batch = []
+        for j in range(k):
+            maps_j = [gather.local_to_global_segments(w, groups[r][j]) for r in range(world)]
+            per_batch.append(gather.combine(got[j], maps_j))
+        allr = gather.combine(per_batch)
+        assert int(allr["item_seg"].numel()) == int(whole["item_seg"].numel())
+        assert gather.same_records(allr, whole)
+        open(os.path.join(outdir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_pipeline_world_size_8():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_pipeline8, args=(8, _free_port(), d), nprocs=8, join=True)
+        assert os.path.exists(os.path.join(d, "ok"))
