@@ -241,6 +241,24 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
         except Exception as e:  # noqa: BLE001
             log(f"[bench] end_to_end with device finishing failed: {e!r}")
             e2e["device_finished"] = {"value": None, "error": repr(e)}
+        # ... and with one output shard per writer thread ("each rank writes its own shard"; the reference's output order is
+        # unspecified): what the ONE-file run is bound by is the file's inode lock, not the device or the record assembly
+        shards_paths = None
+        try:
+            n_sh = max(2, min(8, io_threads // 4))
+            ss = pipeline.run_bam_to_bam(inp, os.path.join(d, "sharded.bam"), index, ixd, cn, rn, rl, window_reads=window_reads, n_workers=max(n_workers, 3), io_threads=io_threads,
+                                         unassembled_path=os.path.join(d, "unassembled_sh.bam"), device_finish=True, out_shards=n_sh)
+            shards_paths = list(ss.out_paths)
+            e2e["output_shards"] = {"value": ss.reads / ss.seconds, "unit": "reads/s", "seconds": ss.seconds, "shards": n_sh, "lift_workers": max(n_workers, 3),
+                                    "records_out": ss.records_out, "output_MB": ss.bytes_out / 1e6,
+                                    "stage_busy_s": {"decode": ss.read_s, "batch construction": ss.batch_s, "lift + finish, summed over workers": ss.lift_s,
+                                                     "record assembly, summed over workers": ss.build_s, "bgzf write, summed over writers": ss.write_s},
+                                    "stage_done_s": {k_: round(v_, 3) for k_, v_ in ss.stage_done_s.items()},
+                                    "same_records_out_and_bytes": bool(ss.records_out == st.records_out and ss.bytes_out == st.bytes_out),
+                                    "note": "device-finished records into one BGZF file per writer thread; the shards' union is the output (samtools cat joins them)"}
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] end_to_end with output shards failed: {e!r}")
+            e2e["output_shards"] = {"value": None, "error": repr(e)}
         if verify:
             # after the timed run: the written BAM re-read with the independent reader and compared, record for record, with the
             # expectation (oracle alignments + the Python restatement of the record logic) for a strided sample of >= 5 000 reads
@@ -260,6 +278,12 @@ def end_to_end(w, index, ixd, sample_reads: int, window_reads: int, n_workers: i
                     e2e["device_finished"]["records_verified"] = vd["records_verified"] if vd["ok"] else 0
                     if not vd["ok"]:
                         log("[bench] END-TO-END VERIFICATION FAILURE (device-finished records)")
+                if shards_paths and (e2e.get("output_shards") or {}).get("value"):
+                    vs = expect.verify_lifted_bam(inp, shards_paths, ixd, cn, rn, window=500, every=every, threads=min(16, io_threads),
+                                                  unassembled_bam=os.path.join(d, "unassembled_sh.bam"))
+                    e2e["output_shards"]["records_verified"] = vs["records_verified"] if vs["ok"] else 0
+                    if not vs["ok"]:
+                        log("[bench] END-TO-END VERIFICATION FAILURE (output shards)")
                 if not v["ok"]:
                     log("[bench] END-TO-END VERIFICATION FAILURE: the written BAM differs from the expected records")
             except Exception as e:  # noqa: BLE001
@@ -651,6 +675,8 @@ def finalize(result) -> int:
         why.append("end_to_end: the written BAM differs from the expected records")
     if (e2e.get("device_finished") or {}).get("records_verified") == 0:
         why.append("end_to_end (device-finished records): the written BAM differs from the expected records")
+    if (e2e.get("output_shards") or {}).get("records_verified") == 0:
+        why.append("end_to_end (output shards): the written shards differ from the expected records")
     if (result.get("verify") or {}).get("gathered_equals_single_gpu_result") is False:
         why.append("gathered records differ from the single-GPU result")
     if (result.get("end_to_end_sharded") or {}).get("records_verified") == 0 and "verification" in (result.get("end_to_end_sharded") or {}):

@@ -66,6 +66,7 @@ class PipelineStats:
     finish_device_ms: float = 0.0  # device_finish: HIP-event time of the finishing, reverse-complement and SA-text kernels
     stage_done_s: dict = field(default_factory=dict)  # when each stage's thread ended, and the closes behind them (seconds after the start)
     lift_detail_s: dict = field(default_factory=dict)  # device_finish: the lift stage by step (host clock; the steps that wait for the device carry its time)
+    out_paths: List[str] = field(default_factory=list)  # the output file, or the shards (out_shards > 1)
     errors: List[str] = field(default_factory=list)
 
 
@@ -74,7 +75,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                    io_threads: int = 16, level: int = 0, unassembled_path: Optional[str] = None, is_target_region: bool = False,
                    cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
                    device_finish: bool = False, read_threads: Optional[int] = None, build_threads: Optional[int] = None,
-                   write_threads: Optional[int] = None, ramp: bool = True, part: Optional[int] = None, n_parts: int = 1) -> PipelineStats:  # noqa: E501
+                   write_threads: Optional[int] = None, ramp: bool = True, part: Optional[int] = None, n_parts: int = 1,
+                   out_shards: int = 1) -> PipelineStats:  # noqa: E501
     """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
     (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
     plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
@@ -85,7 +87,12 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     a device), None = as the environment says.
     part / n_parts: this process's share of the input (plo_bam_open_range: a split by compressed offset) -- with several GPUs every rank
     runs the pipeline over its part and writes its own output shard (the reference's output order is unspecified: the shards'
-    concatenation is a valid result)"""
+    concatenation is a valid result)
+    out_shards > 1: the lifted records go into that many files (`out_path` with .0, .1, ... in front of its extension), one writer thread
+    each, a window's records to whichever writer is free -- the reference's output order is unspecified (docs/user_guide.md:227-230), so the
+    shards' union is the output (`samtools cat` joins them).  Buffered writes into ONE file are serialised by its inode lock (9.5 GB/s
+    from any number of threads on the GPU box, 61-126 GB/s into a file per thread: tools/write_bench.cpp), which is what bounds the
+    one-file pipeline at ~320 k reads/s of 15 kb HiFi records."""
     # threads inside the stages (inflate / batch construction, record assembly per worker, BGZF output).  The stages run at the same
     # time: half of io_threads each by default (tools/bench_e2e_threads.py on the 16-core GPU box, best of three runs: 80.6-81.4 k reads/s
     # with 8 / 4-8 / 6-8 threads against 77.1 k with 16 each; the input and output stages are bound by the page cache either way)
@@ -99,7 +106,15 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                        part=part, n_parts=n_parts)
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
-    wr = bam.BamWriter(out_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level, n_threads=write_threads)
+    out_shards = max(1, int(out_shards))
+    if out_shards == 1:
+        out_paths = [out_path]
+    else:
+        stem, ext = os.path.splitext(out_path)
+        out_paths = [f"{stem}.{k}{ext}" for k in range(out_shards)]
+    st.out_paths = list(out_paths)
+    hdr_out = bam.output_header(ref_names, ref_lens, cmdline=cmdline)
+    wrs = [bam.BamWriter(p_, hdr_out, ref_names, ref_lens, level=level, n_threads=max(1, write_threads // out_shards)) for p_ in out_paths]
     un = None
     if unassembled_path:
         un = bam.BamWriter(unassembled_path, bam.output_header(ref_names, ref_lens, cmdline=cmdline), ref_names, ref_lens, level=level,
@@ -173,6 +188,9 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.stage_done_s["batcher"] = time.perf_counter() - t0
             for _ in range(n_workers):
                 put(q_in, None)
+            # the reader's teardown (its page-locked stream buffer and device buffers: ~0.1 s for a 4 GB input) runs beside the last
+            # windows' lifting and writing: no window needs the reader once its batch is built
+            closer.start()
 
     def lifter(k):
         eng = None
@@ -248,43 +266,62 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
             st.stage_done_s[f"lift worker {k}"] = time.perf_counter() - t0
             if eng is not None:
                 eng.close()
-            put(q_out, None)
 
-    def writer():
-        done = 0
+    un_lock = threading.Lock()
+
+    def close_reader():
+        t = time.perf_counter()
+        rd.close()
+        st.stage_done_s["reader closed"] = time.perf_counter() - t0
+        st.stage_done_s["reader close took"] = time.perf_counter() - t
+
+    closer = threading.Thread(target=close_reader)
+
+    def writer(k):
+        # (one sentinel per writer, posted by the main thread when every lift worker has ended)
         try:
-            while done < n_workers and not abort.is_set():
+            while not abort.is_set():
                 item = get(q_out)
                 if item is None:
-                    done += 1
-                    continue
+                    break
                 win, rb = item
                 t = time.perf_counter()
                 if rb is not None and rb.n_bytes:
-                    wr.write((rb.bytes, rb.n_bytes))
+                    wrs[k].write((rb.bytes, rb.n_bytes))
                 ub, nu = win.unmapped_bytes()
                 if nu:
-                    st.unmapped_passed_through += nu
-                    if un is not None:
-                        un.write(ub)
+                    with un_lock:
+                        st.unmapped_passed_through += nu
+                        if un is not None:
+                            un.write(ub)
                 win.close()
-                st.write_s += time.perf_counter() - t
+                with lock:
+                    st.write_s += time.perf_counter() - t
         except BaseException as e:  # noqa: BLE001
-            st.errors.append(f"writer: {e!r}")
+            st.errors.append(f"writer {k}: {e!r}")
             abort.set()
-        st.stage_done_s["writer"] = time.perf_counter() - t0
+        st.stage_done_s["writer" if out_shards == 1 else f"writer {k}"] = time.perf_counter() - t0
 
     st.stage_done_s["set up"] = time.perf_counter() - t0
-    threads = [threading.Thread(target=reader), threading.Thread(target=batcher), threading.Thread(target=writer)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
-    for t in threads:
+    front = [threading.Thread(target=reader), threading.Thread(target=batcher)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
+    writers = [threading.Thread(target=writer, args=(k,)) for k in range(out_shards)]
+    for t in front + writers:
         t.start()
-    for t in threads:
+    for t in front:
         t.join()
-    wr.close()
+    for _ in writers:
+        put(q_out, None)
+    for t in writers:
+        t.join()
+    for wr in wrs:
+        wr.close()
     st.stage_done_s["output closed"] = time.perf_counter() - t0
     if un is not None:
         un.close()
-    rd.close()
+    if closer.ident is not None:  # (started by the batcher)
+        closer.join()
+    else:
+        rd.close()
     st.seconds = time.perf_counter() - t0
     st.stage_done_s["all closed"] = st.seconds
     if st.errors:

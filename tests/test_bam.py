@@ -683,6 +683,29 @@ def test_bam_to_bam_chr20_size_every_record(tmp_path, device_finish):
     index.close()
 
 
+@pytest.mark.gpu
+def test_bam_to_bam_into_output_shards(tmp_path):
+    """out_shards: the lifted records into three files, one writer thread each (buffered writes into ONE file are serialised by its inode
+    lock: the one-file pipeline's bound) -- the shards' union holds exactly the expected records, every shard is a BAM of its own"""
+    from oracle import expect
+    from portello_amd import pipeline
+
+    w = synth.generate(synth.config("chr20", n_reads=20_000), device="cuda")
+    inp, outp, unp = str(tmp_path / "reads.bam"), str(tmp_path / "lifted.bam"), str(tmp_path / "unassembled.bam")
+    meta = bamsynth.write_read_bam(w, inp, level=1, n_threads=8)
+    ixd = w.index_data()
+    index = api.Index(w.index_data_device())
+    cn, rn = meta["contig_names"], bamsynth.ref_names(w)
+    st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, [int(s.numel()) for s in w.chrom_seq], window_reads=1500, n_workers=2,
+                                 io_threads=8, unassembled_path=unp, device_finish=True, out_shards=3)
+    assert st.reads == w.n_reads and len(st.out_paths) == 3 and all(os.path.exists(p_) and os.path.getsize(p_) > 1000 for p_ in st.out_paths)
+    assert not os.path.exists(outp)
+    v = expect.verify_lifted_bam(inp, st.out_paths, ixd, cn, rn, window=1000, every=1, threads=8, unassembled_bam=unp)
+    assert v["ok"] and v["reads_verified"] == w.n_reads and v["records_verified"] == st.records_out == v["records_in_output"], v
+    assert v["unassembled_ok"]
+    index.close()
+
+
 def test_long_tail_of_unmapped_reads_comes_in_bounded_windows(tmp_path):
     """a window ends on the count of primary records -- and on 4 x that many (+ 1024) unmapped ones: the unmapped tail of a sorted BAM does
     not end up in one window, and every pass-through record still arrives exactly once, in order"""
