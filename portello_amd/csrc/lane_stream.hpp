@@ -56,6 +56,8 @@ PLO_DEV void pipe_idle(int streak) {
 PLO_DEV void pipe_order() { asm volatile("" ::: "memory"); }  // LDS operations of a wave execute in order: only the compiler may not move them
 #endif
 
+constexpr uint32_t PIPE_PAIR = 0x4Fu;  // (a marker, see below) an indel cluster of more than one op begins behind this word
+
 // Ring of N ops per lane (N a power of two): op e lives in b[(e & (N - 1)) * 64] (b: the lane's word of element 0; bank = lane).
 // Producer side: lane_push()'s logic (leading edge, zero-length filter, run merging) with `rel`: entries [0, rel) are final; `rk`: what
 // the consumer has taken (its own count, or the last look at the consumer's published one).
@@ -69,6 +71,7 @@ struct LaneRing {
     uint32_t acc = 0;  // the open run (starts as Match(0), cigar/mod.rs:206)
     int lead_shift = 0;
     bool seen_m = false, ovf = false;
+    bool in_pair = false;  // MARK (ring_push): the indel cluster being written has its PIPE_PAIR marker already
 };
 template <int N>
 PLO_DEV int ring_room(const LaneRing<N> &r) { return N - (r.no - r.rk); }
@@ -79,6 +82,7 @@ PLO_DEV void ring_new_item(LaneRing<N> &r, bool on) {
     r.lead_shift = on ? 0 : r.lead_shift;
     r.seen_m = r.seen_m & !on;
     r.ovf = r.ovf & !on;
+    r.in_pair = r.in_pair & !on;
 }
 // one raw word (headers, markers): the open run must have been flushed
 template <int N>
@@ -87,7 +91,10 @@ PLO_DEV void ring_put(LaneRing<N> &o, bool on, uint32_t v) {
     o.no += on ? 1 : 0;
 }
 // lane_push (lane_core.hpp) into a ring: straight-line; a flushed alignment-match op releases everything up to and including itself
-template <bool PAD, int N>
+// MARK (the liftover's ring, round 6): an indel cluster of MORE THAN ONE op -- the only place the simplify stage can change anything
+// (simplify_alignment_indels.rs:41-48: a cluster of one kind is emitted as it is) -- gets a PIPE_PAIR marker in front of its first op; it is
+// written when the cluster's first op is flushed with another indel behind it (both still unreleased: a release ends at a match).
+template <bool PAD, int N, bool MARK = false>
 PLO_DEV void ring_push(LaneRing<N> &o, bool on, int t, int L) {
     const bool lead = on & !o.seen_m;
     const bool drop_d = lead & (t == OP_D);
@@ -99,10 +106,19 @@ PLO_DEV void ring_push(LaneRing<N> &o, bool on, int t, int L) {
     const bool same = live & (t == at);
     // (the callers leave room for a step's pushes; a push without room would overwrite what the consumer has not read: the op is lost,
     // the ring stays as it is -- every entry the consumer sees is a whole one -- and the item goes to the retry list)
-    const bool ok = (o.no - o.rk) < N;
     const bool wflush = live & !same & (o.acc >= 16u);
+    bool pair = false;
+    if constexpr (MARK) {
+        pair = wflush & b_is_indel(at) & b_is_indel(t) & !o.in_pair;
+        o.in_pair = (o.in_pair | pair) & !(live & !b_is_indel(t));
+    }
+    const bool ok = (o.no - o.rk) < N - (pair ? 1 : 0);
     o.ovf = o.ovf | (wflush & !ok);
     const bool flush = wflush & ok;
+    if constexpr (MARK) {
+        if (flush & pair) o.b[(o.no & (N - 1)) * 64] = PIPE_PAIR;
+        o.no += (flush & pair) ? 1 : 0;
+    }
     if (flush) o.b[(o.no & (N - 1)) * 64] = o.acc;
     o.no += flush ? 1 : 0;
     o.rel = (flush & b_is_match(at)) ? o.no : o.rel;
@@ -135,7 +151,9 @@ PLO_DEV void ring_finish(LaneRing<N> &o, bool on) {
         int t = op_type(c);
         const int L = op_len(c);
         i += act ? 1 : 0;
-        const bool keep = act & (t != OP_D);  // a trailing D becomes S(0), which compress_cigar drops
+        // a trailing D becomes S(0), which compress_cigar drops; a PIPE_PAIR marker goes with the cluster it marked (no indel is left behind
+        // the last match)
+        const bool keep = act & (t != OP_D) & (t != 15);
         t = (t == OP_I) ? (int)OP_S : t;
         const bool same = keep & (run >= 16u) & (t == (int)(run & 15u));
         const bool flush = keep & !same & (run >= 16u);
@@ -159,11 +177,22 @@ constexpr uint32_t PIPE_TERM = 0x3Fu;  // the lane's last word
 constexpr int PIPE_ST_OVF = 0xFE;      // EOI status: retry list
 constexpr int PIPE_H1 = 3, PIPE_H2 = 4;  // entries of an item's header in Q1 / Q2 (SOI included)
 PLO_DEV bool pipe_is_marker(uint32_t c) { return (c & 15u) == 15u; }
-
 constexpr int STREAM_A_PUSH = 8;    // most ops one step of a stage can flush into its ring: shift event M I D, again for a cluster right in front of a flushing op, M other;
-constexpr int STREAM_B_PUSH = 2;    // liftover: gap deletion + piece,
+constexpr int STREAM_B_PUSH = 1;    // liftover: a gap deletion or a piece (+ one PIPE_PAIR marker where the ring has them: stream_b_push),
 constexpr int STREAM_C_PUSH = 5;    // simplify: M I D M + the copied op
 constexpr int STREAM_END_PUSH = 2;  // an item's end: the open run + the end marker
+// The liftover's ring carries PIPE_PAIR markers, and the simplify wave copies unmarked stretches through, when the ring has 16 entries or
+// more (the production geometry); the 8-entry ring of the tests' tightest geometry has no room for a marker beside a step's two ops, a
+// header and an end, and keeps every op on the step-by-step path.
+PLO_DEV constexpr bool stream_marks(int n2) { return n2 >= 16; }
+// (one op per step, a marker in front of it at most -- and never less than an item's end needs: the step that takes the input's end marker
+// writes nothing, and the end must find its room behind it or the lane waits for a consumer that has nothing released to take)
+PLO_DEV constexpr int stream_b_push(int n2) { return (1 + (stream_marks(n2) ? 1 : 0)) > STREAM_END_PUSH ? (1 + (stream_marks(n2) ? 1 : 0)) : STREAM_END_PUSH; }
+
+#ifndef PLO_PIPE_BULK
+#define PLO_PIPE_BULK 8
+#endif
+constexpr int STREAM_BULK = PLO_PIPE_BULK;  // ops per lane the simplify wave copies through per trip where it cannot change them (0: every op through its step)
 #ifndef PLO_PIPE_REFILL
 #define PLO_PIPE_REFILL 16
 #endif
@@ -669,11 +698,12 @@ PLO_DEV void pipe_stage_liftover(const DevIndex &ix, const DevBatch &bt, const D
         } else {
             b_avail = rk1 < rel1;
         }
-        const bool room_ok = ring_room(q2) >= STREAM_B_PUSH;
+        const bool room_ok = ring_room(q2) >= stream_b_push(N2);
         const bool b_rdy = live & (drop | room_ok) & (in_op | b_avail);
         const bool stuck = live & !drop & !room_ok & (q2.rk == q2.rel);
         if (wv::ballot(stuck) != 0ull) {
             q2.no = stuck ? wv::imax(q2.rel, q2.base) : q2.no;
+            q2.in_pair = q2.in_pair & !stuck;
             q2.acc = stuck ? 0u : q2.acc;
             q2.ovf = q2.ovf | stuck;
             drop = drop | stuck;
@@ -691,7 +721,7 @@ PLO_DEV void pipe_stage_liftover(const DevIndex &ix, const DevBatch &bt, const D
                     bool av;
                     if constexpr (HEAD) av = (b_k < in_hi) | (b_k >= n_in);
                     else av = rk1 < rel1;
-                    bm = live & (drop | (ring_room(q2) >= STREAM_B_PUSH)) & (in_op | av);
+                    bm = live & (drop | (ring_room(q2) >= stream_b_push(N2))) & (in_op | av);
                     const unsigned long long m2 = wv::ballot(bm);
                     if (2 * __builtin_popcountll(m2) < __builtin_popcountll(mB) || m2 == 0ull) break;
                 }
@@ -740,18 +770,20 @@ PLO_DEV void pipe_stage_liftover(const DevIndex &ix, const DevBatch &bt, const D
                 r2s = set_start ? wrap_add(vb, block_pos - kb) : r2s;
                 has_start = has_start | set_start;
                 const int d = wrap_add(vb, -r2e);  // :91-96 (wrapping: vb is NONE32 where the piece is not mapped, and then unused)
+                // ONE writer call per step, as in lane_tile (round 6): a piece that enters its block behind a jump of the reference takes two
+                // steps -- the deletion D(d) first, which moves ref2_end_pos up to the block's start, then the piece itself with d == 0
                 const bool e0 = mp & has_end & (d > 0) & has_start;
                 has_end = has_end | mp;
-                r2e = mp ? wrap_add(vb, pend_ - kb) : r2e;  // :98-100
+                const bool go = piece & !e0;
+                r2e = mp ? wrap_add(vb, e0 ? 0 : pend_ - kb) : r2e;  // :98-100
                 // :102-109 mapped piece | :111-115 insertion over an unmapped block | :117-123 soft clip before the first block
-                const bool e1p = piece & (mapped ? (ism_op | has_start) : ism_op);
+                const bool e1p = go & (mapped ? (ism_op | has_start) : ism_op);
                 const int t1p = mapped ? (t_op == OP_D ? (int)OP_D : (t_op == OP_N ? (int)OP_N : (int)OP_M)) : (bvalid ? (int)OP_I : (int)OP_S);
-                block_pos = piece ? pend_ : block_pos;
-                const bool done = piece & (pend_ >= seg_end);
+                block_pos = go ? pend_ : block_pos;
+                const bool done = go & (pend_ >= seg_end);
                 in_op = in_op & !done;
                 seg_start = done ? seg_end : seg_start;
-                ring_push<false>(q2, e0, OP_D, d);
-                ring_push<false>(q2, copy | e1p, copy ? tf : t1p, copy ? Lf : plen);
+                ring_push<false, N2, stream_marks(N2)>(q2, e0 | copy | e1p, e0 ? (int)OP_D : (copy ? tf : t1p), e0 ? d : (copy ? Lf : plen));
                 kf = adv ? fk : kf;  // the entry after next (kv_fetch above)
                 vf = adv ? fv : vf;
                 finp = finp | b_end;
@@ -798,6 +830,7 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
     ReadSeq rd = item_read_seq<SP>(bt, 0ull, 0, 0);
     int c_ref_head = 0, c_read_head = 0, c_del = 0, c_ins = 0, c_blk_ref = 0, c_blk_read = 0, cmp = 0;
     bool c_in_blk = false, spanic = false, zero_m = false;
+    bool pair_open = false;  // a PIPE_PAIR marker has been taken and its cluster is not through yet: no copying ahead
     LaneRing<N3> q3;  // (both sides in this wave)
     q3.b = pm.q3;
     int flushed = 0;  // ops of the item written out; q3.rk = the start of the chunk that holds the next one (its ops go out again with it)
@@ -867,6 +900,7 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
                 c_ins = mine ? 0 : c_ins;
                 cmp = mine ? 0 : cmp;
                 c_in_blk = c_in_blk & !mine;
+                pair_open = pair_open & !mine;
                 spanic = spanic & !mine;
                 zero_m = zero_m & !mine;
                 ring_new_item(q3, mine);
@@ -937,6 +971,52 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
                 flushing = flushing & !em;
             }
         }
+        // ---- the stretches the stage cannot change (round 6, DESIGN.md 11.3 of round 5; off line 99.4 % of the stress profile's ops): up to
+        // STREAM_BULK ops per lane go from Q2 to Q3 as they are -- no cluster state machine, no writer: the liftover's ring holds a cleaned,
+        // compressed CIGAR, and on such a CIGAR the stage is the identity except at indel clusters of more than one op
+        // (simplify_alignment_indels.rs:41-48), which the liftover has marked (PIPE_PAIR).  An op is taken while the entry BEHIND it is a
+        // released op too: the op in front of a marker -- a match the cluster's M(pre) may merge into -- and the one in front of the item's end
+        // are left to the step below, as is everything until the first match (the leading-edge rule) and while a cluster is open.
+        unsigned long long mK = 0ull;
+        if constexpr (STREAM_BULK > 0 && stream_marks(N2)) {
+            const int avail = rel2 - rk2;
+            const bool bk = live & !passthru & !ovf & q3.seen_m & !c_in_blk & !pair_open & (avail >= 3) & (ring_room(q3) >= STREAM_BULK + 1);
+            const unsigned long long mb = wv::ballot(bk);
+            if (mb != 0ull && 4 * __builtin_popcountll(mb) >= __builtin_popcountll(wv::ballot(live))) {
+                mK = mb;
+                uint32_t cw[STREAM_BULK + 1];
+#pragma unroll
+                for (int j = 0; j <= STREAM_BULK; ++j) cw[j] = pm.q2[((bk ? rk2 + j : 0) & (N2 - 1)) * 64];
+                // nb: the longest run of ops from the front whose successor is a released op
+                int nb = 0;
+                bool run = bk;
+#pragma unroll
+                for (int j = 0; j < STREAM_BULK; ++j) {
+                    run = run & (j + 1 < avail) & !pipe_is_marker(cw[j]) & !pipe_is_marker(cw[j + 1]);
+                    nb += run ? 1 : 0;
+                }
+                const bool any = nb > 0;
+                {   // the writer's open run goes out first (what follows it in a compressed CIGAR is of another kind)
+                    const bool fl = any & (q3.acc >= 16u);
+                    if (fl) q3.b[(q3.no & (N3 - 1)) * 64] = q3.acc;
+                    q3.no += fl ? 1 : 0;
+                    q3.rel = (fl & b_is_match((int)(q3.acc & 15u))) ? q3.no : q3.rel;
+                    q3.acc = any ? 0u : q3.acc;
+                }
+#pragma unroll
+                for (int j = 0; j < STREAM_BULK; ++j) {
+                    const bool on = j < nb;
+                    const uint32_t c = cw[j];
+                    const int t = op_type(c), L = op_len(c);
+                    if (on) q3.b[(q3.no & (N3 - 1)) * 64] = c;
+                    q3.no += on ? 1 : 0;
+                    q3.rel = (on & b_is_match(t)) ? q3.no : q3.rel;
+                    c_read_head += (on & b_read_cons(t)) ? L : 0;
+                    c_ref_head += (on & b_ref_cons(t)) ? L : 0;
+                }
+                rk2 += nb;
+            }
+        }
         // ---- the step ----
         const bool c_avail = rk2 < rel2;
         const bool room_ok = ring_room(q3) >= STREAM_C_PUSH;
@@ -959,9 +1039,11 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
             const uint8_t *const cref = (const uint8_t *)(uintptr_t)chrom_ref;
             const uint32_t c = pm.q2[((cm ? rk2 : 0) & (N2 - 1)) * 64];
             rk2 += cm ? 1 : 0;
-            const bool atend = cm & pipe_is_marker(c);  // (inside an item the only marker is its end)
+            const bool is_pair = cm & (c == PIPE_PAIR);  // (the liftover's mark in front of a cluster of several ops: nothing to do for it here)
+            const bool atend = cm & pipe_is_marker(c) & !is_pair;  // (the only other marker inside an item is its end)
             up_st = atend ? (int)((c >> 8) & 0xffu) : up_st;
-            const bool valid = cm & !atend & !ovf;
+            const bool valid = cm & !atend & !is_pair & !ovf;
+            pair_open = pair_open | is_pair;
             const int t = op_type(c), L = op_len(c);
             const bool raw = valid & passthru;
             if (raw) q3.b[(q3.no & (N3 - 1)) * 64] = c;
@@ -1017,6 +1099,7 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
                 c_del = endc ? 0 : c_del;
                 c_ins = endc ? 0 : c_ins;
                 c_in_blk = c_in_blk & !endc;
+                pair_open = pair_open & !endc;
             }
             const bool open = indel & !c_in_blk;  // _add_indel (:16-22)
             c_blk_ref = open ? c_ref_head : c_blk_ref;
@@ -1047,8 +1130,8 @@ PLO_DEV void pipe_stage_simplify(const DevBatch &bt, const DevWork &wk, PipeMem<
         pipe_order();
         *pm.q2_rk = (uint32_t)rk2;
         if (wv::ballot(!termd | flushing) == 0ull) break;
-        streak = (mC | mF) != 0ull ? 0 : streak + 1;
-        if ((mC | mF) == 0ull) pipe_idle(streak);
+        streak = (mC | mF | mK) != 0ull ? 0 : streak + 1;
+        if ((mC | mF | mK) == 0ull) pipe_idle(streak);
     }
 }
 
@@ -1058,7 +1141,7 @@ template <bool SP, int NI, int N1, int N2, int N3>
 PLO_DEV void pipe_team(const DevIndex &ix, const DevBatch &bt, const DevWork &wk, uint32_t b, uint32_t e, bool has_shift, uint32_t *lds, WaveCtx &ctx) {
     static_assert((NI & (NI - 1)) == 0 && (N1 & (N1 - 1)) == 0 && (N2 & (N2 - 1)) == 0 && (N3 & (N3 - 1)) == 0, "ring sizes are powers of two");
     static_assert(NI >= STREAM_REFILL + STREAM_A_MIN_IN, "IN: a refill fits while a step's worth of input is left");
-    static_assert(N1 >= PIPE_H1 + STREAM_A_PUSH && N2 >= PIPE_H2 + STREAM_B_PUSH + STREAM_END_PUSH && N3 >= STREAM_C_PUSH + STREAM_FLUSH + 4, "a fresh item's first step fits behind its header");
+    static_assert(N1 >= PIPE_H1 + STREAM_A_PUSH && N2 >= PIPE_H2 + stream_b_push(N2) + STREAM_END_PUSH && N3 >= STREAM_C_PUSH + STREAM_FLUSH + 4, "a fresh item's first step fits behind its header");
     const int role = wv::wave_id(), lane = wv::lane();
     PipeMem<NI, N1, N2, N3> pm(lds, lane);
     if (role == 0) {
