@@ -1086,6 +1086,33 @@ def main():
                 return d_
 
             dt_async = guarded(async_run)
+        # (a') the same synchronous gather through the library's own C ABI (plo_gather_*: ncclAllGather of the sizes + grouped ncclSend / ncclRecv
+        # on a communicator the library creates -- what a Rust host binds, INTEGRATION.md section 6 route (b)); torch.distributed only
+        # carries the 128-byte id
+        dt_abi = None
+        abi_parts = None
+        if dt_sync is not None and not host_comm and n_workers == 1:
+            def abi_run():
+                ag = plo_gather.AbiGather(index.lib, dist, rank, world, dev_index)
+                last = [None]
+
+                def run(n_steps):
+                    for _ in range(n_steps):
+                        out_ = eng.liftover_batch_dev(desc)
+                        eng.compact_output_dev(out_)
+                        last[0] = ag.gather(eng, out_, dev).wait()
+
+                run(1)
+                d_ = timed(run, args.steps)
+                parts_ = [{k_: v.clone() for k_, v in t_.items()} for t_ in last[0]] if rank == 0 else None
+                ag.close()
+                return d_, parts_
+
+            got_abi = guarded(abi_run)
+            if got_abi is not None:
+                dt_abi, abi_parts = got_abi
+            else:
+                gather_error[0] = None  # (supplementary: the modes below still run)
         # (c) the reference's window loop on every rank (src/read_alignment_scanner.rs:508-534: window tasks one after the other, one locked
         # writer behind them): the rank's windows as k batches on two contexts, the exchange of batch i under the compute of batch i + 1 --
         # across the steps' boundaries too; only the last batch's exchange of the last step is waited for with nothing to hide it under.
@@ -1103,6 +1130,9 @@ def main():
                 p_streams = [streams[0], s2]
                 p_engs = [engs[0], api.Engine(index, stream=s2.cuda_stream)]
 
+                def snap(got_):  # (the root's own part is a view of a context's buffers, which the context's next batch overwrites)
+                    return None if got_ is None else [{k_: v.clone() for k_, v in t_.items()} for t_ in got_]
+
                 def pipe_run(n_steps, keep=None):
                     pending = [None, None]
                     for i in range(n_steps * k_pipe):
@@ -1111,7 +1141,7 @@ def main():
                             with torch.cuda.stream(p_streams[c_]):
                                 got_ = pending[c_][1].wait()
                             if keep is not None:
-                                keep[pending[c_][0]] = got_
+                                keep[pending[c_][0]] = snap(got_)
                             pending[c_] = None
                         out_j = p_engs[c_].liftover_batch_dev(sub_descs[j])
                         p_engs[c_].compact_output_dev(out_j)
@@ -1120,7 +1150,7 @@ def main():
                                 mine = {k_: v.cpu() for k_, v in plo_gather.tensors_from_out(out_j, dev).items()}
                                 got_ = plo_gather.gather_payloads(mine, dist, rank, world)
                                 if keep is not None:
-                                    keep[j] = got_
+                                    keep[j] = snap(got_)
                             else:
                                 pending[c_] = (j, plo_gather.gather_results_async(out_j, dev, dist, rank, world))
                     for c_ in (0, 1):
@@ -1128,7 +1158,7 @@ def main():
                             with torch.cuda.stream(p_streams[c_]):
                                 got_ = pending[c_][1].wait()
                             if keep is not None:
-                                keep[pending[c_][0]] = got_
+                                keep[pending[c_][0]] = snap(got_)
 
                 pipe_run(1)  # (sizes the second context's buffers)
                 d_ = timed(pipe_run, args.steps)
@@ -1137,7 +1167,7 @@ def main():
                 torch.cuda.synchronize()
                 parts_ = None
                 if rank == 0:
-                    parts_ = [[{k_: v.clone() for k_, v in t_.items()} for t_ in kept[j]] for j in range(k_pipe)]
+                    parts_ = [kept[j] for j in range(k_pipe)]
                 p_engs[1].close()
                 engs[0].liftover_batch_dev(desc)  # (this rank's own whole-share result back in the first context)
                 engs[0].sync()
@@ -1155,6 +1185,9 @@ def main():
             if dt_async < dt_sync:  # the headline is the faster complete pipeline: K steps, all K record sets on rank 0 when the clock stops
                 result = make_result(dt_async, "rccl send/recv to rank 0, the exchange of batch i overlapped with the compute of batch i+1 "
                                                "(two contexts alternate)")
+        if dt_abi is not None:
+            gather_modes["c_abi"] = {"value": total_reads * args.steps / dt_abi, "unit": "reads/s", "ms_per_step": dt_abi / args.steps * 1e3,
+                                     "note": "plo_gather_records / plo_gather_wait after every step (the library's own RCCL communicator)"}
         if dt_pipe is not None:
             gather_modes["window_pipeline"] = {"value": total_reads * args.steps / dt_pipe, "unit": "reads/s", "ms_per_step": dt_pipe / args.steps * 1e3,
                                                "batches_per_rank_and_step": k_pipe, "reads_per_batch_this_rank": [int(d_.n_reads) for d_ in sub_dbs],
@@ -1258,6 +1291,11 @@ def main():
                               "reads": int(w.n_reads), "single_gpu_device_ms": whole_ms,
                               "this_rank": {"reads": int(my_reads), "ms_per_step_no_gather": dt_ng / args.steps * 1e3,
                                             "single_gpu_pro_rata_ms": whole_ms * my_reads / max(1.0, total_reads)}}
+                    if abi_parts is not None:  # the C ABI's gather
+                        same_a = plo_gather.same_records(plo_gather.combine([{k_: v.to(comm_dev) for k_, v in t_.items()} for t_ in abi_parts], seg_maps), whole)
+                        verify["c_abi_gather_equals_single_gpu_result"] = bool(same_a)
+                        same = same and same_a
+                        verify["gathered_equals_single_gpu_result"] = bool(same)
                     if pipe_parts is not None:  # the window pipeline's batches, every one mapped back to the unsharded numbering
                         per_batch = []
                         for j in range(k_pipe):

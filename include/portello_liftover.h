@@ -346,6 +346,32 @@ plo_status plo_sa_segments_dev(plo_ctx *ctx, const plo_sa_in *in, plo_sa_out *ou
    stream (or call plo_ctx_sync). */
 plo_status plo_compact_output_dev(plo_ctx *ctx, plo_batch_out *out);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The record gather of several GPUs (one process per GPU; SURVEY.md 8(e), INTEGRATION.md section 6 route (b)): the reference's sink is
+ * one locked writer behind all workers (src/read_alignment_scanner.rs:24, :483) -- here rank `root` receives every rank's result
+ * arrays over RCCL: a 16-byte size all-gather, then ONE group of ncclSend (peers) / ncclRecv (root) per array, device memory to device
+ * memory (xGMI is point to point: every peer's link runs into the root at once).  RCCL is bound by name at the first call.
+ *   rank 0:      plo_gather_unique_id(id); hand `id` to the other ranks (a file, a socket, MPI, torch.distributed ...)
+ *   every rank:  plo_gather_create(id, rank, world, device, &g);
+ *   per batch:   plo_liftover_batch_dev(ctx, ..., &out); plo_compact_output_dev(ctx, &out);
+ *                plo_gather_records(g, ctx, &out, root, gathered = an array of `world` structs on root, NULL elsewhere); ... plo_gather_wait(g);
+ * plo_gather_records returns when the exchange is posted on the context's stream (behind the compaction); the sizes in `gathered` are
+ * valid at once, the arrays after plo_gather_wait (or any synchronisation of that stream).  gathered[root] points at the rank's own
+ * arrays, the others at buffers the gather object owns until its next call.  A context must not start its next batch before the
+ * exchange that reads its buffers is through (two contexts taking turns hide the exchange under the next batch's kernels).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define PLO_GATHER_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+typedef struct plo_gather plo_gather;
+plo_status plo_gather_unique_id(uint8_t id[PLO_GATHER_ID_BYTES]);
+plo_status plo_gather_create(const uint8_t id[PLO_GATHER_ID_BYTES], int rank, int world, int device, plo_gather **out);
+void plo_gather_destroy(plo_gather *g);
+plo_status plo_gather_records(plo_gather *g, plo_ctx *ctx, const plo_batch_out *out, int root, plo_batch_out *gathered);
+plo_status plo_gather_wait(plo_gather *g);
+const char *plo_gather_last_error(const plo_gather *g); /* g == NULL: the calling thread's last plo_gather_unique_id / _create failure */
+/* the HIP stream and device ordinal a context runs on (what a caller orders its own work behind / selects before its own HIP calls) */
+void *plo_ctx_stream(plo_ctx *ctx);
+int plo_ctx_device(plo_ctx *ctx);
+
 /* Page-locked host memory for the arrays handed to plo_liftover_batch: copies from such buffers are direct DMA transfers
    (measured on MI355X, chr20 batch of 50 k reads / 385 MB: pageable 14 GB/s, page-locked see DESIGN.md).  The caller fills
    them in place (e.g. one set per worker thread, reused from batch to batch) and releases them with plo_host_free. */

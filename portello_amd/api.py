@@ -80,6 +80,22 @@ def load_library(path: Optional[str] = None):
     L.plo_ctx_sync.argtypes = [vp]
     L.plo_ctx_download.restype = C.c_int
     L.plo_ctx_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.plo_gather_unique_id.restype = C.c_int
+    L.plo_gather_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.plo_gather_create.restype = C.c_int
+    L.plo_gather_create.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.plo_gather_destroy.restype = None
+    L.plo_gather_destroy.argtypes = [vp]
+    L.plo_gather_records.restype = C.c_int
+    L.plo_gather_records.argtypes = [vp, vp, C.POINTER(abi.PloBatchOut), C.c_int, C.POINTER(abi.PloBatchOut)]
+    L.plo_gather_wait.restype = C.c_int
+    L.plo_gather_wait.argtypes = [vp]
+    L.plo_gather_last_error.restype = C.c_char_p
+    L.plo_gather_last_error.argtypes = [vp]
+    L.plo_ctx_stream.restype = vp
+    L.plo_ctx_stream.argtypes = [vp]
+    L.plo_ctx_device.restype = C.c_int
+    L.plo_ctx_device.argtypes = [vp]
     L.plo_ctx_set_stats.restype = C.c_int
     L.plo_ctx_set_stats.argtypes = [vp, C.c_int]
     L.plo_api_version.restype = C.c_uint32

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libportello_liftover.so")
-SOURCES = ["engine.hip", "bam_host.cpp", "phase1.cpp"]
+SOURCES = ["engine.hip", "bam_host.cpp", "phase1.cpp", "gather_rccl.cpp"]
 LIBS = ["-lz", "-ldl"]
 HEADERS = ["plo_wave.hpp", "lift_core.hpp", "lane_core.hpp", "lane_stream.hpp", "inflate.hpp", "finish_core.hpp", "lift_types.hpp", "index_pack.hpp", "enumerate.hpp", "bam_internal.hpp"]
 
@@ -37,7 +37,7 @@ def build_timing() -> str:
     """instrumented variant (per-phase s_memtime accumulation) used by tools/tune.py only"""
     out = os.path.join(HERE, "libportello_liftover_timing.so")
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPLO_PHASE_TIMING", "-I" + CSRC, "-o", out,
-           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "bam_host.cpp"), os.path.join(CSRC, "phase1.cpp")] + LIBS
+           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "bam_host.cpp"), os.path.join(CSRC, "phase1.cpp"), os.path.join(CSRC, "gather_rccl.cpp")] + LIBS
     subprocess.check_call(cmd)
     return out
 

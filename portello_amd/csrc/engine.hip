@@ -1778,6 +1778,9 @@ void plo_ctx_destroy(plo_ctx *c) {
 
 const char *plo_last_error(const plo_ctx *c) { return c ? c->err.c_str() : g_index_err.c_str(); }
 
+void *plo_ctx_stream(plo_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int plo_ctx_device(plo_ctx *c) { return c ? c->ix->device : -1; }
+
 plo_status plo_ctx_set_stats(plo_ctx *c, int on) {
     if (!c) return PLO_ERR_INVALID_ARG;
     c->lane_stats = on != 0;

@@ -251,3 +251,66 @@ def local_to_global_segments(w, read_ranges) -> torch.Tensor:
         s1 = int(torch.searchsorted(w.seg_read, torch.tensor(hi, device=dev)).item())
         parts.append(torch.arange(s0, s1, device=dev))
     return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long, device=dev)
+
+
+# ---- the same exchange through the library's C ABI (plo_gather_*: what a host that is not Python binds) ----
+
+class AbiGather:
+    """plo_gather_create / plo_gather_records / plo_gather_wait.  The communicator is the library's own (ncclCommInitRank on an id that
+    rank 0 makes and `dist` -- any initialised torch.distributed group, gloo will do -- carries to the others)."""
+
+    def __init__(self, lib, dist, rank: int, world: int, device: int, root: int = 0):
+        import ctypes as C
+
+        self.lib, self.rank, self.world, self.root = lib, rank, world, root
+        ident = (C.c_uint8 * 128)()
+        if rank == root:
+            st = lib.plo_gather_unique_id(ident)
+            if st != abi.PLO_OK:
+                raise RuntimeError(f"plo_gather_unique_id: {(lib.plo_gather_last_error(None) or b'').decode()}")
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=root)
+        ident = (C.c_uint8 * 128)(*box[0])
+        h = C.c_void_p()
+        st = lib.plo_gather_create(ident, rank, world, device, C.byref(h))
+        if st != abi.PLO_OK:
+            raise RuntimeError(f"plo_gather_create: {(lib.plo_gather_last_error(None) or b'').decode()}")
+        self.handle = h
+        self._outs = None
+
+    def gather(self, eng, out: abi.PloBatchOut, dev) -> "AbiPending":
+        """posts the exchange of `out` (the engine's last, compacted result) behind the engine's kernels; wait() gives the per-rank tensor
+        dicts on the root (zero-copy views of the library's receive buffers, valid until the next gather), None elsewhere"""
+        import ctypes as C
+
+        outs = (abi.PloBatchOut * self.world)() if self.rank == self.root else None
+        st = self.lib.plo_gather_records(self.handle, eng.handle, C.byref(out), self.root, outs)
+        if st != abi.PLO_OK:
+            raise RuntimeError(f"plo_gather_records: {(self.lib.plo_gather_last_error(self.handle) or b'').decode()}")
+        self._outs = outs
+        return AbiPending(self, outs, dev)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.plo_gather_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class AbiPending:
+    def __init__(self, g: AbiGather, outs, dev):
+        self.g, self.outs, self.dev = g, outs, dev
+
+    def wait(self):
+        st = self.g.lib.plo_gather_wait(self.g.handle)
+        if st != abi.PLO_OK:
+            raise RuntimeError(f"plo_gather_wait: {(self.g.lib.plo_gather_last_error(self.g.handle) or b'').decode()}")
+        if self.outs is None:
+            return None
+        return [tensors_from_out(self.outs[r], self.dev) for r in range(self.g.world)]

@@ -545,7 +545,8 @@ def test_rccl_gather_path_with_one_rank():
     line = json.loads(lines[0])
     assert line["value"] and not line.get("gather_failed") and line["config"]["gather"].startswith("rccl")
     assert line["verify"]["gathered_equals_single_gpu_result"] is True and line["verify"]["reads"] == 30000
-    assert set(line["gather_modes"]) >= {"after_every_step"}
+    assert set(line["gather_modes"]) >= {"after_every_step", "c_abi"}  # (c_abi: the same exchange through plo_gather_* of the C ABI)
+    assert line["verify"]["c_abi_gather_equals_single_gpu_result"] is True
 
 
 def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
