@@ -10,11 +10,11 @@ python bench.py > $o/bench.json 2>/dev/null
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 bench.py --no-cpu-baseline --e2e-reads 0 --overlap-workers 0 --window-calls 0 > $o/bench_under_rocprof.json 2>/dev/null
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/kernel_stats.csv
 PMC_EXTRA="--e2e-reads 0"
-tools/pmc_pass.sh "FETCH_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
-tools/pmc_pass.sh "WRITE_SIZE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_write.csv 2>&1
-tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
-tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
-tools/pmc_pass.sh "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "${PLO_PROFILE_KERNEL:-k_lift_lanes}" $PMC_EXTRA > $o/pmc_tcc.csv 2>&1
+tools/pmc_pass.sh "FETCH_SIZE" "${PLO_PROFILE_KERNEL:-^k_lift_lanes\\(}" $PMC_EXTRA > $o/pmc_fetch.csv 2>&1
+tools/pmc_pass.sh "WRITE_SIZE" "${PLO_PROFILE_KERNEL:-^k_lift_lanes\\(}" $PMC_EXTRA > $o/pmc_write.csv 2>&1
+tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "${PLO_PROFILE_KERNEL:-^k_lift_lanes\\(}" $PMC_EXTRA > $o/pmc_sq1.csv 2>&1
+tools/pmc_pass.sh "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" "${PLO_PROFILE_KERNEL:-^k_lift_lanes\\(}" $PMC_EXTRA > $o/pmc_sq2.csv 2>&1
+tools/pmc_pass.sh "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "${PLO_PROFILE_KERNEL:-^k_lift_lanes\\(}" $PMC_EXTRA > $o/pmc_tcc.csv 2>&1
 # what FETCH_SIZE counts for scattered 16-byte loads (tools/calib_fetch.hip): the factor save_profiles.py applies
 tools/calib_fetch.sh $o/fetch_calibration.json > $o/fetch_calibration.log 2>&1
 # stress: the lane-per-item kernel over heavy items (100 k heavy items: above its threshold)
