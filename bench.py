@@ -1091,7 +1091,11 @@ def main():
         # carries the 128-byte id
         dt_abi = None
         abi_parts = None
-        if dt_sync is not None and not host_comm and n_workers == 1:
+        # (on by default with one rank -- what the one-GPU boxes of this pool can run, RCCL refuses two ranks on one device -- and with
+        # PLO_BENCH_ABI_GATHER=1: a multi-rank exchange through it has not run on hardware yet, and a collective that hangs would take the
+        # complete measurements above with it)
+        abi_on = os.environ.get("PLO_BENCH_ABI_GATHER", "1" if world == 1 else "0") == "1"
+        if dt_sync is not None and not host_comm and n_workers == 1 and abi_on:
             def abi_run():
                 ag = plo_gather.AbiGather(index.lib, dist, rank, world, dev_index)
                 last = [None]
