@@ -944,7 +944,14 @@ def main():
                          "frac_of_issue_floor_all": allc * 4.0 / (n_simds * clock_hz) * 1e3 / dom_ms,
                          "wave_instructions_per_launch": {k_: issue[k_] for k_ in ("valu", "salu", "lds", "vmem_rd", "vmem_wr", "branch") if k_ in issue},
                          "wave_instructions_per_item": allc / max(1, int(tm.n_items)), "simds": n_simds, "clock_ghz": clock_hz / 1e9,
-                         "binding_resource": "instruction issue" if fl / dom_ms > achieved / HBM_PEAK_GBS else "hbm"}
+                         # (round 6, tools/issue_model.hip: neither the vector unit -- this fraction -- nor the CU's scalar unit is saturated; a wave's
+                         # group is a dependent chain and three waves share a SIMD: DESIGN.md section 6)
+                         "binding_resource": "dependent instruction chains of the 3 waves per SIMD (vector issue floor and memory-side traffic beside it)"}
+        # what the memory side moves while the kernel runs (the counters' traffic, 128-byte lines for 20-byte homology probes included)
+        traffic_obj = {}
+        if traffic and dom_ms > 0:
+            traffic_obj = {"traffic_GBps": traffic / (dom_ms * 1e-3) / 1e9, "traffic_frac_of_peak": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic_over_algorithmic": traffic / max(1.0, algo_bytes * share)}
         result = {
             "metric": "lifted HiFi reads/sec (whole node)",
             "value": total_reads * args.steps / dt_,
@@ -977,7 +984,7 @@ def main():
                          "lane_utilisation": stats["lane_utilisation"],  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
                          "statistics_from": "one call of the counting kernel outside the timed region (plo_ctx_set_stats); the timed kernel carries no counters",
                          "lanes_ms_counting_kernel": stats["lanes_ms_counting_kernel"],
-                         "host_syncs_per_call": int(tm.host_syncs), **issue_obj},
+                         "host_syncs_per_call": int(tm.host_syncs), **issue_obj, **traffic_obj},
         }
         return result
 
