@@ -1456,7 +1456,7 @@ struct plo_ctx {
     // the rounds every wave takes by fixed slots first (PLO_LANE_STATIC; < 0: fixed slots only)
     DevBuf lane_ticket;
     uint32_t lane_epoch = 0;
-    int lane_static_rounds = 1;
+    int lane_static_rounds = 0;  // 0: by the launch's rounds (lane_ticket_arm); > 0: that many; < 0: fixed slots only
     int lane_tail_rounds = 1;  // PLO_LANE_TAIL: rounds' worth of cheap groups (no shift stage) dealt last (0: classes one to one)
     int lane_kvs = LANE_KVS;  // block-map entries staged per wave (PLO_LANE_KVS: 64 .. LANE_KVS_MAX)
     bool lane_h16 = false;    // PLO_LANE_H16=1: 16-bit regions (k_lift_lanes16; stage sets with the liftover)
@@ -1850,7 +1850,11 @@ static lane_kernel_t lane_kernel_of(const plo_ctx *c, uint32_t stages, bool sp) 
 
 // The lane kernel's ticket counters (lane_tiles_persistent): this launch's -- zero, because the context's previous launch cleared it or the
 // allocation did -- and the next launch's, which this one clears.  Without them (PLO_LANE_STATIC < 0, or no memory) the waves keep to fixed slots.
-static void lane_ticket_arm(plo_ctx *c, DevWork &wk) {
+// `groups`, `waves`: the launch's groups (an estimate will do) and waves -- the rounds of fixed slots in front of the tickets follow them unless
+// PLO_LANE_STATIC names a number: all but the last two and a half rounds.  Measured on wgs30x (10.5 rounds; EXPERIMENTS 6.2b): 1 / 4 / 8 / 9
+// fixed rounds 1.126-1.147 / 1.095-1.103 / 1.085-1.097 / 1.133-1.148 ms -- neighbouring groups on neighbouring waves of one XCD share their
+// descriptor, CIGAR and block-map lines in its L2, which the tickets give up; the last rounds are what levels the waves.
+static void lane_ticket_arm(plo_ctx *c, DevWork &wk, uint32_t groups, uint32_t waves) {
     wk.lane_kvs = (uint32_t)c->lane_kvs;
     wk.lane_tail_rounds = (uint32_t)c->lane_tail_rounds;
     wk.lane_ticket = nullptr;
@@ -1867,7 +1871,8 @@ static void lane_ticket_arm(plo_ctx *c, DevWork &wk) {
     uint32_t *const t = c->lane_ticket.as<uint32_t>();  // (the two counters on lines of their own)
     wk.lane_ticket = t + 32 * (c->lane_epoch & 1u);
     wk.lane_ticket_next = t + 32 * ((c->lane_epoch + 1u) & 1u);
-    wk.lane_static_rounds = (uint32_t)std::max(1, c->lane_static_rounds);
+    const uint32_t rounds = waves ? groups / waves : 0u;  // whole rounds of the launch
+    wk.lane_static_rounds = c->lane_static_rounds > 0 ? (uint32_t)c->lane_static_rounds : std::max(1u, rounds > 2u ? rounds - 2u : 1u);
     ++c->lane_epoch;
 }
 
@@ -2285,7 +2290,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
             wk.slab_pre = 1u;  // first slab by wave id
             wk.slab_offset = (unsigned long long)nblk * LANE_WAVES * SLAB_OPS;
             PLO_STAT_RANGE(nblk * LANE_WAVES);
-            lane_ticket_arm(c, wk);
+            lane_ticket_arm(c, wk, (n0 + gs - 1) / gs + (n1 + gs - 1) / gs, nblk * LANE_WAVES);
             hipLaunchKernelGGL(lane_kernel_of(c, stages, sp), dim3(nblk), dim3(LANE_WAVES * 64), lds, st, ix, bt, wk, stages, n0, n1, gs, c->lane_capw, (const uint32_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
         }
@@ -2676,7 +2681,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_seq, 0));
         c->seq_pending = false;
     }
-    lane_ticket_arm(c, wk);
+    lane_ticket_arm(c, wk, (c->fast_n0 + lane_gs - 1) / lane_gs + (c->fast_n1 + lane_gs - 1) / lane_gs, lane_nblk * LANE_WAVES);  // (the last batch's class counts)
     hipLaunchKernelGGL(lane_kernel_of(c, stages, false), dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
