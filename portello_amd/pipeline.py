@@ -76,7 +76,7 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                    cmdline: str = "", sparse_margin: Optional[int] = 32, device_inflate: Optional[bool] = True,
                    device_finish: bool = False, read_threads: Optional[int] = None, build_threads: Optional[int] = None,
                    write_threads: Optional[int] = None, ramp: bool = True, part: Optional[int] = None, n_parts: int = 1,
-                   out_shards: int = 1) -> PipelineStats:  # noqa: E501
+                   out_shards: int = 1, n_readers: int = 1) -> PipelineStats:  # noqa: E501
     """device_finish: the records are finished on the device -- the window's batch goes up with all its bases and qualities
     (sparse_margin is ignored), plo_finish_batch_dev (flags, bin, primary record, reverse_alignment_seq_and_qual) and
     plo_sa_segments_dev (SA text) run behind the lift kernels, their results come back and plo_records_build_finished only copies
@@ -88,6 +88,9 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     part / n_parts: this process's share of the input (plo_bam_open_range: a split by compressed offset) -- with several GPUs every rank
     runs the pipeline over its part and writes its own output shard (the reference's output order is unspecified: the shards'
     concatenation is a valid result)
+    n_readers > 1: the input (or this process's part of it) is cut again into that many parts by compressed offset (plo_bam_open_range),
+    every part with a reader and a batcher thread of its own feeding the same lift workers: with the output in shards the reader -- one
+    chain of refills: stage, inflate on the device, copy back, walk -- is what the run waits for (390 k reads/s alone on the bench sample).
     out_shards > 1: the lifted records go into that many files (`out_path` with .0, .1, ... in front of its extension), one writer thread
     each, a window's records to whichever writer is free -- the reference's output order is unspecified (docs/user_guide.md:227-230), so the
     shards' union is the output (`samtools cat` joins them).  Buffered writes into ONE file are serialised by its inode lock (9.5 GB/s
@@ -102,8 +105,14 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     write_threads = write_threads or half
     st = PipelineStats()
     ixd = index_data.to_desc()
-    rd = bam.BamReader(in_path, read_threads, device_inflate=(index.device if device_inflate else (-1 if device_inflate is False else None)),
-                       part=part, n_parts=n_parts)
+    n_readers = max(1, int(n_readers))
+    dev_arg = (index.device if device_inflate else (-1 if device_inflate is False else None))
+    if n_readers == 1:
+        rds = [bam.BamReader(in_path, read_threads, device_inflate=dev_arg, part=part, n_parts=n_parts)]
+    else:
+        p0, np0 = (part or 0), max(1, n_parts)
+        rds = [bam.BamReader(in_path, max(1, read_threads // n_readers), device_inflate=dev_arg, part=p0 * n_readers + i, n_parts=np0 * n_readers) for i in range(n_readers)]
+    rd = rds[0]
     if list(rd.ref_names) != list(contig_names):
         raise ValueError("the read->contig BAM's @SQ list differs from the contig names of the index")
     out_shards = max(1, int(out_shards))
@@ -143,9 +152,11 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
 
     # the input side is two stages: BGZF inflate + record walk (read_window), then the window's batch arrays (batch_desc: CIGARs,
     # bases, qualities gathered into the plo_batch_in layout) -- about half of the reader's time each
-    q_win: "queue.Queue" = queue.Queue(maxsize=2)
+    q_wins = [queue.Queue(maxsize=2) for _ in rds]
+    chains_left = [len(rds)]  # batcher chains still running: the last one posts the lift workers' sentinels and starts the readers' teardown
 
-    def reader():
+    def reader(ci):
+        rd, q_win = rds[ci], q_wins[ci]
         try:
             # the first windows are small and double up to window_reads: the stages behind the reader start after milliseconds instead of
             # after a whole window's decode -- a five-stage pipeline over a handful of full windows is mostly ramp otherwise
@@ -157,16 +168,18 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                 win = rd.read_window(size)
                 if win is None:
                     break
-                st.read_s += time.perf_counter() - t
+                with lock:
+                    st.read_s += time.perf_counter() - t
                 put(q_win, win)
         except BaseException as e:  # noqa: BLE001
-            st.errors.append(f"reader: {e!r}")
+            st.errors.append(f"reader {ci}: {e!r}")
             abort.set()
         finally:
-            st.stage_done_s["reader"] = time.perf_counter() - t0
+            st.stage_done_s["reader" if len(rds) == 1 else f"reader {ci}"] = time.perf_counter() - t0
             put(q_win, None)
 
-    def batcher():
+    def batcher(ci):
+        q_win = q_wins[ci]
         try:
             while True:
                 win = get(q_win)
@@ -179,18 +192,23 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
                     desc = win.batch_desc(with_finish=True)  # (plo_batch_in, plo_finish_in), dense bases
                 else:
                     desc = win.batch_desc(sparse_margin=sparse_margin, index_desc=ixd if sparse_margin is not None else None)
-                st.batch_s += time.perf_counter() - t
+                with lock:
+                    st.batch_s += time.perf_counter() - t
                 put(q_in, (win, desc))
         except BaseException as e:  # noqa: BLE001
-            st.errors.append(f"batcher: {e!r}")
+            st.errors.append(f"batcher {ci}: {e!r}")
             abort.set()
         finally:
-            st.stage_done_s["batcher"] = time.perf_counter() - t0
-            for _ in range(n_workers):
-                put(q_in, None)
-            # the reader's teardown (its page-locked stream buffer and device buffers: ~0.1 s for a 4 GB input) runs beside the last
-            # windows' lifting and writing: no window needs the reader once its batch is built
-            closer.start()
+            st.stage_done_s["batcher" if len(rds) == 1 else f"batcher {ci}"] = time.perf_counter() - t0
+            with lock:
+                chains_left[0] -= 1
+                last = chains_left[0] == 0
+            if last:
+                for _ in range(n_workers):
+                    put(q_in, None)
+                # the readers' teardown (page-locked stream buffers and device buffers: ~0.1 s for a 4 GB input) runs beside the last
+                # windows' lifting and writing: no window needs its reader once its batch is built
+                closer.start()
 
     def lifter(k):
         eng = None
@@ -271,7 +289,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
 
     def close_reader():
         t = time.perf_counter()
-        rd.close()
+        for r_ in rds:
+            r_.close()
         st.stage_done_s["reader closed"] = time.perf_counter() - t0
         st.stage_done_s["reader close took"] = time.perf_counter() - t
 
@@ -303,7 +322,8 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
         st.stage_done_s["writer" if out_shards == 1 else f"writer {k}"] = time.perf_counter() - t0
 
     st.stage_done_s["set up"] = time.perf_counter() - t0
-    front = [threading.Thread(target=reader), threading.Thread(target=batcher)] + [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)]
+    front = ([threading.Thread(target=reader, args=(ci,)) for ci in range(len(rds))] + [threading.Thread(target=batcher, args=(ci,)) for ci in range(len(rds))] +
+             [threading.Thread(target=lifter, args=(k,)) for k in range(n_workers)])
     writers = [threading.Thread(target=writer, args=(k,)) for k in range(out_shards)]
     for t in front + writers:
         t.start()
@@ -318,10 +338,11 @@ def run_bam_to_bam(in_path: str, out_path: str, index: api.Index, index_data: ab
     st.stage_done_s["output closed"] = time.perf_counter() - t0
     if un is not None:
         un.close()
-    if closer.ident is not None:  # (started by the batcher)
+    if closer.ident is not None:  # (started by the last batcher)
         closer.join()
     else:
-        rd.close()
+        for r_ in rds:
+            r_.close()
     st.seconds = time.perf_counter() - t0
     st.stage_done_s["all closed"] = st.seconds
     if st.errors:

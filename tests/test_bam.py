@@ -697,7 +697,7 @@ def test_bam_to_bam_into_output_shards(tmp_path):
     index = api.Index(w.index_data_device())
     cn, rn = meta["contig_names"], bamsynth.ref_names(w)
     st = pipeline.run_bam_to_bam(inp, outp, index, ixd, cn, rn, [int(s.numel()) for s in w.chrom_seq], window_reads=1500, n_workers=2,
-                                 io_threads=8, unassembled_path=unp, device_finish=True, out_shards=3)
+                                 io_threads=8, unassembled_path=unp, device_finish=True, out_shards=3, n_readers=2)  # (two reader chains: the file cut in two)
     assert st.reads == w.n_reads and len(st.out_paths) == 3 and all(os.path.exists(p_) and os.path.getsize(p_) > 1000 for p_ in st.out_paths)
     assert not os.path.exists(outp)
     v = expect.verify_lifted_bam(inp, st.out_paths, ixd, cn, rn, window=1000, every=1, threads=8, unassembled_bam=unp)
