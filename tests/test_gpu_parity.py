@@ -549,6 +549,43 @@ def test_rccl_gather_path_with_one_rank():
     assert line["verify"]["c_abi_gather_equals_single_gpu_result"] is True
 
 
+def test_c_abi_gather_with_one_rank(oracle):
+    """plo_gather_unique_id / _create / _records / _wait / _destroy through ctypes (gather.AbiGather), world size 1 -- what this pool's boxes
+    allow: the library opens RCCL by name and creates its own communicator, the size all-gather runs, the root's part is its own arrays; the
+    gathered set equals the engine's result and the oracle's.  Wrong arguments are refused."""
+    import ctypes as C
+
+    import torch
+
+    from portello_amd import devbatch, gather
+
+    w = synth.generate(synth.config("tiny", n_reads=400, seed=207, split_read_frac=0.2), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    lib = eng_ix.lib
+    assert lib.plo_ctx_device(eng.handle) == 0 and lib.plo_ctx_stream(eng.handle)
+    ag = gather.AbiGather(lib, None, 0, 1, 0)
+    for _ in range(2):  # (the gather object is reused from batch to batch)
+        out = eng.liftover_batch_dev(devbatch.DeviceBatch.from_workload(w).desc())
+        eng.compact_output_dev(out)
+        parts = ag.gather(eng, out, dev).wait()
+        assert len(parts) == 1
+        got = gather.to_result(gather.combine(parts))
+        _assert_same(devbatch.download(eng, out), got, "c_abi_gather")
+    _assert_same(oracle.liftover_batch(w.index_data(), w.batch_data(), abi.STAGES_ALL, 2), got, "c_abi_gather_vs_oracle")
+    # refused: a root outside the communicator, no place for the gathered records on the root
+    outs = (abi.PloBatchOut * 1)()
+    assert lib.plo_gather_records(ag.handle, eng.handle, C.byref(out), 3, outs) == abi.PLO_ERR_INVALID_ARG
+    assert lib.plo_gather_records(ag.handle, eng.handle, C.byref(out), 0, None) == abi.PLO_ERR_INVALID_ARG
+    ident = (C.c_uint8 * 128)()
+    h = C.c_void_p()
+    assert lib.plo_gather_create(ident, 2, 2, 0, C.byref(h)) == abi.PLO_ERR_INVALID_ARG  # rank outside the world
+    ag.close()
+    eng.close()
+    eng_ix.close()
+
+
 def test_zero_copy_views_of_device_outputs_for_the_gather(oracle):
     """bench.py's N > 1 path wraps the engine's device outputs as torch tensors (no copy) before the RCCL gather"""
     import torch
