@@ -330,10 +330,14 @@ def test_full_size_wgs30x(oracle):
     _full_size("wgs30x", oracle, 250, 1000, threads=os.cpu_count() or 8)
 
 
-def test_every_item_of_wgs30x(oracle):
+@pytest.mark.parametrize("h16", ["0", "1"])
+def test_every_item_of_wgs30x(oracle, h16, monkeypatch):
     """the headline configuration once in full -- every one of the ~2.07 M items of BASELINE configs[2] compared with the
-    oracle (blocks of 10 000 reads tiling the whole read set, all host cores; the other full-size test and the bench keep their eighth)"""
+    oracle (blocks of 10 000 reads tiling the whole read set, all host cores; the other full-size test and the bench keep their eighth).
+    h16 = 1: the same through the 16-bit-region experiment kernel (k_lift_lanes16)."""
     import torch
+
+    monkeypatch.setenv("PLO_LANE_H16", h16)
 
     import fullsize
     from portello_amd import devbatch
@@ -347,7 +351,7 @@ def test_every_item_of_wgs30x(oracle):
     assert int(eng.timing().host_syncs) == 1
     blocks = [(lo, min(lo + 10_000, w.n_reads)) for lo in range(0, w.n_reads, 10_000)]
     n_cmp, n_flip, n_contigs = fullsize.check_strided_parity(w, res, oracle, threads=os.cpu_count() or 8, blocks=blocks)
-    _dump("every_item_wgs30x.json", {"reads": w.n_reads, "items": int(res.n_items), "items_compared_with_oracle": n_cmp, "of_them_flipped": n_flip,
+    _dump("every_item_wgs30x.json" if h16 == "0" else "every_item_wgs30x_16bit_regions.json", {"reads": w.n_reads, "retry_items": int(eng.timing().n_retry_items), "items": int(res.n_items), "items_compared_with_oracle": n_cmp, "of_them_flipped": n_flip,
                                      "contigs_in_sample": n_contigs, "blocks": len(blocks)})
     assert n_cmp == res.n_items and n_flip > 0
     eng.close()
