@@ -53,7 +53,18 @@ PLO_DEV void pipe_idle(int streak) {
     if (streak < 3) __builtin_amdgcn_s_sleep(PLO_PIPE_SLEEP);
     else __builtin_amdgcn_s_sleep(8 * PLO_PIPE_SLEEP);
 }
-PLO_DEV void pipe_order() { asm volatile("" ::: "memory"); }  // LDS operations of a wave execute in order: only the compiler may not move them
+// Between a ring's words and the count that publishes them (producer), and between reading a count and the words it covers (consumer).
+// DS operations of a wave execute in order and a workgroup shares one CU's LDS, so what is needed is that the COMPILER keeps the order; the
+// workgroup-scope fences say so inside the HIP memory model -- on gfx950, outside threadgroup-split mode, they lower to a wait
+// for the wave's outstanding LDS operations and nothing else.
+PLO_DEV void pipe_order() {
+#ifdef PLO_PIPE_ASM_ORDER
+    asm volatile("" ::: "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
 #endif
 
 constexpr uint32_t PIPE_PAIR = 0x4Fu;  // (a marker, see below) an indel cluster of more than one op begins behind this word
