@@ -553,6 +553,35 @@ def test_rccl_gather_path_with_one_rank():
     assert line["verify"]["c_abi_gather_equals_single_gpu_result"] is True
 
 
+def test_empty_device_batch_through_the_device_path_and_the_gather():
+    """a rank whose share of a window-pipeline batch is empty (fewer windows than batches) still takes part in the exchange: an empty device
+    batch goes through plo_liftover_batch_dev / plo_compact_output_dev and gathers as zero records"""
+    import torch
+
+    from portello_amd import devbatch, gather
+
+    w = synth.generate(synth.config("tiny", n_reads=50, seed=208), device="cuda")
+    eng_ix = api.Index(w.index_data_device())
+    eng = api.Engine(eng_ix, stream=torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    full = eng.liftover_batch_dev(devbatch.DeviceBatch.from_workload(w).desc())
+    assert int(full.n_items) > 0
+    db = devbatch.DeviceBatch.from_read_ranges(w, [])
+    assert db.n_reads == 0
+    out = eng.liftover_batch_dev(db.desc())
+    eng.compact_output_dev(out)
+    eng.sync()
+    assert int(out.n_items) == 0 and int(out.n_cigar) == 0
+    t = gather.tensors_from_out(out, dev)
+    assert all(int(v.numel()) == 0 for v in t.values())
+    ag = gather.AbiGather(eng_ix.lib, None, 0, 1, 0)
+    parts = ag.gather(eng, out, dev).wait()
+    assert len(parts) == 1 and int(parts[0]["item_seg"].numel()) == 0
+    ag.close()
+    eng.close()
+    eng_ix.close()
+
+
 def test_c_abi_gather_with_one_rank(oracle):
     """plo_gather_unique_id / _create / _records / _wait / _destroy through ctypes (gather.AbiGather), world size 1 -- what this pool's boxes
     allow: the library opens RCCL by name and creates its own communicator, the size all-gather runs, the root's part is its own arrays; the
