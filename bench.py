@@ -1292,12 +1292,13 @@ def main():
                     got_all = plo_gather.combine(last_gather[0], seg_maps)
                     got_all = {k_: v.clone() for k_, v in got_all.items()}
                     whole_db = devbatch.DeviceBatch.from_workload(w)
+                    eng.liftover_batch_dev(whole_db.desc())  # (sizes the context's buffers for the whole set: its events would span the allocations)
                     whole_out = eng.liftover_batch_dev(whole_db.desc())
+                    whole_ms = float(eng.timing().total_ms)  # device time of the WHOLE read set on this one GPU
                     eng.compact_output_dev(whole_out)
                     eng.sync()
                     whole = {k_: v.to(comm_dev) for k_, v in plo_gather.tensors_from_out(whole_out, dev).items()}
                     same = plo_gather.same_records(got_all, whole)
-                    whole_ms = float(eng.timing().total_ms)  # device time of the WHOLE read set on this one GPU
                     verify = {"gathered_equals_single_gpu_result": bool(same), "items": int(whole["item_seg"].numel()),
                               "reads": int(w.n_reads), "single_gpu_device_ms": whole_ms,
                               "this_rank": {"reads": int(my_reads), "ms_per_step_no_gather": dt_ng / args.steps * 1e3,
