@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLO_API_VERSION 4 /* 4: plo_timing starts with struct_size (the callee fills no more than the caller's struct holds) */
+#define PLO_API_VERSION 5 /* 4: plo_timing starts with struct_size (the callee fills no more than the caller's struct holds); 5: plo_gather_*, plo_ctx_set_stats (plo_timing::algo_bytes / lane_utilisation of light items only on request), plo_ctx_stream / plo_ctx_device */
 
 typedef enum plo_status {
     PLO_OK = 0,
