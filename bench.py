@@ -1027,10 +1027,20 @@ def main():
 
         gather_error = [None]
 
-        def guarded(fn):
+        def supp_bail():
+            # a SUPPLEMENTARY gather mode hung: the complete measurement made so far goes out as it is (marked), the process cannot go on
+            log("[bench] a supplementary gather mode did not finish in time")
+            if rank == 0:
+                r_ = dict(pending_print[0])
+                r_["supplementary_timed_out"] = True
+                r_["degraded"] = True
+                print(json.dumps(r_), flush=True)
+            os._exit(4)
+
+        def guarded(fn, fatal=True):
             if gather_error[0] is not None:  # (after an RCCL error the next collective would only hang until the watchdog fires)
                 return None
-            wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "150")), gather_bail)
+            wd = threading.Timer(float(os.environ.get("PLO_BENCH_GATHER_TIMEOUT", "150")), gather_bail if fatal else supp_bail)
             wd.daemon = True
             wd.start()
             try:
@@ -1119,7 +1129,7 @@ def main():
                 ag.close()
                 return d_, parts_
 
-            got_abi = guarded(abi_run)
+            got_abi = guarded(abi_run, fatal=False)
             if got_abi is not None:
                 dt_abi, abi_parts = got_abi
             else:
@@ -1184,9 +1194,11 @@ def main():
                 engs[0].sync()
                 return d_, parts_
 
-            got_pipe = guarded(pipe_run_outer)
+            got_pipe = guarded(pipe_run_outer, fatal=False)
             if got_pipe is not None:
                 dt_pipe, pipe_parts = got_pipe
+            else:
+                gather_error[0] = None  # (supplementary: what follows still runs)
         gather_modes = {}  # reads/s of the whole job with the records of every step on rank 0 when the clock stops
         if dt_sync is not None:
             gather_modes["after_every_step"] = {"value": total_reads * args.steps / dt_sync, "unit": "reads/s", "ms_per_step": dt_sync / args.steps * 1e3}
