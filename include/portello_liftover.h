@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLO_API_VERSION 5 /* 4: plo_timing starts with struct_size (the callee fills no more than the caller's struct holds); 5: plo_gather_*, plo_ctx_set_stats (plo_timing::algo_bytes / lane_utilisation of light items only on request), plo_ctx_stream / plo_ctx_device */
+#define PLO_API_VERSION 6 /* 4: plo_timing starts with struct_size (the callee fills no more than the caller's struct holds); 5: plo_gather_*, plo_ctx_set_stats (plo_timing::algo_bytes / lane_utilisation of light items only on request), plo_ctx_stream / plo_ctx_device; 6: plo_ctx_set_phase_events */
 
 typedef enum plo_status {
     PLO_OK = 0,
@@ -253,6 +253,11 @@ void plo_ctx_destroy(plo_ctx *ctx);
 /* on != 0: the light-item kernel of this context's later calls counts plo_timing::algo_bytes and lane_utilisation (an instantiation with
    the counters in its loops, a few per cent slower); default: off, or what the environment's PLO_LANE_STATS says at plo_ctx_create */
 plo_status plo_ctx_set_stats(plo_ctx *ctx, int on);
+/* on == 0: the one-round-trip calls of this context (plo_liftover_batch_dev on a context whose last batch had light items only) record no
+   HIP events between their phases -- every record is a bubble of ~6 us on the stream, 5 % of a reference-sized window's call -- and
+   plo_ctx_timing then reports the counts of such a call but no times (enumerate_ms, lanes_ms, total_ms = 0).  A production caller that
+   never asks for the times switches them off; default: on (or what the environment's PLO_PHASE_EVENTS says at plo_ctx_create). */
+plo_status plo_ctx_set_phase_events(plo_ctx *ctx, int on);
 
 /* Host buffers in, host (pinned, context-owned) buffers out; synchronous. */
 plo_status plo_liftover_batch(plo_ctx *ctx, const plo_batch_in *in, uint32_t stages, plo_batch_out *out);

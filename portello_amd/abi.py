@@ -112,7 +112,7 @@ class PloBatchOut(C.Structure):
     ]
 
 
-PLO_API_VERSION = 5  # include/portello_liftover.h
+PLO_API_VERSION = 6  # include/portello_liftover.h
 
 
 class PloTiming(C.Structure):

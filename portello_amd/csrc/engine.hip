@@ -796,6 +796,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *in,
     }
 }
 
+// (Round 6 also tried ONE WORKGROUP for a window's ~52 k values -- 16 waves, every wave its stretch as coalesced rows, one exchange through LDS:
+// 0.239-0.242 ms per 50 k-read call against 0.236-0.239 with the three launches, EXPERIMENTS 6.12; removed.  Back-to-back launches of small
+// kernels overlap their dispatch; a command is only dear where the stream has to drain: event records, the copy back.)
 // The exclusive scan in ONE launch (decoupled look-back), an experiment of the one-round-trip path that stays switched off (PLO_SCAN_CHAIN=1):
 // two launches fewer, but the chain of look-backs costs more than their ~5 us each -- wgs30x 2 M reads (1 006 tiles): enumerate pass 0.273 ms
 // against 0.261, step 1.512 against 1.490 ms; 50 k-read window (25 tiles): 0.249-0.258 against 0.250 ms (tools/exp_scan.sh).
@@ -1175,6 +1178,54 @@ __global__ __launch_bounds__(256) void k_sum_stats(unsigned long long *ws, uint3
     }
 }
 
+// The one-round-trip path's last launch: k_lift_retry and k_sum_stats in one (a command of any size costs ~5 us on the stream, and a
+// reference-sized window's call is made of a dozen of them).  Every wave lifts its share of the retry list as k_lift_retry does, then adds
+// what it counted straight into the batch counters (nothing to add for the common wave without a retry item); the first SUM_BLOCKS waves
+// also sum (and clear) the statistic slots the light-item kernel's waves left -- complete by stream order, `n_lane_slots` of them from slot 0.
+constexpr uint32_t SUM_BLOCKS = 32;
+__global__ __launch_bounds__(64) void k_lift_retry_sum(DevIndex ix, DevBatch bt, DevWork wk, uint32_t stages, int big_thresh, int cap, uint32_t n_lane_slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileMem m = carve_tile_mem(smem, cap);
+    WaveCtx ctx;
+    Coop<1> co;
+    const uint32_t n_retry = (uint32_t)wk.counters[CNT_NRETRY];
+    for (uint32_t r = blockIdx.x * RETRY_PER; r < n_retry; r += gridDim.x * RETRY_PER) {
+        uint32_t left = n_retry - r;
+        lift_tile<1, false>(co, ix, bt, wk, stages, r, (int)(left < RETRY_PER ? left : RETRY_PER), m, wk.retry_list, LEVEL_RETRY, big_thresh, ctx);
+        wv::sync();
+    }
+    // this wave's own counts, per lane as wave_ctx_flush reads them; the slots of the light-item kernel on top (lane l of wave b: slots
+    // b + SUM_BLOCKS (l + 64 j))
+    unsigned long long a[5] = {ctx.algo_bytes, ctx.in_ops, ctx.out_ops, 0ull, 0ull};
+    const uint32_t lane = (uint32_t)wv::lane();
+    if (lane == 0) {
+        a[3] = ctx.u_act;
+        a[4] = ctx.u_trips;
+    }
+    if (blockIdx.x < SUM_BLOCKS) {
+        for (uint32_t i = blockIdx.x + SUM_BLOCKS * lane; i < n_lane_slots; i += SUM_BLOCKS * 64u) {
+            unsigned long long *w = wk.wave_stats + (size_t)i * STAT_WORDS;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                a[k] += w[k];
+                w[k] = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) a[k] += (unsigned long long)__shfl_xor((long long)a[k], d, 64);
+    }
+    if (lane == 0) {
+        if (a[0]) atomicAdd(&wk.counters[CNT_ALGO_BYTES], a[0]);
+        if (a[1]) atomicAdd(&wk.counters[CNT_IN_OPS], a[1]);
+        if (a[2]) atomicAdd(&wk.counters[CNT_OUT_OPS], a[2]);
+        if (a[3]) atomicAdd(&wk.counters[CNT_LANE_ACT], a[3]);
+        if (a[4]) atomicAdd(&wk.counters[CNT_LANE_TRIPS], a[4]);
+    }
+}
+
 // ---- record finishing (finish_core.hpp) ----------------------------------------------------------------------------------
 __global__ void k_finish_items(DevBatch bt, DevWork wk, DevFinish f) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1422,6 +1473,9 @@ struct plo_ctx {
     DevBuf fast_blk;  // liftover_fast: class totals, validation flags and batch counters in one block (one fill, one copy back)
     bool fast_timing = false;  // the last batch took liftover_fast: events 0, 1, 4 only
     bool scan_chain = false;   // liftover_fast: the segments' item offsets by k_scan_chain (PLO_SCAN_CHAIN=1; measured slower than the three scan launches)
+    bool fast_fuse = true;     // liftover_fast: the counters' sum inside the retry launch (k_lift_retry_sum; PLO_FAST_FUSE=0: k_lift_retry + k_sum_stats)
+    bool phase_events = true;  // liftover_fast records events 0, 1, 4 around its phases (plo_ctx_set_phase_events; every record is a ~5 us bubble on the stream)
+    bool fast_no_events = false;  // the last batch took liftover_fast without them: plo_ctx_timing reports no times for it
     // host staging for plo_liftover_batch
     DevBuf i_read_rev, i_read_len, i_read_off, i_seq, i_seg_read, i_seg_contig, i_seg_pos, i_seg_fwd, i_seg_coff, i_cigar,
         i_item_seg, i_item_cseg;
@@ -1470,6 +1524,8 @@ struct plo_ctx {
     // class counts, whether it had heavy items (a context that sees windows of one shape lifts them without asking the device for counts)
     bool fast = true;
     uint32_t fast_ns_cap = 0, fast_item_cap = 0, fast_n0 = 0, fast_n1 = 0;
+    uint32_t fast_ref_items = 0, fast_ref_ns = 0;  // items and segments of the last careful batch: the one-round-trip path's launch bound
+    bool fast_launch_bound = true;                 // (PLO_FAST_LAUNCH_BOUND=0: grids by the arrays' capacity whatever the batch's size)
     uint32_t item_cap_now = 0;   // items the per-item arrays hold
     uint32_t fast_extra_syncs = 0;  // a fast attempt that fell back: its round trip counts in the call's host_syncs
     bool fast_light_only = false;
@@ -1738,6 +1794,9 @@ plo_status plo_ctx_create(const plo_index *ix, void *hip_stream, plo_ctx **out) 
     if (const char *e = getenv("PLO_LANE_STREAM_RATIO")) c->lane_stream_ratio = std::max(1, atoi(e));
     if (const char *e = getenv("PLO_FAST_PATH")) c->fast = atoi(e) != 0;
     if (const char *e = getenv("PLO_SCAN_CHAIN")) c->scan_chain = atoi(e) != 0;
+    if (const char *e = getenv("PLO_FAST_LAUNCH_BOUND")) c->fast_launch_bound = atoi(e) != 0;
+    if (const char *e = getenv("PLO_FAST_FUSE")) c->fast_fuse = atoi(e) != 0;
+    if (const char *e = getenv("PLO_PHASE_EVENTS")) c->phase_events = atoi(e) != 0;
     if (const char *e = getenv("PLO_LANE_CAPW")) c->lane_capw = std::min(40000, std::max(64, atoi(e))) & ~3;
     if (c->lane_max_w + LANE_SLACK > c->lane_capw) c->lane_max_w = c->lane_capw - LANE_SLACK;
     if (const char *e = getenv("PLO_TILE_WAVES")) c->tile_waves = std::min(TILE_WAVES, std::max(1, atoi(e)));
@@ -1784,6 +1843,12 @@ int plo_ctx_device(plo_ctx *c) { return c ? c->ix->device : -1; }
 plo_status plo_ctx_set_stats(plo_ctx *c, int on) {
     if (!c) return PLO_ERR_INVALID_ARG;
     c->lane_stats = on != 0;
+    return PLO_OK;
+}
+
+plo_status plo_ctx_set_phase_events(plo_ctx *c, int on) {
+    if (!c) return PLO_ERR_INVALID_ARG;
+    c->phase_events = on != 0;
     return PLO_OK;
 }
 
@@ -1955,6 +2020,7 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     hipStream_t st = c->stream;
     memset(&c->timing, 0, sizeof(c->timing));
     c->fast_timing = false;
+    c->fast_no_events = false;
     uint32_t n_syncs = 0;  // host round trips of the call
     c->ev_big = false;
     c->ev_mid = false;
@@ -2566,6 +2632,8 @@ plo_status plo_liftover_batch_dev(plo_ctx *c, const plo_batch_in *in, uint32_t s
     c->fast_ns_cap = ns;
     // (PLO_FAST_CAP_EXACT=1, tests: the last batch's item count, so that a window with a few items more exercises the VERR_CAP fallback)
     c->fast_item_cap = getenv("PLO_FAST_CAP_EXACT") ? n_items : std::max(n_items, c->item_cap_now);
+    c->fast_ref_items = n_items;
+    c->fast_ref_ns = ns;
     c->fast_n0 = h_cls[0];
     c->fast_n1 = h_cls[1];
     // (items the lane kernel handed to the retry kernel are fine: the fast path runs that kernel too; items IT hands on are not)
@@ -2606,7 +2674,16 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     fallback = false;
     const DevIndex &ix = c->ix->d;
     hipStream_t st = c->stream;
-    const uint32_t ns = in->n_segs, cap = c->fast_item_cap;
+    const uint32_t ns = in->n_segs;
+    // The item capacity the kernels are launched with: what the arrays hold -- but no more than this batch can plausibly need (a quarter more
+    // items per segment than the last careful batch had, + 1 024).  A context that has once lifted a 2 M-read batch would otherwise run every
+    // 50 k-read window with grids for 2 M items: surplus workgroups leave at once, yet a thousand of them per class kernel and a lane grid of
+    // every wave slot cost the call ~20 us (tools/ab_window.py).  A batch with more items raises VERR_CAP like one beyond the arrays.
+    uint32_t cap = c->fast_item_cap;
+    if (c->fast_launch_bound && c->fast_ref_ns) {
+        const unsigned long long per = ((unsigned long long)ns * c->fast_ref_items + c->fast_ref_ns - 1) / c->fast_ref_ns;
+        cap = (uint32_t)std::min<unsigned long long>(cap, per + per / 4 + 1024ull);
+    }
     // Everything the kernels of this path count in, one block: cleared by ONE fill and read back by ONE copy (a launch of any size costs
     // ~5 us on the stream: three fills and four copies were a quarter of a 50 k-read call's kernels, tools/trace_window.sh)
     //   [0, 256) the class totals ([6] = the item count) and the lane kernel's group counter, [256, 272) the validation flags,
@@ -2623,7 +2700,8 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     uint8_t *const fb = c->fast_blk.as<uint8_t>();
     uint32_t *const misc_d = (uint32_t *)fb, *const verr_d = (uint32_t *)(fb + FB_VERR);
     unsigned long long *const counters_d = (unsigned long long *)(fb + FB_COUNTERS);
-    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    const bool ev_on = c->phase_events;  // (plo_ctx_set_phase_events(ctx, 0): no event records -- two bubbles of ~6 us fewer on the stream, no phase times)
+    if (ev_on) HIP_TRY(c, hipEventRecord(c->ev[0], st));
     HIP_TRY(c, hipMemsetAsync(fb, 0, fb_bytes, st));
     hipLaunchKernelGGL(k_seg_count, dim3((unsigned)(((unsigned long long)ns * SEG_LANES + 255) / 256)), dim3(256), 0, st, ix, bt, c->seg_cnt.as<uint32_t>(),
                        c->seg_reflen.as<int>(), c->seg_readlen.as<uint32_t>(), c->seg_nm.as<uint32_t>(), verr_d);
@@ -2647,7 +2725,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     hipLaunchKernelGGL(k_permute2_s, dim3(cls_nb), dim3(CLS_THREADS), 0, st, (const uint32_t *)c->item_cls.as<uint32_t>(), (const uint32_t *)c->item_nin.as<uint32_t>(),
                        (const uint32_t *)c->cls_partial.as<uint32_t>(), misc_d, cap, cls_nb, c->perm.as<uint32_t>(), c->nin_p.as<uint32_t>(),
                        c->adaptive ? (uint32_t)((WHIST_BINS - 1) * WHIST_STEP) : 0xffffffffu, n_dev);
-    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    if (ev_on) HIP_TRY(c, hipEventRecord(c->ev[1], st));
     // launch geometry from the last batch's class counts (a window of the same shape has the same): group size, persistent grid
     uint32_t lane_gs = 64, lane_nblk = 0;
     const size_t lane_lds = (size_t)(c->lane_capw + 2 * c->lane_kvs) * 4 * LANE_WAVES;
@@ -2684,17 +2762,27 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     lane_ticket_arm(c, wk, (c->fast_n0 + lane_gs - 1) / lane_gs + (c->fast_n1 + lane_gs - 1) / lane_gs, lane_nblk * LANE_WAVES);  // (the last batch's class counts)
     hipLaunchKernelGGL(lane_kernel_of(c, stages, false), dim3(lane_nblk), dim3(LANE_WAVES * 64), lane_lds, st, ix, bt, wk, stages, 0u, 0u, lane_gs, c->lane_capw, totals_dev);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
+    if (ev_on) HIP_TRY(c, hipEventRecord(c->ev[4], st));  // (the last event of this path: every record is a ~5 us bubble on the stream; retry and counters are not timed)
     {
         const int retry_cap = 320;
         const uint32_t lds = (uint32_t)((tile_mem_bytes(retry_cap) + 15) & ~(size_t)15), nw = (uint32_t)c->n_cus * 2u;
-        wk.stat_base = stat_used;
-        stat_used += nw;
-        hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, 256, retry_cap);
-        HIP_TRY(c, hipGetLastError());
+#ifdef PLO_PHASE_TIMING
+        const bool fuse = false;  // (timing builds: the waves' clocks travel in their slots, wave_ctx_flush)
+#else
+        const bool fuse = c->fast_fuse;
+#endif
+        if (fuse) {  // the counters' sum rides in the retry launch: its waves add their own counts, the first of them the light-item kernel's slots
+            hipLaunchKernelGGL(k_lift_retry_sum, dim3(std::max(nw, SUM_BLOCKS)), dim3(64), lds, st, ix, bt, wk, stages, 256, retry_cap, stat_used);
+            HIP_TRY(c, hipGetLastError());
+        } else {
+            wk.stat_base = stat_used;
+            stat_used += nw;
+            hipLaunchKernelGGL(k_lift_retry, dim3(nw), dim3(64), lds, st, ix, bt, wk, stages, 0xffffffffu, 256, retry_cap);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(k_sum_stats, dim3(std::min<uint32_t>((stat_used + 255) / 256, 16u)), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), stat_used,
+                               counters_d);
+        }
     }
-    hipLaunchKernelGGL(k_sum_stats, dim3(std::min<uint32_t>((stat_used + 255) / 256, 16u)), dim3(256), 0, st, c->wave_stats.as<unsigned long long>(), stat_used,
-                       counters_d);
     // the one look: class totals and item count, validation flags, counters
     uint8_t *const hb = c->h_counters.as<uint8_t>();
     HIP_TRY(c, hipMemcpyAsync(hb, fb, FB_BACK, hipMemcpyDeviceToHost, st));
@@ -2731,6 +2819,7 @@ static plo_status liftover_fast(plo_ctx *c, const plo_batch_in *in, uint32_t sta
     c->timing.lane_utilisation = hc[CNT_LANE_TRIPS] ? (float)((double)hc[CNT_LANE_ACT] / (64.0 * (double)hc[CNT_LANE_TRIPS])) : 0.0f;
     c->timing.host_syncs = 1;
     c->fast_timing = true;
+    c->fast_no_events = !ev_on;
     for (int k = 0; k < 12; ++k) c->phase_cycles[k] = hc[CNT_PHASE0 + k];
     c->fast_n0 = n0;
     c->fast_n1 = n1;
@@ -3115,8 +3204,10 @@ plo_status plo_ctx_timing(plo_ctx *c, plo_timing *t) {
     if (!c || !t) return PLO_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float a = 0, l = 0, b = 0, r = 0, g = 0, md = 0;
-    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&l, c->ev[1], c->ev[4]);
+    if (!c->fast_no_events) {  // (a one-round-trip call on a context with plo_ctx_set_phase_events(ctx, 0) recorded nothing: counts only)
+        (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&l, c->ev[1], c->ev[4]);
+    }
     if (!c->fast_timing) {  // (liftover_fast records events 0, 1 and 4 only: its retry launch and the counters' sum are not timed)
         (void)hipEventElapsedTime(&b, c->ev[4], c->ev[2]);
         (void)hipEventElapsedTime(&r, c->ev[2], c->ev[5]);

@@ -905,3 +905,49 @@ def test_one_host_round_trip_path(oracle, monkeypatch):
     index_s.close()
     eng.close()
     index.close()
+
+
+def test_one_round_trip_path_with_fewer_commands(oracle, monkeypatch):
+    """the one-round-trip path with the counters summed inside the retry launch (k_lift_retry_sum), grids bounded by what
+    the batch can need instead of what the arrays hold and -- on request -- no event records between its phases (plo_ctx_set_phase_events)
+    gives the same results, the same counts (in / out ops, algorithmic bytes, lane utilisation of the counting kernel) and the same single
+    round trip as the path with k_lift_retry + k_sum_stats and capacity-sized grids"""
+    import torch
+
+    from portello_amd import devbatch
+
+    w = synth.generate(synth.config("chr20", n_reads=30_000), device="cuda")
+    ix = w.index_data()
+    index = api.Index(w.index_data_device())
+    parts = [(0, 30000), (0, 30000), (0, 8000), (9000, 13000), (9000, 9900)]  # (windows far smaller than the arrays: the launch bound at work)
+    refs = [oracle.liftover_batch(ix, w.batch_data(lo, hi), abi.STAGES_ALL, os.cpu_count() or 8).canonical() for lo, hi in parts]
+    variants = [("old", {"PLO_FAST_FUSE": "0", "PLO_FAST_LAUNCH_BOUND": "0"}, True), ("new", {}, True), ("new_no_events", {}, False),
+                ("bound_only", {"PLO_FAST_FUSE": "0"}, True), ("fuse_only", {"PLO_FAST_LAUNCH_BOUND": "0"}, False)]
+    counts = {}
+    for name, env, events in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = api.Engine(index, stream=torch.cuda.current_stream().cuda_stream).set_stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        if not events:
+            eng.set_phase_events(False)
+        rows = []
+        for (lo, hi), ref in zip(parts, refs):
+            db = devbatch.DeviceBatch.from_workload(w, lo, hi)
+            torch.cuda.synchronize()
+            got = devbatch.run_and_download(eng, db)
+            t = eng.timing()
+            assert got.canonical() == ref, f"{name}: reads [{lo}, {hi})"
+            rows.append((int(t.n_items), int(t.n_in_ops), int(t.n_out_ops), int(t.algo_bytes), int(t.n_retry_items), int(t.host_syncs), round(float(t.lane_utilisation), 5)))
+            if rows[-1][5] == 1:  # a one-round-trip call: times only with the events
+                assert (float(t.total_ms) > 0.0) == events and (float(t.lanes_ms) > 0.0) == events, (name, lo, hi, float(t.total_ms))
+            else:
+                assert float(t.total_ms) > 0.0
+        assert [r[5] for r in rows[1:]] == [1, 1, 1, 1], (name, rows)
+        counts[name] = rows
+        eng.close()
+    for name in counts:
+        assert counts[name] == counts["old"], (name, counts[name], counts["old"])
+    assert all(r[1] > 0 and r[2] > 0 and r[3] > 0 and r[6] > 0 for r in counts["new"])
+    index.close()
