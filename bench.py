@@ -574,7 +574,7 @@ def stream_main(args, cfg, dev, dev_index, chunk_reads):
                      "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(algo_per_call * share),
                      "kernel_ms": dom_ms, "launches_per_step": len(descs), "enumerate_ms": float(np.sum(times["enum"])) / n_calls,
                      "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"], "lift_big_ms": kms["k_lift_big"],
-                     "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms["k_lift_lanes_g"], "heavy_kernel": heavy_name},
+                     "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms["k_lift_lanes_g"], "heavy_kernel": heavy_name if agg.get("heavy_kernel", 0) else None},
     }
     one.close()
     if args.overlap_workers > 1:
@@ -980,7 +980,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(algo_bytes * share), "kernel_ms": dom_ms,
                          "enumerate_ms": float(np.mean(times["enum"])), "enumerate_pass": enum_obj, "lift_lanes_ms": kms["k_lift_lanes"], "lift_tiles_ms": kms["k_lift_tiles"],
-                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms[heavy_name], "heavy_kernel": heavy_name,
+                         "lift_big_ms": kms["k_lift_big"], "lift_mid_ms": kms["k_lift_mid"], "lift_retry_ms": kms["k_lift_retry"], "lift_heavy_ms": kms[heavy_name], "heavy_kernel": heavy_name if int(tm.heavy_kernel) else None,
                          "lane_utilisation": stats["lane_utilisation"],  # lanes at work / (64 x trips) of the lane kernels' liftover loop and shift rounds
                          "statistics_from": "one call of the counting kernel outside the timed region (plo_ctx_set_stats); the timed kernel carries no counters",
                          "lanes_ms_counting_kernel": stats["lanes_ms_counting_kernel"],
