@@ -111,3 +111,10 @@ def test_fails_loudly_without_gpu(lib_path):
     with pytest.raises(api.PortelloError) as ei:
         cs.run(abi.STAGE_LIFTOVER)
     assert ei.value.status == abi.PLO_ERR_NO_DEVICE
+
+
+def test_integration_doc_binds_every_declared_symbol():
+    """INTEGRATION.md shows the reference-side binding a maintainer would add: every entry point the headers declare appears in it"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in declared_symbols() if not re.search(r"\b" + s + r"\b", doc)]
+    assert not missing, missing
