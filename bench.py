@@ -97,7 +97,9 @@ def cpu_baseline(w, got, budget_s: float = 12.0, ixd=None):
     pyoracle.liftover_batch(ixd, w.batch_data(0, probe), abi.STAGES_ALL, 1)
     rate1 = probe / max(1e-4, time.perf_counter() - t0)
     return {"value": n_done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "block_map": "array-based (sorted key / value arrays + bisection): faster than the reference's BTreeMap -- the baseline errs on the conservative side",
+            "block_map": "array-based (sorted key / value arrays + bisection): no slower than the reference's BTreeMap -- the baseline errs on the conservative side; "
+                         "the look-ups are a few per cent of its time either way (three bisections per alignment-match op against ~60 us per read; nine look-ups "
+                         "instead of one did not move the single-thread time beyond run-to-run noise, DESIGN section 6)",
             "sample": f"{n_blocks} blocks of {block} consecutive reads spread evenly over the read set ({n_done} reads), "
                       f"oracle/liboracle.so = C restatement of the reference algorithm, not the reference binary (sorted-array block "
                       f"maps with bisection where the reference has a BTreeMap; segments split evenly over {cores} pthreads where the "
